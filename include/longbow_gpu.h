@@ -1,0 +1,182 @@
+/*
+ * longbow_gpu.h -- C ABI of liblongbow_gpu.so: the MI355X (gfx950) k-NN
+ * distance / top-k / PQ-ADC backend that drops in behind Longbow's
+ * internal/gpu plug-point and keeps internal/simd's metric semantics.
+ *
+ * Plain pointers and sizes only; every call returns an lb_status code (0 = ok)
+ * and never aborts the process (reference convention: non-zero -> Go
+ * fmt.Errorf("... code %d"), NULL handle = init failure;
+ * internal/gpu/faiss_gpu.go:56-66,99-101,134-137).
+ *
+ * Each entry point cites the reference interface it replaces
+ * (paths relative to 23skdu/longbow).  The cgo stub a maintainer adds is in
+ * INTEGRATION.md and go/internal/gpu/hip_gpu.go.
+ *
+ * Pointer naming: plain names are HOST pointers, borrowed for the call only
+ * (cgo pointer rules: the library copies/DMAs during the call and retains
+ * nothing).  `d_` names are DEVICE (HBM) pointers on the index's device.
+ */
+#ifndef LONGBOW_GPU_H
+#define LONGBOW_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* simd.MetricType values (internal/simd/registry.go:8-15); search returns the
+ * value Longbow ranks by, ascending: L2 with sqrt, 1-cos, NEGATED dot
+ * (internal/store/distance_resolvers.go:12-16,74-83). */
+typedef enum {
+    LB_METRIC_EUCLIDEAN = 0,
+    LB_METRIC_COSINE = 1,
+    LB_METRIC_DOT = 2
+} lb_metric;
+
+/* f32 accumulation order of the reported distances (both exist in the reference):
+ * SEQ     one accumulator, i ascending (internal/simd/simd_test.go:13-33,
+ *         simd.go:138-163) -- the canonical oracle order, default;
+ * UNROLL4 four accumulators (internal/simd/simd.go:365-479,
+ *         distance_functions.go:195-227) -- what EuclideanDistanceBatchFlat runs. */
+typedef enum { LB_ORDER_SEQ = 0, LB_ORDER_UNROLL4 = 1 } lb_order;
+
+typedef enum {
+    LB_OK = 0,
+    LB_ERR_INVALID_ARG = 1, /* NULL / negative / mismatched sizes                  */
+    LB_ERR_CLOSED = 2,      /* "index is closed" (faiss_gpu.go:79,111)             */
+    LB_ERR_NO_DEVICE = 3,   /* no HIP device / bad device id (ErrGPUNotAvailable)   */
+    LB_ERR_HIP = 4,         /* a HIP runtime call failed; see lb_gpu_last_error     */
+    LB_ERR_OOM = 5,         /* HBM or pinned-host allocation failed                 */
+    LB_ERR_UNSUPPORTED = 6, /* e.g. PQ with K != 256 (simd.go:350 stride)           */
+    LB_ERR_INTERNAL = 7
+} lb_status;
+
+typedef struct lb_gpu_index lb_gpu_index; /* opaque; replaces FaissGpuResourcesPtr +
+                                             FaissGpuIndexFlatL2Ptr (faiss_gpu.go:12-13) */
+
+/* ---- library ------------------------------------------------------------ */
+int lb_gpu_device_count(void);          /* 0 when no GPU is visible; never fails */
+const char *lb_gpu_version(void);
+const char *lb_gpu_status_string(int status);
+
+/* ---- gpu.Index: NewIndexWithConfig / Add / Search / Close ------------------
+ * Replaces faiss_gpu_resources_new + faiss_gpu_index_flat_l2_new
+ * (internal/gpu/faiss_gpu.go:16-19,44-72; interface.go:3-19).  dim <= 0 or an
+ * unknown metric -> NULL (gpu_test.go:49-55).  out_status (nullable) receives
+ * the reason. */
+lb_gpu_index *lb_gpu_index_new(int device, int dim, int metric, int *out_status);
+
+/* Close (faiss_gpu.go:147-167): frees HBM; idempotent on NULL. */
+void lb_gpu_index_free(lb_gpu_index *h);
+
+/* Text of the last failure on this handle ("" if none).  Valid until the next
+ * failing call on the same handle. */
+const char *lb_gpu_last_error(const lb_gpu_index *h);
+
+int lb_gpu_index_set_order(lb_gpu_index *h, int order);
+int64_t lb_gpu_index_ntotal(const lb_gpu_index *h);
+int lb_gpu_index_dim(const lb_gpu_index *h);
+
+/* Pre-size HBM for n_total rows (optional; add grows geometrically otherwise). */
+int lb_gpu_index_reserve(lb_gpu_index *h, int64_t n_total);
+
+/* Add (replaces faiss_gpu_index_add, faiss_gpu.go:20,75-104): APPENDS n rows of
+ * row-major f32[n*dim] -- the values buffer of an Arrow FixedSizeList<float32>
+ * column (internal/store/adaptive_index.go:276-315).  ids nullable: labels are
+ * then insertion positions (what the FAISS binding does, faiss_gpu.go:93-97).
+ * The host buffer is staged through library-owned pinned memory and DMA'd. */
+int lb_gpu_index_add(lb_gpu_index *h, int64_t n, const float *vectors, const int64_t *ids);
+/* Same with the rows already in HBM on the index's device (D2D append). */
+int lb_gpu_index_add_device(lb_gpu_index *h, int64_t n, const float *d_vectors,
+                            const int64_t *d_ids);
+
+/* Search (replaces faiss_gpu_index_search, faiss_gpu.go:21,107-144; semantics of
+ * BruteForceIndex.SearchVectors, internal/store/adaptive_index.go:161-225):
+ * exact k-NN of nq queries, results ascending by (distance, row position).
+ * dist/labels are nq*k; fewer than k hits -> label -1 / dist FLT_MAX padding.
+ * Thread-safe for concurrent calls on one handle (faiss_gpu.go:108 RLock). */
+int lb_gpu_index_search(lb_gpu_index *h, int64_t nq, const float *queries, int k,
+                        float *dist, int64_t *labels);
+/* Queries and results resident in HBM; `stream` is a hipStream_t (NULL = the
+ * library's own).  Results are complete when the call returns. */
+int lb_gpu_index_search_device(lb_gpu_index *h, int64_t nq, const float *d_queries, int k,
+                               float *d_dist, int64_t *d_labels, void *stream);
+
+/* Metadata predicate mask for filtered search (SURVEY f-3; byte-per-row 0/1 as
+ * internal/query/filter_evaluator.go:79-115 produces).  mask has ntotal bytes;
+ * NULL clears it.  Rows with mask 0 never appear in results. */
+int lb_gpu_index_set_filter(lb_gpu_index *h, const uint8_t *mask, int64_t n);
+
+/* Per-search telemetry of the most recent search on this handle (for benches):
+ * number of queries that needed the exact-scan fallback. */
+int64_t lb_gpu_index_last_fallbacks(const lb_gpu_index *h);
+
+/* ---- internal/simd batch interface on the GPU --------------------------------
+ * simd.EuclideanDistanceBatchFlat / CosineDistanceBatch / DotProductBatch
+ * (internal/simd/batch_operations.go:64-87,131-157): one query x n rows of
+ * flat[n*dims] -> results[n], in the requested accumulation order, bit-exact
+ * with the scalar formulas.  metric DOT returns the RAW dot product here (as
+ * simd.DotProduct does, distance_functions.go:59-73), not the negated value. */
+int lb_simd_distance_batch_flat(int device, int metric, int order, const float *query,
+                                const float *flat, int64_t n, int dims, float *results);
+int lb_simd_distance_batch_flat_device(int device, int metric, int order, const float *d_query,
+                                       const float *d_flat, int64_t n, int dims,
+                                       float *d_results, void *stream);
+
+/* ---- internal/pq on the GPU ---------------------------------------------------
+ * Codebooks arrive as the reference's serialised blob (internal/pq/persistence.go:9-35:
+ * u32 LE dims, M, K, then M*K*SubDim f32 LE).  K must be 256 (simd.go:350). */
+typedef struct lb_gpu_pq lb_gpu_pq;
+lb_gpu_pq *lb_gpu_pq_new(int device, const uint8_t *codebook_blob, size_t len, int *out_status);
+void lb_gpu_pq_free(lb_gpu_pq *p);
+const char *lb_gpu_pq_last_error(const lb_gpu_pq *p);
+int lb_gpu_pq_m(const lb_gpu_pq *p);
+int lb_gpu_pq_dims(const lb_gpu_pq *p);
+int64_t lb_gpu_pq_ntotal(const lb_gpu_pq *p);
+/* Append n codes u8[n*M] (row-major, as pq.Encode emits them). */
+int lb_gpu_pq_add_codes(lb_gpu_pq *p, int64_t n, const uint8_t *codes);
+int lb_gpu_pq_add_codes_device(lb_gpu_pq *p, int64_t n, const uint8_t *d_codes);
+/* pq.BuildADCTable (internal/pq/adc_table.go:15-51): table f32[M*K] for one query. */
+int lb_gpu_pq_build_adc_table(lb_gpu_pq *p, const float *query, float *table);
+/* simd.ADCDistanceBatch (internal/simd/batch_operations.go:119-127, simd.go:345-355):
+ * results[i] = float32(sqrt(float64(sum_j table[j*256+codes[i*M+j]]))) over the stored codes
+ * rows [row0, row0+n). */
+int lb_gpu_pq_adc_distance_batch(lb_gpu_pq *p, const float *table, int64_t row0, int64_t n,
+                                 float *results);
+/* ADC k-NN over all stored codes: builds the table per query, scans, top-k ascending by
+ * (distance, position).  nq queries of f32[dims]. */
+int lb_gpu_pq_search(lb_gpu_pq *p, int64_t nq, const float *queries, int k, float *dist,
+                     int64_t *labels);
+int lb_gpu_pq_search_device(lb_gpu_pq *p, int64_t nq, const float *d_queries, int k,
+                            float *d_dist, int64_t *d_labels, void *stream);
+
+/* ---- cross-shard merge ---------------------------------------------------------
+ * store.MergeSortedStreams (internal/store/result_merger.go:34-101) for S shards:
+ * inputs [S][nq][k] ascending per (shard, query) (padding label -1 / FLT_MAX allowed),
+ * output [nq][k] ascending by (distance, label).  Device pointers. */
+int lb_gpu_merge_topk_device(int device, int nshards, int64_t nq, int k, const float *d_dist_in,
+                             const int64_t *d_labels_in, float *d_dist_out, int64_t *d_labels_out,
+                             void *stream);
+
+/* ---- synthetic data (bench / tests) ------------------------------------------------
+ * Counter-based uniform [0,1) f32 / uniform u8, bit-identical to the oracle's
+ * lbo_fill_uniform / lbo_fill_codes. */
+int lb_gpu_fill_uniform_device(int device, float *d_dst, int64_t n, uint64_t seed, int64_t offset,
+                               void *stream);
+int lb_gpu_fill_codes_device(int device, uint8_t *d_dst, int64_t n, uint64_t seed, int64_t offset,
+                             void *stream);
+
+/* ---- instrumentation (bench.py roofline leg) ----------------------------------------
+ * HIP-event timing of the dominant kernels of the most recent search on this handle,
+ * recorded on the stream the kernels ran on.  Enable before the search. */
+int lb_gpu_index_set_profiling(lb_gpu_index *h, int enable);
+/* ms spent in: [0] candidate GEMM kernels, [1] select kernels, [2] re-rank, [3] scan
+ * kernels, [4] whole search (device side).  n_launch[i] = launches of that class. */
+int lb_gpu_index_last_timing(const lb_gpu_index *h, float ms[5], int n_launch[5]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,109 @@
+"""ctypes loader for liblongbow_gpu.so -- the only place the library is opened.
+
+Fails loudly: a missing/unloadable library raises ImportError-like RuntimeError at
+first use; a missing GPU raises GPUNotAvailable (the reference's ErrGPUNotAvailable,
+internal/gpu/stub.go:10).  Nothing here ever computes on the CPU.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "liblongbow_gpu.so")
+
+LB_OK = 0
+STATUS = {0: "ok", 1: "invalid argument", 2: "index is closed", 3: "GPU not available",
+          4: "HIP runtime error", 5: "out of device memory", 6: "unsupported configuration",
+          7: "internal error"}
+
+
+class LongbowGPUError(RuntimeError):
+    def __init__(self, code, msg=""):
+        self.code = code
+        super().__init__(f"longbow_gpu: {STATUS.get(code, 'error')} (code {code}){': ' + msg if msg else ''}")
+
+
+class GPUNotAvailable(LongbowGPUError):
+    """internal/gpu/stub.go:10 ErrGPUNotAvailable"""
+
+
+_lib = None
+
+# every symbol include/longbow_gpu.h declares: (name, restype, argtypes)
+_vp, _i, _i64, _u64, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_size_t
+_ip = C.POINTER(C.c_int)
+SIGNATURES = [
+    ("lb_gpu_device_count", _i, []),
+    ("lb_gpu_version", C.c_char_p, []),
+    ("lb_gpu_status_string", C.c_char_p, [_i]),
+    ("lb_gpu_index_new", _vp, [_i, _i, _i, _ip]),
+    ("lb_gpu_index_free", None, [_vp]),
+    ("lb_gpu_last_error", C.c_char_p, [_vp]),
+    ("lb_gpu_index_set_order", _i, [_vp, _i]),
+    ("lb_gpu_index_ntotal", _i64, [_vp]),
+    ("lb_gpu_index_dim", _i, [_vp]),
+    ("lb_gpu_index_reserve", _i, [_vp, _i64]),
+    ("lb_gpu_index_add", _i, [_vp, _i64, _vp, _vp]),
+    ("lb_gpu_index_add_device", _i, [_vp, _i64, _vp, _vp]),
+    ("lb_gpu_index_search", _i, [_vp, _i64, _vp, _i, _vp, _vp]),
+    ("lb_gpu_index_search_device", _i, [_vp, _i64, _vp, _i, _vp, _vp, _vp]),
+    ("lb_gpu_index_set_filter", _i, [_vp, _vp, _i64]),
+    ("lb_gpu_index_last_fallbacks", _i64, [_vp]),
+    ("lb_simd_distance_batch_flat", _i, [_i, _i, _i, _vp, _vp, _i64, _i, _vp]),
+    ("lb_simd_distance_batch_flat_device", _i, [_i, _i, _i, _vp, _vp, _i64, _i, _vp, _vp]),
+    ("lb_gpu_pq_new", _vp, [_i, _vp, _sz, _ip]),
+    ("lb_gpu_pq_free", None, [_vp]),
+    ("lb_gpu_pq_last_error", C.c_char_p, [_vp]),
+    ("lb_gpu_pq_m", _i, [_vp]),
+    ("lb_gpu_pq_dims", _i, [_vp]),
+    ("lb_gpu_pq_ntotal", _i64, [_vp]),
+    ("lb_gpu_pq_add_codes", _i, [_vp, _i64, _vp]),
+    ("lb_gpu_pq_add_codes_device", _i, [_vp, _i64, _vp]),
+    ("lb_gpu_pq_build_adc_table", _i, [_vp, _vp, _vp]),
+    ("lb_gpu_pq_adc_distance_batch", _i, [_vp, _vp, _i64, _i64, _vp]),
+    ("lb_gpu_pq_search", _i, [_vp, _i64, _vp, _i, _vp, _vp]),
+    ("lb_gpu_pq_search_device", _i, [_vp, _i64, _vp, _i, _vp, _vp, _vp]),
+    ("lb_gpu_merge_topk_device", _i, [_i, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp]),
+    ("lb_gpu_fill_uniform_device", _i, [_i, _vp, _i64, _u64, _i64, _vp]),
+    ("lb_gpu_fill_codes_device", _i, [_i, _vp, _i64, _u64, _i64, _vp]),
+    ("lb_gpu_index_set_profiling", _i, [_vp, _i]),
+    ("lb_gpu_index_last_timing", _i, [_vp, _vp, _vp]),
+]
+
+
+def load():
+    """dlopen the HIP library and bind every declared symbol (no GPU needed for this)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError(
+            f"{SO_PATH} is missing: build it with `python -m longbow_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(SO_PATH)
+    for name, res, args in SIGNATURES:
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def require_gpu(device=0):
+    lib = load()
+    n = lib.lb_gpu_device_count()
+    if n <= 0 or device >= n:
+        raise GPUNotAvailable(3, f"{n} HIP device(s) visible, device {device} requested")
+    return lib
+
+
+def check(rc, handle=None, pq=False):
+    if rc == LB_OK:
+        return
+    msg = ""
+    if handle:
+        lib = load()
+        raw = lib.lb_gpu_pq_last_error(handle) if pq else lib.lb_gpu_last_error(handle)
+        msg = raw.decode() if raw else ""
+    if rc == 3:
+        raise GPUNotAvailable(rc, msg)
+    raise LongbowGPUError(rc, msg)

@@ -1,0 +1,787 @@
+// index.hip -- host side of liblongbow_gpu.so: the C ABI of include/longbow_gpu.h.
+//
+// Mirrors the contract of Longbow's gpu.Index (internal/gpu/interface.go:3-19) as
+// the FAISS binding realises it (internal/gpu/faiss_gpu.go:44-167): opaque handle,
+// int return codes, Add appends, Search is safe from many threads at once
+// (RWMutex: Add/Close exclusive, Search shared), nothing aborts the process.
+//
+// There is NO CPU fallback in this library: without a HIP device every entry point
+// returns LB_ERR_NO_DEVICE / NULL.
+#include "../../include/longbow_gpu.h"
+#include "lb_device.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cfloat>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <shared_mutex>
+#include <string>
+#include <vector>
+
+using namespace lb;
+
+namespace {
+
+constexpr int kScanMaxQ = 8;          // queries per scan launch (register accumulators)
+constexpr int kGemmMinQ = 17;         // below this the exact scan path is used for everything
+constexpr int kMaxBatch = 4096;       // queries per internal batch (workspace sizing)
+constexpr int64_t kChunk0 = 4096;     // bootstrap chunk: every row is admitted
+constexpr int64_t kChunk1 = 65536;    // second chunk: admits ~kc*ln(16)
+constexpr size_t kStageBytes = 32u << 20; // pinned staging slab (x2)
+
+struct HipErr {
+    hipError_t e;
+    const char *what;
+};
+
+#define LB_HIP(call)                                          \
+    do {                                                      \
+        hipError_t _e = (call);                               \
+        if (_e != hipSuccess) throw HipErr{_e, #call};        \
+    } while (0)
+
+struct Event {
+    hipEvent_t a = nullptr, b = nullptr;
+    int cls = 0;
+};
+
+struct Workspace {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int nq_cap = 0;
+    uint32_t cap = 0;
+    CandState cs{};
+    float *d_qna = nullptr;
+    int *d_qsel = nullptr;
+    uint32_t *h_flags = nullptr; // pinned
+    int *h_qsel = nullptr;       // pinned
+    // host-API staging (device side)
+    float *d_q = nullptr;
+    size_t d_q_bytes = 0;
+    float *d_dist = nullptr;
+    int64_t *d_lab = nullptr;
+    size_t d_out_n = 0;
+    std::vector<Event> events;
+    size_t ev_used = 0;
+
+    ~Workspace()
+    {
+        (void)hipSetDevice(device);
+        if (cs.lists) (void)hipFree(cs.lists);
+        if (cs.cnt) (void)hipFree(cs.cnt);
+        if (cs.tau) (void)hipFree(cs.tau);
+        if (cs.flags) (void)hipFree(cs.flags);
+        if (d_qna) (void)hipFree(d_qna);
+        if (d_qsel) (void)hipFree(d_qsel);
+        if (h_flags) (void)hipHostFree(h_flags);
+        if (h_qsel) (void)hipHostFree(h_qsel);
+        if (d_q) (void)hipFree(d_q);
+        if (d_dist) (void)hipFree(d_dist);
+        if (d_lab) (void)hipFree(d_lab);
+        for (auto &e : events) {
+            if (e.a) (void)hipEventDestroy(e.a);
+            if (e.b) (void)hipEventDestroy(e.b);
+        }
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+} // namespace
+
+struct lb_gpu_index {
+    int device = 0, dim = 0, metric = 0;
+    std::atomic<int> order{LB_ORDER_SEQ};
+    std::shared_mutex mu;
+    bool closed = false;
+
+    float *d_X = nullptr;
+    int64_t n = 0, capacity = 0;
+    float *d_norm2 = nullptr, *d_rnorm = nullptr;
+    uint32_t *d_maxnorm2 = nullptr;
+    int64_t *d_ids = nullptr;
+    bool has_ids = false;
+    uint8_t *d_mask = nullptr;
+    bool has_mask = false;
+
+    hipStream_t add_stream = nullptr;
+    void *h_stage[2] = {nullptr, nullptr};
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
+
+    std::mutex ws_mu;
+    std::vector<std::unique_ptr<Workspace>> ws_free;
+
+    mutable std::mutex err_mu;
+    std::string last_error;
+
+    std::atomic<int64_t> last_fallbacks{0};
+    std::atomic<int> profiling{0};
+    std::mutex prof_mu;
+    float prof_ms[5] = {0, 0, 0, 0, 0};
+    int prof_n[5] = {0, 0, 0, 0, 0};
+
+    void set_error(const char *fmt, ...)
+    {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        std::lock_guard<std::mutex> g(err_mu);
+        last_error = buf;
+    }
+};
+
+namespace {
+
+int fail_hip(lb_gpu_index *h, const HipErr &e)
+{
+    h->set_error("HIP error %d (%s) in %s", (int)e.e, hipGetErrorString(e.e), e.what);
+    return (e.e == hipErrorOutOfMemory) ? LB_ERR_OOM : LB_ERR_HIP;
+}
+
+// candidate-list geometry for a request of k
+void cand_geometry(int k, int &kc, uint32_t &cap)
+{
+    int want = std::max(2 * k, k + 32);
+    kc = (int)next_pow2_host((uint32_t)std::max(want, 64));
+    cap = std::max<uint32_t>(8192u, 4u * (uint32_t)kc);
+}
+
+std::unique_ptr<Workspace> acquire_ws(lb_gpu_index *h, int nq, uint32_t cap)
+{
+    {
+        std::lock_guard<std::mutex> g(h->ws_mu);
+        for (size_t i = 0; i < h->ws_free.size(); i++) {
+            if (h->ws_free[i]->nq_cap >= nq && h->ws_free[i]->cap == cap) {
+                auto w = std::move(h->ws_free[i]);
+                h->ws_free.erase(h->ws_free.begin() + (long)i);
+                return w;
+            }
+        }
+    }
+    auto w = std::make_unique<Workspace>();
+    w->device = h->device;
+    w->nq_cap = std::max(nq, 8);
+    w->cap = cap;
+    w->cs.cap = cap;
+    LB_HIP(hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking));
+    LB_HIP(hipMalloc(&w->cs.lists, (size_t)w->nq_cap * cap * sizeof(uint64_t)));
+    LB_HIP(hipMalloc(&w->cs.cnt, (size_t)w->nq_cap * sizeof(uint32_t)));
+    LB_HIP(hipMalloc(&w->cs.tau, (size_t)w->nq_cap * sizeof(uint64_t)));
+    LB_HIP(hipMalloc(&w->cs.flags, (size_t)w->nq_cap * sizeof(uint32_t)));
+    LB_HIP(hipMalloc(&w->d_qna, (size_t)w->nq_cap * sizeof(float)));
+    LB_HIP(hipMalloc(&w->d_qsel, (size_t)w->nq_cap * sizeof(int)));
+    LB_HIP(hipHostMalloc(&w->h_flags, (size_t)w->nq_cap * sizeof(uint32_t), hipHostMallocDefault));
+    LB_HIP(hipHostMalloc(&w->h_qsel, (size_t)w->nq_cap * sizeof(int), hipHostMallocDefault));
+    return w;
+}
+
+void release_ws(lb_gpu_index *h, std::unique_ptr<Workspace> w)
+{
+    std::lock_guard<std::mutex> g(h->ws_mu);
+    if (h->ws_free.size() < 8) h->ws_free.push_back(std::move(w));
+}
+
+struct ProfScope {
+    Workspace *w;
+    hipStream_t s;
+    bool on;
+    size_t idx = 0;
+    ProfScope(Workspace *w_, hipStream_t s_, bool on_, int cls) : w(w_), s(s_), on(on_)
+    {
+        if (!on) return;
+        if (w->ev_used == w->events.size()) {
+            Event e;
+            if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) {
+                on = false;
+                return;
+            }
+            w->events.push_back(e);
+        }
+        idx = w->ev_used++;
+        w->events[idx].cls = cls;
+        (void)hipEventRecord(w->events[idx].a, s);
+    }
+    ~ProfScope()
+    {
+        if (on) (void)hipEventRecord(w->events[idx].b, s);
+    }
+};
+
+// Exact scan of all rows for the query slots sel[0..nsel) (indices into d_q rows).
+// safe=false: 3 chunks (bootstrap / 64k / rest); safe=true: chunks that cannot overflow.
+void run_scan_path(lb_gpu_index *h, Workspace *w, hipStream_t s, const float *d_q, const int *d_sel,
+                   int nsel, int k, bool safe, float *d_dist, int64_t *d_lab, bool prof)
+{
+    const int metric = h->metric, order = h->order.load();
+    const int64_t n = h->n;
+    const uint8_t *mask = h->has_mask ? h->d_mask : nullptr;
+    const int kkeep = std::max(k, 1);
+    launch_init_cand(w->cs, d_sel, nsel, s);
+    for (int g0 = 0; g0 < nsel; g0 += kScanMaxQ) {
+        const int gn = std::min(kScanMaxQ, nsel - g0);
+        const int *use_sel = d_sel + g0; // d_sel is always an explicit slot list here
+        if (metric == LB_METRIC_COSINE) {
+            ProfScope p(w, s, prof, 3);
+            launch_query_norms(order, d_q, use_sel, gn, h->dim, w->d_qna, s);
+        }
+        int64_t pos = 0;
+        int step = 0;
+        while (pos < n) {
+            int64_t end;
+            if (safe) end = std::min<int64_t>(n, pos + (int64_t)(w->cap - (uint32_t)kkeep));
+            else end = step == 0 ? std::min(n, kChunk0) : step == 1 ? std::min(n, kChunk1) : n;
+            {
+                ProfScope p(w, s, prof, 3);
+                launch_scan(metric, order, false, h->d_X, pos, end, h->dim, d_q, use_sel, gn, w->d_qna,
+                            mask, w->cs, nullptr, 0, s);
+            }
+            {
+                ProfScope p(w, s, prof, 1);
+                launch_select(w->cs, use_sel, gn, kkeep, s);
+            }
+            pos = end;
+            step++;
+        }
+        launch_emit_lists(w->cs, use_sel, gn, k, h->has_ids ? h->d_ids : nullptr, d_dist, d_lab, s);
+    }
+}
+
+// download flags for slots [0,nq) and return those with any of `bits` set
+int collect_flagged(Workspace *w, hipStream_t s, int nq, uint32_t bits, const int *h_subset,
+                    int nsubset, std::vector<int> &out)
+{
+    LB_HIP(hipMemcpyAsync(w->h_flags, w->cs.flags, (size_t)nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    LB_HIP(hipStreamSynchronize(s));
+    out.clear();
+    if (h_subset) {
+        for (int i = 0; i < nsubset; i++)
+            if (w->h_flags[h_subset[i]] & bits) out.push_back(h_subset[i]);
+    } else {
+        for (int i = 0; i < nq; i++)
+            if (w->h_flags[i] & bits) out.push_back(i);
+    }
+    return (int)out.size();
+}
+
+void upload_sel(Workspace *w, hipStream_t s, const std::vector<int> &sel)
+{
+    std::memcpy(w->h_qsel, sel.data(), sel.size() * sizeof(int));
+    LB_HIP(hipMemcpyAsync(w->d_qsel, w->h_qsel, sel.size() * sizeof(int), hipMemcpyHostToDevice, s));
+}
+
+void scan_with_retry(lb_gpu_index *h, Workspace *w, hipStream_t s, const float *d_q, int nq_total,
+                     const std::vector<int> &sel, int k, float *d_dist, int64_t *d_lab, bool prof)
+{
+    if (sel.empty()) return;
+    upload_sel(w, s, sel);
+    run_scan_path(h, w, s, d_q, w->d_qsel, (int)sel.size(), k, false, d_dist, d_lab, prof);
+    std::vector<int> over;
+    if (collect_flagged(w, s, nq_total, 1u, sel.data(), (int)sel.size(), over) > 0) {
+        upload_sel(w, s, over);
+        run_scan_path(h, w, s, d_q, w->d_qsel, (int)over.size(), k, true, d_dist, d_lab, prof);
+        LB_HIP(hipStreamSynchronize(s));
+    }
+}
+
+int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, const float *d_q, int k,
+                        float *d_dist, int64_t *d_lab, int kc, bool prof, int64_t &fallbacks)
+{
+    const int metric = h->metric, order = h->order.load();
+    const int64_t n = h->n;
+    const uint8_t *mask = h->has_mask ? h->d_mask : nullptr;
+    ProfScope whole(w, s, prof, 4);
+
+    if (nq < kGemmMinQ) {
+        std::vector<int> all(nq);
+        for (int i = 0; i < nq; i++) all[i] = i;
+        scan_with_retry(h, w, s, d_q, nq, all, k, d_dist, d_lab, prof);
+        return LB_OK;
+    }
+
+    // ---- batched path: MFMA candidate generation + exact re-rank --------------------
+    launch_init_cand(w->cs, nullptr, nq, s);
+    if (metric == LB_METRIC_COSINE) launch_query_norms(order, d_q, nullptr, nq, h->dim, w->d_qna, s);
+    int64_t pos = 0;
+    int step = 0;
+    while (pos < n) {
+        const int64_t end = step == 0 ? std::min(n, kChunk0) : step == 1 ? std::min(n, kChunk1) : n;
+        {
+            ProfScope p(w, s, prof, 0);
+            launch_gemm_filter(metric, h->d_X, h->d_norm2, h->d_rnorm, pos, end, h->dim, d_q, nq, mask,
+                               w->cs, s);
+        }
+        {
+            ProfScope p(w, s, prof, 1);
+            launch_select(w->cs, nullptr, nq, kc, s);
+        }
+        pos = end;
+        step++;
+    }
+    {
+        ProfScope p(w, s, prof, 2);
+        launch_rerank(metric, order, h->d_X, h->dim, d_q, nq, w->d_qna, w->cs, kc, k, h->d_maxnorm2,
+                      h->has_ids ? h->d_ids : nullptr, d_dist, d_lab, s);
+    }
+    std::vector<int> bad;
+    if (collect_flagged(w, s, nq, 3u, nullptr, 0, bad) > 0) {
+        fallbacks += (int64_t)bad.size();
+        scan_with_retry(h, w, s, d_q, nq, bad, k, d_dist, d_lab, prof);
+    }
+    return LB_OK;
+}
+
+__global__ void fill_empty_kernel(float *dist, int64_t *lab, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        dist[i] = FLT_MAX;
+        lab[i] = -1;
+    }
+}
+
+void finish_profile(lb_gpu_index *h, Workspace *w)
+{
+    float ms[5] = {0, 0, 0, 0, 0};
+    int cnt[5] = {0, 0, 0, 0, 0};
+    for (size_t i = 0; i < w->ev_used; i++) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, w->events[i].a, w->events[i].b) == hipSuccess) {
+            ms[w->events[i].cls] += t;
+            cnt[w->events[i].cls]++;
+        }
+    }
+    w->ev_used = 0;
+    std::lock_guard<std::mutex> g(h->prof_mu);
+    for (int i = 0; i < 5; i++) {
+        h->prof_ms[i] = ms[i];
+        h->prof_n[i] = cnt[i];
+    }
+}
+
+int grow(lb_gpu_index *h, int64_t need)
+{
+    if (need <= h->capacity) return LB_OK;
+    int64_t cap = std::max<int64_t>(need, h->capacity * 2);
+    cap = std::max<int64_t>(cap, 1024);
+    float *nx = nullptr, *n2 = nullptr, *rn = nullptr;
+    int64_t *ni = nullptr;
+    uint8_t *nm = nullptr;
+    const size_t row_bytes = (size_t)h->dim * sizeof(float);
+    LB_HIP(hipMalloc(&nx, (size_t)cap * row_bytes));
+    LB_HIP(hipMalloc(&n2, (size_t)cap * sizeof(float)));
+    LB_HIP(hipMalloc(&rn, (size_t)cap * sizeof(float)));
+    LB_HIP(hipMalloc(&ni, (size_t)cap * sizeof(int64_t)));
+    LB_HIP(hipMalloc(&nm, (size_t)cap));
+    if (h->n > 0) {
+        LB_HIP(hipMemcpyAsync(nx, h->d_X, (size_t)h->n * row_bytes, hipMemcpyDeviceToDevice, h->add_stream));
+        LB_HIP(hipMemcpyAsync(n2, h->d_norm2, (size_t)h->n * sizeof(float), hipMemcpyDeviceToDevice, h->add_stream));
+        LB_HIP(hipMemcpyAsync(rn, h->d_rnorm, (size_t)h->n * sizeof(float), hipMemcpyDeviceToDevice, h->add_stream));
+        LB_HIP(hipMemcpyAsync(ni, h->d_ids, (size_t)h->n * sizeof(int64_t), hipMemcpyDeviceToDevice, h->add_stream));
+        LB_HIP(hipMemcpyAsync(nm, h->d_mask, (size_t)h->n, hipMemcpyDeviceToDevice, h->add_stream));
+        LB_HIP(hipStreamSynchronize(h->add_stream));
+    }
+    if (h->d_X) (void)hipFree(h->d_X);
+    if (h->d_norm2) (void)hipFree(h->d_norm2);
+    if (h->d_rnorm) (void)hipFree(h->d_rnorm);
+    if (h->d_ids) (void)hipFree(h->d_ids);
+    if (h->d_mask) (void)hipFree(h->d_mask);
+    h->d_X = nx; h->d_norm2 = n2; h->d_rnorm = rn; h->d_ids = ni; h->d_mask = nm;
+    h->capacity = cap;
+    return LB_OK;
+}
+
+__global__ void iota_ids_kernel(int64_t *ids, int64_t start, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ids[start + i] = start + i;
+}
+
+// Rows [h->n, h->n + n) are already in d_X; finish the append (norms, ids, mask).
+void finish_add(lb_gpu_index *h, int64_t n, const int64_t *ids_src, bool ids_on_device)
+{
+    hipStream_t s = h->add_stream;
+    const int64_t start = h->n;
+    launch_row_norms(h->d_X + (size_t)start * h->dim, n, h->dim, h->d_norm2 + start, h->d_rnorm + start,
+                     h->d_maxnorm2, s);
+    if (ids_src) {
+        if (!h->has_ids && start > 0)
+            hipLaunchKernelGGL(iota_ids_kernel, dim3((unsigned)((start + 255) / 256)), dim3(256), 0, s, h->d_ids,
+                               (int64_t)0, start);
+        LB_HIP(hipMemcpyAsync(h->d_ids + start, ids_src, (size_t)n * sizeof(int64_t),
+                              ids_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+        h->has_ids = true;
+    } else if (h->has_ids) {
+        hipLaunchKernelGGL(iota_ids_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->d_ids, start, n);
+    }
+    LB_HIP(hipMemsetAsync(h->d_mask + start, 1, (size_t)n, s));
+    LB_HIP(hipStreamSynchronize(s));
+    h->n += n;
+}
+
+bool device_ok(int device)
+{
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess) return false;
+    return device >= 0 && device < cnt;
+}
+
+} // namespace
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+extern "C" {
+
+int lb_gpu_device_count(void)
+{
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;
+    return cnt;
+}
+
+const char *lb_gpu_version(void) { return "longbow_gpu 0.1.0 (gfx950, HIP)"; }
+
+const char *lb_gpu_status_string(int status)
+{
+    switch (status) {
+    case LB_OK: return "ok";
+    case LB_ERR_INVALID_ARG: return "invalid argument";
+    case LB_ERR_CLOSED: return "index is closed";
+    case LB_ERR_NO_DEVICE: return "GPU not available";
+    case LB_ERR_HIP: return "HIP runtime error";
+    case LB_ERR_OOM: return "out of device memory";
+    case LB_ERR_UNSUPPORTED: return "unsupported configuration";
+    default: return "internal error";
+    }
+}
+
+lb_gpu_index *lb_gpu_index_new(int device, int dim, int metric, int *out_status)
+{
+    auto st = [&](int v) { if (out_status) *out_status = v; };
+    if (dim <= 0 || metric < 0 || metric > 2) { st(LB_ERR_INVALID_ARG); return nullptr; }
+    if (!device_ok(device)) { st(LB_ERR_NO_DEVICE); return nullptr; }
+    auto *h = new (std::nothrow) lb_gpu_index();
+    if (!h) { st(LB_ERR_OOM); return nullptr; }
+    h->device = device; h->dim = dim; h->metric = metric;
+    try {
+        LB_HIP(hipSetDevice(device));
+        LB_HIP(hipStreamCreateWithFlags(&h->add_stream, hipStreamNonBlocking));
+        LB_HIP(hipMalloc(&h->d_maxnorm2, sizeof(uint32_t)));
+        LB_HIP(hipMemset(h->d_maxnorm2, 0, sizeof(uint32_t)));
+    } catch (const HipErr &e) {
+        st(e.e == hipErrorOutOfMemory ? LB_ERR_OOM : LB_ERR_HIP);
+        lb_gpu_index_free(h);
+        return nullptr;
+    }
+    st(LB_OK);
+    return h;
+}
+
+void lb_gpu_index_free(lb_gpu_index *h)
+{
+    if (!h) return;
+    {
+        std::unique_lock<std::shared_mutex> g(h->mu);
+        h->closed = true;
+        (void)hipSetDevice(h->device);
+        (void)hipDeviceSynchronize();
+        {
+            std::lock_guard<std::mutex> g2(h->ws_mu);
+            h->ws_free.clear();
+        }
+        if (h->d_X) (void)hipFree(h->d_X);
+        if (h->d_norm2) (void)hipFree(h->d_norm2);
+        if (h->d_rnorm) (void)hipFree(h->d_rnorm);
+        if (h->d_ids) (void)hipFree(h->d_ids);
+        if (h->d_mask) (void)hipFree(h->d_mask);
+        if (h->d_maxnorm2) (void)hipFree(h->d_maxnorm2);
+        for (int i = 0; i < 2; i++) {
+            if (h->h_stage[i]) (void)hipHostFree(h->h_stage[i]);
+            if (h->stage_ev[i]) (void)hipEventDestroy(h->stage_ev[i]);
+        }
+        if (h->add_stream) (void)hipStreamDestroy(h->add_stream);
+    }
+    delete h;
+}
+
+const char *lb_gpu_last_error(const lb_gpu_index *h)
+{
+    if (!h) return "null handle";
+    std::lock_guard<std::mutex> g(h->err_mu);
+    return h->last_error.c_str();
+}
+
+int lb_gpu_index_set_order(lb_gpu_index *h, int order)
+{
+    if (!h || (order != LB_ORDER_SEQ && order != LB_ORDER_UNROLL4)) return LB_ERR_INVALID_ARG;
+    h->order.store(order);
+    return LB_OK;
+}
+
+int64_t lb_gpu_index_ntotal(const lb_gpu_index *h) { return h ? h->n : 0; }
+int lb_gpu_index_dim(const lb_gpu_index *h) { return h ? h->dim : 0; }
+
+int lb_gpu_index_reserve(lb_gpu_index *h, int64_t n_total)
+{
+    if (!h || n_total < 0) return LB_ERR_INVALID_ARG;
+    std::unique_lock<std::shared_mutex> g(h->mu);
+    if (h->closed) return LB_ERR_CLOSED;
+    try {
+        LB_HIP(hipSetDevice(h->device));
+        return grow(h, n_total);
+    } catch (const HipErr &e) {
+        return fail_hip(h, e);
+    }
+}
+
+int lb_gpu_index_add(lb_gpu_index *h, int64_t n, const float *vectors, const int64_t *ids)
+{
+    if (!h || n < 0 || (n > 0 && !vectors)) return LB_ERR_INVALID_ARG;
+    std::unique_lock<std::shared_mutex> g(h->mu);
+    if (h->closed) { h->set_error("index is closed"); return LB_ERR_CLOSED; }
+    if (n == 0) return LB_OK;
+    if (h->n + n > (int64_t)0xffffffffll) { h->set_error("more than 2^32 rows per device"); return LB_ERR_UNSUPPORTED; }
+    try {
+        LB_HIP(hipSetDevice(h->device));
+        grow(h, h->n + n);
+        for (int i = 0; i < 2; i++) {
+            if (!h->h_stage[i]) LB_HIP(hipHostMalloc(&h->h_stage[i], kStageBytes, hipHostMallocDefault));
+            if (!h->stage_ev[i]) LB_HIP(hipEventCreateWithFlags(&h->stage_ev[i], hipEventDisableTiming));
+        }
+        // host buffer -> pinned slab (memcpy) -> HBM (async DMA), two slabs in flight
+        const size_t total = (size_t)n * h->dim * sizeof(float);
+        const char *src = reinterpret_cast<const char *>(vectors);
+        char *dst = reinterpret_cast<char *>(h->d_X + (size_t)h->n * h->dim);
+        size_t off = 0;
+        int slab = 0;
+        bool used[2] = {false, false};
+        while (off < total) {
+            const size_t len = std::min(kStageBytes, total - off);
+            if (used[slab]) LB_HIP(hipEventSynchronize(h->stage_ev[slab]));
+            std::memcpy(h->h_stage[slab], src + off, len);
+            LB_HIP(hipMemcpyAsync(dst + off, h->h_stage[slab], len, hipMemcpyHostToDevice, h->add_stream));
+            LB_HIP(hipEventRecord(h->stage_ev[slab], h->add_stream));
+            used[slab] = true;
+            slab ^= 1;
+            off += len;
+        }
+        finish_add(h, n, ids, false);
+    } catch (const HipErr &e) {
+        return fail_hip(h, e);
+    }
+    return LB_OK;
+}
+
+int lb_gpu_index_add_device(lb_gpu_index *h, int64_t n, const float *d_vectors, const int64_t *d_ids)
+{
+    if (!h || n < 0 || (n > 0 && !d_vectors)) return LB_ERR_INVALID_ARG;
+    std::unique_lock<std::shared_mutex> g(h->mu);
+    if (h->closed) { h->set_error("index is closed"); return LB_ERR_CLOSED; }
+    if (n == 0) return LB_OK;
+    if (h->n + n > (int64_t)0xffffffffll) { h->set_error("more than 2^32 rows per device"); return LB_ERR_UNSUPPORTED; }
+    try {
+        LB_HIP(hipSetDevice(h->device));
+        grow(h, h->n + n);
+        LB_HIP(hipMemcpyAsync(h->d_X + (size_t)h->n * h->dim, d_vectors, (size_t)n * h->dim * sizeof(float),
+                              hipMemcpyDeviceToDevice, h->add_stream));
+        finish_add(h, n, d_ids, true);
+    } catch (const HipErr &e) {
+        return fail_hip(h, e);
+    }
+    return LB_OK;
+}
+
+int lb_gpu_index_set_filter(lb_gpu_index *h, const uint8_t *mask, int64_t n)
+{
+    if (!h) return LB_ERR_INVALID_ARG;
+    std::unique_lock<std::shared_mutex> g(h->mu);
+    if (h->closed) return LB_ERR_CLOSED;
+    if (!mask) { h->has_mask = false; return LB_OK; }
+    if (n != h->n) { h->set_error("filter mask has %lld bytes, index has %lld rows", (long long)n, (long long)h->n); return LB_ERR_INVALID_ARG; }
+    try {
+        LB_HIP(hipSetDevice(h->device));
+        if (n > 0) LB_HIP(hipMemcpy(h->d_mask, mask, (size_t)n, hipMemcpyHostToDevice));
+        h->has_mask = true;
+    } catch (const HipErr &e) {
+        return fail_hip(h, e);
+    }
+    return LB_OK;
+}
+
+int64_t lb_gpu_index_last_fallbacks(const lb_gpu_index *h) { return h ? h->last_fallbacks.load() : 0; }
+
+int lb_gpu_index_search_device(lb_gpu_index *h, int64_t nq, const float *d_queries, int k, float *d_dist,
+                               int64_t *d_labels, void *stream)
+{
+    if (!h || nq < 0 || k <= 0 || (nq > 0 && (!d_queries || !d_dist || !d_labels))) return LB_ERR_INVALID_ARG;
+    std::shared_lock<std::shared_mutex> g(h->mu);
+    if (h->closed) { h->set_error("index is closed"); return LB_ERR_CLOSED; }
+    if (nq == 0) return LB_OK;
+    if (k > 2048) { h->set_error("k=%d exceeds the supported maximum 2048", k); return LB_ERR_UNSUPPORTED; }
+    std::unique_ptr<Workspace> w;
+    try {
+        LB_HIP(hipSetDevice(h->device));
+        int kc;
+        uint32_t cap;
+        cand_geometry(k, kc, cap);
+        w = acquire_ws(h, (int)std::min<int64_t>(nq, kMaxBatch), cap);
+        hipStream_t s = stream ? (hipStream_t)stream : w->stream;
+        const bool prof = h->profiling.load() != 0;
+        w->ev_used = 0;
+        int64_t fallbacks = 0;
+        if (h->n == 0) {
+            const int64_t tot = nq * k;
+            hipLaunchKernelGGL(fill_empty_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, d_dist,
+                               d_labels, tot);
+        } else {
+            for (int64_t q0 = 0; q0 < nq; q0 += kMaxBatch) {
+                const int bq = (int)std::min<int64_t>(kMaxBatch, nq - q0);
+                int rc = search_batch_device(h, w.get(), s, bq, d_queries + (size_t)q0 * h->dim, k,
+                                             d_dist + (size_t)q0 * k, d_labels + (size_t)q0 * k, kc, prof, fallbacks);
+                if (rc != LB_OK) { release_ws(h, std::move(w)); return rc; }
+            }
+        }
+        LB_HIP(hipStreamSynchronize(s));
+        h->last_fallbacks.store(fallbacks);
+        if (prof) finish_profile(h, w.get());
+        release_ws(h, std::move(w));
+    } catch (const HipErr &e) {
+        return fail_hip(h, e);
+    }
+    return LB_OK;
+}
+
+int lb_gpu_index_search(lb_gpu_index *h, int64_t nq, const float *queries, int k, float *dist, int64_t *labels)
+{
+    if (!h || nq < 0 || k <= 0 || (nq > 0 && (!queries || !dist || !labels))) return LB_ERR_INVALID_ARG;
+    if (nq == 0) return LB_OK;
+    {
+        std::shared_lock<std::shared_mutex> g(h->mu);
+        if (h->closed) { h->set_error("index is closed"); return LB_ERR_CLOSED; }
+    }
+    // stage queries/results through device buffers owned by this call
+    float *d_q = nullptr, *d_d = nullptr;
+    int64_t *d_l = nullptr;
+    int rc = LB_OK;
+    try {
+        LB_HIP(hipSetDevice(h->device));
+        LB_HIP(hipMalloc(&d_q, (size_t)nq * h->dim * sizeof(float)));
+        LB_HIP(hipMalloc(&d_d, (size_t)nq * k * sizeof(float)));
+        LB_HIP(hipMalloc(&d_l, (size_t)nq * k * sizeof(int64_t)));
+        LB_HIP(hipMemcpy(d_q, queries, (size_t)nq * h->dim * sizeof(float), hipMemcpyHostToDevice));
+        rc = lb_gpu_index_search_device(h, nq, d_q, k, d_d, d_l, nullptr);
+        if (rc == LB_OK) {
+            LB_HIP(hipMemcpy(dist, d_d, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost));
+            LB_HIP(hipMemcpy(labels, d_l, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost));
+        }
+    } catch (const HipErr &e) {
+        rc = fail_hip(h, e);
+    }
+    if (d_q) (void)hipFree(d_q);
+    if (d_d) (void)hipFree(d_d);
+    if (d_l) (void)hipFree(d_l);
+    return rc;
+}
+
+int lb_gpu_index_set_profiling(lb_gpu_index *h, int enable)
+{
+    if (!h) return LB_ERR_INVALID_ARG;
+    h->profiling.store(enable ? 1 : 0);
+    return LB_OK;
+}
+
+int lb_gpu_index_last_timing(const lb_gpu_index *hc, float ms[5], int n_launch[5])
+{
+    if (!hc || !ms || !n_launch) return LB_ERR_INVALID_ARG;
+    auto *h = const_cast<lb_gpu_index *>(hc);
+    std::lock_guard<std::mutex> g(h->prof_mu);
+    for (int i = 0; i < 5; i++) { ms[i] = h->prof_ms[i]; n_launch[i] = h->prof_n[i]; }
+    return LB_OK;
+}
+
+// ---- simd batch interface ---------------------------------------------------------
+int lb_simd_distance_batch_flat_device(int device, int metric, int order, const float *d_query,
+                                       const float *d_flat, int64_t n, int dims, float *d_results, void *stream)
+{
+    if (metric < 0 || metric > 2 || (order != 0 && order != 1) || n < 0 || dims < 0) return LB_ERR_INVALID_ARG;
+    if (n == 0) return LB_OK; // batch_operations.go:65-67
+    if (!d_query || !d_flat || !d_results || dims == 0) return LB_ERR_INVALID_ARG;
+    if (!device_ok(device)) return LB_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return LB_ERR_HIP;
+    hipStream_t s = (hipStream_t)stream;
+    float *d_qna = nullptr;
+    if (metric == LB_METRIC_COSINE) {
+        if (hipMalloc(&d_qna, sizeof(float)) != hipSuccess) return LB_ERR_OOM;
+        launch_query_norms(order, d_query, nullptr, 1, dims, d_qna, s);
+    }
+    CandState cs{};
+    launch_scan(metric, order, /*raw_dot=*/true, d_flat, 0, n, dims, d_query, nullptr, 1, d_qna, nullptr, cs,
+                d_results, n, s);
+    hipError_t e = hipStreamSynchronize(s);
+    if (d_qna) (void)hipFree(d_qna);
+    return e == hipSuccess ? LB_OK : LB_ERR_HIP;
+}
+
+int lb_simd_distance_batch_flat(int device, int metric, int order, const float *query, const float *flat,
+                                int64_t n, int dims, float *results)
+{
+    if (metric < 0 || metric > 2 || (order != 0 && order != 1) || n < 0 || dims < 0) return LB_ERR_INVALID_ARG;
+    if (n == 0) return LB_OK;
+    if (!query || !flat || !results || dims == 0) return LB_ERR_INVALID_ARG;
+    if (!device_ok(device)) return LB_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return LB_ERR_HIP;
+    float *d_q = nullptr, *d_x = nullptr, *d_r = nullptr;
+    int rc = LB_OK;
+    if (hipMalloc(&d_q, (size_t)dims * 4) != hipSuccess || hipMalloc(&d_x, (size_t)n * dims * 4) != hipSuccess ||
+        hipMalloc(&d_r, (size_t)n * 4) != hipSuccess) {
+        rc = LB_ERR_OOM;
+    } else if (hipMemcpy(d_q, query, (size_t)dims * 4, hipMemcpyHostToDevice) != hipSuccess ||
+               hipMemcpy(d_x, flat, (size_t)n * dims * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        rc = LB_ERR_HIP;
+    } else {
+        rc = lb_simd_distance_batch_flat_device(device, metric, order, d_q, d_x, n, dims, d_r, nullptr);
+        if (rc == LB_OK && hipMemcpy(results, d_r, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = LB_ERR_HIP;
+    }
+    if (d_q) (void)hipFree(d_q);
+    if (d_x) (void)hipFree(d_x);
+    if (d_r) (void)hipFree(d_r);
+    return rc;
+}
+
+// ---- merge / fill -----------------------------------------------------------------
+int lb_gpu_merge_topk_device(int device, int nshards, int64_t nq, int k, const float *d_dist_in,
+                             const int64_t *d_labels_in, float *d_dist_out, int64_t *d_labels_out, void *stream)
+{
+    if (nshards <= 0 || nq < 0 || k <= 0 || (int64_t)nshards * k > 8192) return LB_ERR_INVALID_ARG;
+    if (nq == 0) return LB_OK;
+    if (!d_dist_in || !d_labels_in || !d_dist_out || !d_labels_out) return LB_ERR_INVALID_ARG;
+    if (!device_ok(device)) return LB_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return LB_ERR_HIP;
+    launch_merge_topk(nshards, nq, k, d_dist_in, d_labels_in, d_dist_out, d_labels_out, (hipStream_t)stream);
+    return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? LB_OK : LB_ERR_HIP;
+}
+
+int lb_gpu_fill_uniform_device(int device, float *d_dst, int64_t n, uint64_t seed, int64_t offset, void *stream)
+{
+    if (n < 0 || (n > 0 && !d_dst)) return LB_ERR_INVALID_ARG;
+    if (!device_ok(device)) return LB_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return LB_ERR_HIP;
+    launch_fill_uniform(d_dst, n, seed, offset, (hipStream_t)stream);
+    return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? LB_OK : LB_ERR_HIP;
+}
+
+int lb_gpu_fill_codes_device(int device, uint8_t *d_dst, int64_t n, uint64_t seed, int64_t offset, void *stream)
+{
+    if (n < 0 || (n > 0 && !d_dst)) return LB_ERR_INVALID_ARG;
+    if (!device_ok(device)) return LB_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return LB_ERR_HIP;
+    launch_fill_codes(d_dst, n, seed, offset, (hipStream_t)stream);
+    return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? LB_OK : LB_ERR_HIP;
+}
+
+} // extern "C"

@@ -1,0 +1,459 @@
+// kernels_scan.hip -- exact-order distance scan (HBM-bound path), row norms, data fill.
+//
+// scan_kernel restates, bit for bit, the reference's per-pair arithmetic for a few
+// queries against every corpus row:
+//   SEQ     referenceEuclidean/referenceCosine (internal/simd/simd_test.go:13-33),
+//           cosineGeneric/dotGeneric (internal/simd/simd.go:138-163)
+//   UNROLL4 euclideanUnrolled4x/cosineUnrolled4x/dotUnrolled4x (internal/simd/simd.go:365-479)
+// i.e. the hot loop of simd.EuclideanDistanceBatchFlat (simd.go:203-229) and of
+// BruteForceIndex.SearchVectors (internal/store/adaptive_index.go:180-211).
+// Each lane owns one corpus row and carries that row's f32 accumulator chain(s)
+// across the D dimension in the reference's order; rows are staged through LDS in
+// coalesced 256-B pieces (128 rows x 64 floats per stage, double buffered) so HBM
+// sees full lines while every lane walks its own row.  No FMA contraction here.
+#include "lb_device.h"
+
+#pragma clang fp contract(off)
+
+namespace lb {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SC_ROWS = 128;   // rows per tile == threads per workgroup
+constexpr int SC_DK = 64;      // floats per row per stage
+constexpr int SC_LD = SC_DK + 4; // padded LDS row stride (floats): conflict-free ds_read_b128
+
+struct ScanArgs {
+    const float *X;
+    int64_t row_begin, row_end;
+    int D;
+    const float *Q;
+    const int *qsel;
+    int nsel;
+    const float *qna; // per selected slot: ||q||^2 in the requested order (cosine)
+    const uint8_t *mask;
+    CandState cs;
+    float *all_out;
+    int64_t ld;
+    int raw_dot;
+    int aligned;
+};
+
+template <int ORDER>
+struct Acc {
+    float s[ORDER == ORDER_UNROLL4 ? 4 : 1];
+    __device__ __forceinline__ void zero()
+    {
+#pragma unroll
+        for (int i = 0; i < (ORDER == ORDER_UNROLL4 ? 4 : 1); i++) s[i] = 0.f;
+    }
+    // t = position within a group of 4 (compile-time); tail elements always use slot 0
+    template <int T>
+    __device__ __forceinline__ void add(float v)
+    {
+        if (ORDER == ORDER_UNROLL4) s[T] = s[T] + v;
+        else s[0] = s[0] + v;
+    }
+    __device__ __forceinline__ void add_tail(float v) { s[0] = s[0] + v; }
+    __device__ __forceinline__ float total() const
+    {
+        if (ORDER == ORDER_UNROLL4) {
+            float t = s[0] + s[1];
+            t = t + s[2];
+            t = t + s[3];
+            return t;
+        }
+        return s[0];
+    }
+};
+
+template <int METRIC, int ORDER, int NQ>
+__global__ __launch_bounds__(SC_ROWS) void scan_kernel(ScanArgs a)
+{
+    // one __shared__ object: [stage][rows | query chunk]
+    constexpr int STAGE_F = SC_ROWS * SC_LD + NQ * SC_DK;
+    __shared__ __attribute__((aligned(16))) float lds[2][STAGE_F];
+    const int tid = threadIdx.x;
+    const int D = a.D;
+    const int nchunks = (D + SC_DK - 1) / SC_DK;
+    const int dmain = D & ~3; // elements covered by the 4-wide main loop of UNROLL4
+    const int64_t nrows = a.row_end - a.row_begin;
+    const int64_t ntiles = (nrows + SC_ROWS - 1) / SC_ROWS;
+
+    // query slots (wave-uniform)
+    int qidx[NQ];
+    uint64_t tau[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; j++) {
+        int jj = j < a.nsel ? j : a.nsel - 1;
+        qidx[j] = __builtin_amdgcn_readfirstlane(a.qsel ? a.qsel[jj] : jj);
+        tau[j] = (a.all_out == nullptr && j < a.nsel) ? a.cs.tau[qidx[j]] : 0ull;
+    }
+
+    // the query chunk rides in the same LDS stage (read back as a broadcast ds_read_b128):
+    // keeping Q off the vector-memory queue lets the row prefetch stay in flight under compute.
+    const bool q_loader = tid < NQ * 16;
+    const float *q_src = nullptr;
+    if (q_loader) {
+        int j = tid >> 4;
+        if (j >= a.nsel) j = a.nsel - 1;
+        q_src = a.Q + (int64_t)(a.qsel ? a.qsel[j] : j) * D;
+    }
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t trow0 = a.row_begin + tile * SC_ROWS;
+        const int64_t myrow = trow0 + tid;
+        const bool valid = myrow < a.row_end;
+
+        Acc<ORDER> acc[NQ]; // L2: sum (q-x)^2 ; cos/dot: sum q*x
+        Acc<ORDER> nb;      // cos: sum x*x
+#pragma unroll
+        for (int j = 0; j < NQ; j++) acc[j].zero();
+        nb.zero();
+
+        f32x4 stg[16];
+        f32x4 stq = {0.f, 0.f, 0.f, 0.f};
+        auto load_stage = [&](int c) {
+            const int d0 = c * SC_DK;
+            if (q_loader) {
+                int k = d0 + (tid & 15) * 4;
+                if (k > D - 4) k = D - 4;
+                stq = *reinterpret_cast<const f32x4 *>(q_src + k);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int ch = tid + SC_ROWS * i;
+                const int r = ch >> 4, p = ch & 15;
+                int64_t row = trow0 + r;
+                if (row >= a.row_end) row = a.row_end - 1;
+                int k = d0 + p * 4;
+                if (k > D - 4) k = D - 4; // D % 4 == 0 here; chunks past D are never consumed
+                stg[i] = *reinterpret_cast<const f32x4 *>(a.X + row * (int64_t)D + k);
+            }
+        };
+        auto write_stage = [&](int st) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int ch = tid + SC_ROWS * i;
+                const int r = ch >> 4, p = ch & 15;
+                *reinterpret_cast<f32x4 *>(&lds[st][r * SC_LD + p * 4]) = stg[i];
+            }
+            if (q_loader)
+                *reinterpret_cast<f32x4 *>(&lds[st][SC_ROWS * SC_LD + (tid >> 4) * SC_DK + (tid & 15) * 4]) = stq;
+        };
+
+        load_stage(0);
+        write_stage(0);
+        __syncthreads();
+
+        for (int c = 0; c < nchunks; c++) {
+            if (c + 1 < nchunks) load_stage(c + 1);
+            const float *xr = &lds[c & 1][tid * SC_LD];
+            const float *lq = &lds[c & 1][SC_ROWS * SC_LD];
+            const int d0 = c * SC_DK;
+            const int nfull4 = (min(dmain, d0 + SC_DK) - d0) >> 2; // groups of 4 in the main loop
+            // main loop: groups of 4 elements, positions 0..3 -> accumulators 0..3 (UNROLL4)
+#pragma unroll 4
+            for (int g = 0; g < nfull4; g++) {
+                const f32x4 xv = *reinterpret_cast<const f32x4 *>(&xr[g * 4]);
+                if (METRIC == METRIC_COS) {
+                    nb.template add<0>(xv.x * xv.x);
+                    nb.template add<1>(xv.y * xv.y);
+                    nb.template add<2>(xv.z * xv.z);
+                    nb.template add<3>(xv.w * xv.w);
+                }
+#pragma unroll
+                for (int j = 0; j < NQ; j++) {
+                    const f32x4 qv = *reinterpret_cast<const f32x4 *>(&lq[j * SC_DK + g * 4]);
+                    const float q0 = qv.x, q1 = qv.y, q2 = qv.z, q3 = qv.w;
+                    if (METRIC == METRIC_L2) {
+                        const float e0 = q0 - xv.x, e1 = q1 - xv.y, e2 = q2 - xv.z, e3 = q3 - xv.w;
+                        acc[j].template add<0>(e0 * e0);
+                        acc[j].template add<1>(e1 * e1);
+                        acc[j].template add<2>(e2 * e2);
+                        acc[j].template add<3>(e3 * e3);
+                    } else {
+                        acc[j].template add<0>(q0 * xv.x);
+                        acc[j].template add<1>(q1 * xv.y);
+                        acc[j].template add<2>(q2 * xv.z);
+                        acc[j].template add<3>(q3 * xv.w);
+                    }
+                }
+            }
+            if (c + 1 < nchunks) write_stage((c + 1) & 1);
+            __syncthreads();
+        }
+
+        if (valid && (a.all_out != nullptr || a.mask == nullptr || a.mask[myrow])) {
+            const float nbt = nb.total();
+#pragma unroll
+            for (int j = 0; j < NQ; j++) {
+                if (j >= a.nsel) break;
+                const float t = acc[j].total();
+                float dist;
+                if (METRIC == METRIC_L2) {
+                    dist = (float)sqrt((double)t);
+                } else if (METRIC == METRIC_COS) {
+                    const float na = a.qna[j];
+                    if (D == 0 || na == 0.0f || nbt == 0.0f) dist = 1.0f;
+                    else {
+                        const float den = (float)sqrt((double)na * (double)nbt);
+                        dist = 1.0f - __fdiv_rn(t, den);
+                    }
+                } else {
+                    dist = a.raw_dot ? t : -t;
+                }
+                if (a.all_out) {
+                    a.all_out[(int64_t)j * a.ld + myrow] = dist;
+                } else {
+                    const uint64_t ent = pack_entry(dist, (uint32_t)myrow);
+                    if (ent < tau[j]) {
+                        const int qj = qidx[j];
+                        uint32_t pos = atomicAdd(&a.cs.cnt[qj], 1u);
+                        if (pos < a.cs.cap) a.cs.lists[(size_t)qj * a.cs.cap + pos] = ent;
+                    }
+                }
+            }
+        }
+    }
+}
+
+
+// Generic fallback for D % 4 != 0 (or a misaligned base): one lane per row walks its row
+// straight from global memory.  Same arithmetic, no staging; correctness path only.
+template <int METRIC, int ORDER>
+__global__ __launch_bounds__(256) void scan_generic_kernel(ScanArgs a)
+{
+    const int D = a.D;
+    const int dmain = D & ~3;
+    for (int64_t row = a.row_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < a.row_end;
+         row += (int64_t)gridDim.x * blockDim.x) {
+        if (a.all_out == nullptr && a.mask != nullptr && !a.mask[row]) continue;
+        const float *x = a.X + row * (int64_t)D;
+        for (int j = 0; j < a.nsel; j++) {
+            const int qj = a.qsel ? a.qsel[j] : j;
+            const float *q = a.Q + (int64_t)qj * D;
+            Acc<ORDER> acc, nb;
+            acc.zero();
+            nb.zero();
+            for (int i = 0; i < dmain; i += 4) {
+                const float x0 = x[i], x1 = x[i + 1], x2 = x[i + 2], x3 = x[i + 3];
+                if (METRIC == METRIC_COS) {
+                    nb.template add<0>(x0 * x0);
+                    nb.template add<1>(x1 * x1);
+                    nb.template add<2>(x2 * x2);
+                    nb.template add<3>(x3 * x3);
+                }
+                if (METRIC == METRIC_L2) {
+                    const float e0 = q[i] - x0, e1 = q[i + 1] - x1, e2 = q[i + 2] - x2, e3 = q[i + 3] - x3;
+                    acc.template add<0>(e0 * e0);
+                    acc.template add<1>(e1 * e1);
+                    acc.template add<2>(e2 * e2);
+                    acc.template add<3>(e3 * e3);
+                } else {
+                    acc.template add<0>(q[i] * x0);
+                    acc.template add<1>(q[i + 1] * x1);
+                    acc.template add<2>(q[i + 2] * x2);
+                    acc.template add<3>(q[i + 3] * x3);
+                }
+            }
+            for (int i = dmain; i < D; i++) {
+                const float xv = x[i];
+                if (METRIC == METRIC_COS) nb.add_tail(xv * xv);
+                if (METRIC == METRIC_L2) {
+                    const float e = q[i] - xv;
+                    acc.add_tail(e * e);
+                } else {
+                    acc.add_tail(q[i] * xv);
+                }
+            }
+            const float t = acc.total();
+            float dist;
+            if (METRIC == METRIC_L2) {
+                dist = (float)sqrt((double)t);
+            } else if (METRIC == METRIC_COS) {
+                const float na = a.qna[j], nbt = nb.total();
+                if (D == 0 || na == 0.0f || nbt == 0.0f) dist = 1.0f;
+                else dist = 1.0f - __fdiv_rn(t, (float)sqrt((double)na * (double)nbt));
+            } else {
+                dist = a.raw_dot ? t : -t;
+            }
+            if (a.all_out) {
+                a.all_out[(int64_t)j * a.ld + row] = dist;
+            } else {
+                const uint64_t ent = pack_entry(dist, (uint32_t)row);
+                if (ent < a.cs.tau[qj]) {
+                    uint32_t pos = atomicAdd(&a.cs.cnt[qj], 1u);
+                    if (pos < a.cs.cap) a.cs.lists[(size_t)qj * a.cs.cap + pos] = ent;
+                }
+            }
+        }
+    }
+}
+
+// ||q||^2 per selected slot in the requested order (cosine only).  One lane per slot.
+template <int ORDER>
+__global__ void query_norms_kernel(const float *Q, const int *qsel, int nsel, int D, float *qna)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nsel) return;
+    const float *q = Q + (int64_t)(qsel ? qsel[j] : j) * D;
+    Acc<ORDER> a;
+    a.zero();
+    const int dmain = D & ~3;
+    for (int i = 0; i < dmain; i += 4) {
+        a.template add<0>(q[i] * q[i]);
+        a.template add<1>(q[i + 1] * q[i + 1]);
+        a.template add<2>(q[i + 2] * q[i + 2]);
+        a.template add<3>(q[i + 3] * q[i + 3]);
+    }
+    for (int i = dmain; i < D; i++) a.add_tail(q[i] * q[i]);
+    qna[j] = a.total();
+}
+
+void launch_query_norms(int order, const float *Q, const int *qsel, int nsel, int D, float *qna,
+                        hipStream_t s)
+{
+    if (nsel <= 0) return;
+    dim3 grid((nsel + 63) / 64), block(64);
+    if (order == ORDER_UNROLL4)
+        hipLaunchKernelGGL(query_norms_kernel<ORDER_UNROLL4>, grid, block, 0, s, Q, qsel, nsel, D, qna);
+    else
+        hipLaunchKernelGGL(query_norms_kernel<ORDER_SEQ>, grid, block, 0, s, Q, qsel, nsel, D, qna);
+}
+
+template <int METRIC, int ORDER>
+static void launch_scan_nq(int nq_t, dim3 grid, hipStream_t s, const ScanArgs &a)
+{
+    switch (nq_t) {
+    case 1: hipLaunchKernelGGL((scan_kernel<METRIC, ORDER, 1>), grid, dim3(SC_ROWS), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((scan_kernel<METRIC, ORDER, 2>), grid, dim3(SC_ROWS), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((scan_kernel<METRIC, ORDER, 4>), grid, dim3(SC_ROWS), 0, s, a); break;
+    default: hipLaunchKernelGGL((scan_kernel<METRIC, ORDER, 8>), grid, dim3(SC_ROWS), 0, s, a); break;
+    }
+}
+
+void launch_scan(int metric, int order, bool raw_dot, const float *X, int64_t row_begin,
+                      int64_t row_end, int D, const float *Q, const int *qsel, int nsel,
+                      const float *qna, const uint8_t *mask, CandState cs, float *all_out,
+                      int64_t ld, hipStream_t s)
+{
+    if (row_end <= row_begin || nsel <= 0) return;
+    ScanArgs a;
+    a.X = X; a.row_begin = row_begin; a.row_end = row_end; a.D = D;
+    a.Q = Q; a.qsel = qsel; a.nsel = nsel; a.qna = qna; a.mask = mask; a.cs = cs;
+    a.all_out = all_out; a.ld = ld; a.raw_dot = raw_dot ? 1 : 0;
+    a.aligned = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+    if (!a.aligned) {
+        int64_t blocks = (row_end - row_begin + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        dim3 g((unsigned)blocks), b(256);
+#define LB_GEN(M)                                                                          \
+    do {                                                                                   \
+        if (order == ORDER_UNROLL4) hipLaunchKernelGGL((scan_generic_kernel<M, ORDER_UNROLL4>), g, b, 0, s, a); \
+        else hipLaunchKernelGGL((scan_generic_kernel<M, ORDER_SEQ>), g, b, 0, s, a);        \
+    } while (0)
+        if (metric == METRIC_L2) LB_GEN(METRIC_L2);
+        else if (metric == METRIC_COS) LB_GEN(METRIC_COS);
+        else LB_GEN(METRIC_DOT);
+#undef LB_GEN
+        return;
+    }
+    const int64_t ntiles = (row_end - row_begin + SC_ROWS - 1) / SC_ROWS;
+    // 69.6 KB LDS per workgroup -> 2 workgroups per CU; 256 CUs.
+    const int64_t maxgrid = 256 * 2 * 2;
+    dim3 grid((unsigned)(ntiles < maxgrid ? ntiles : maxgrid));
+    int nq_t = nsel <= 1 ? 1 : nsel <= 2 ? 2 : nsel <= 4 ? 4 : 8;
+#define LB_SCAN(M)                                                                       \
+    do {                                                                                 \
+        if (order == ORDER_UNROLL4) launch_scan_nq<M, ORDER_UNROLL4>(nq_t, grid, s, a);   \
+        else launch_scan_nq<M, ORDER_SEQ>(nq_t, grid, s, a);                              \
+    } while (0)
+    if (metric == METRIC_L2) LB_SCAN(METRIC_L2);
+    else if (metric == METRIC_COS) LB_SCAN(METRIC_COS);
+    else LB_SCAN(METRIC_DOT);
+#undef LB_SCAN
+}
+
+// ---------------------------------------------------------------------------
+// Row norms at Add time: one wave per row, coalesced float4 reads, wave reduction.
+// Used only for candidate keys and error bounds (never for reported distances).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void row_norms_kernel(const float *X, int64_t n, int D,
+                                                        float *norm2, float *rnorm,
+                                                        uint32_t *maxnorm2, int aligned)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float *x = X + row * (int64_t)D;
+    float s = 0.f;
+    if (aligned) {
+        for (int i = lane * 4; i < D; i += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(x + i);
+            s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+    } else {
+        for (int i = lane; i < D; i += 64) s += x[i] * x[i];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) {
+        norm2[row] = s;
+        rnorm[row] = s > 0.f ? (float)(1.0 / sqrt((double)s)) : 0.f;
+        atomicMax(maxnorm2, __builtin_bit_cast(uint32_t, s)); // s >= 0: uint order == float order
+    }
+}
+
+void launch_row_norms(const float *X, int64_t n, int D, float *norm2, float *rnorm,
+                      uint32_t *d_maxnorm2, hipStream_t s)
+{
+    if (n <= 0) return;
+    const int aligned = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+    dim3 grid((unsigned)((n + 3) / 4));
+    hipLaunchKernelGGL(row_norms_kernel, grid, dim3(256), 0, s, X, n, D, norm2, rnorm, d_maxnorm2,
+                       aligned);
+}
+
+// ---------------------------------------------------------------------------
+// Synthetic data: same counter-based generator as oracle/longbow_oracle.c.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64_at(uint64_t seed, uint64_t idx)
+{
+    uint64_t z = seed + (idx + 1) * 0x9e3779b97f4a7c15ULL;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
+
+__global__ void fill_uniform_kernel(float *dst, int64_t n, uint64_t seed, int64_t offset)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = (float)(splitmix64_at(seed, (uint64_t)(offset + i)) >> 40) * (1.0f / 16777216.0f);
+}
+
+__global__ void fill_codes_kernel(uint8_t *dst, int64_t n, uint64_t seed, int64_t offset)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = (uint8_t)(splitmix64_at(seed, (uint64_t)(offset + i)) >> 56);
+}
+
+void launch_fill_uniform(float *dst, int64_t n, uint64_t seed, int64_t offset, hipStream_t s)
+{
+    if (n <= 0) return;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(fill_uniform_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dst, n, seed, offset);
+}
+
+void launch_fill_codes(uint8_t *dst, int64_t n, uint64_t seed, int64_t offset, hipStream_t s)
+{
+    if (n <= 0) return;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(fill_codes_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dst, n, seed, offset);
+}
+
+} // namespace lb

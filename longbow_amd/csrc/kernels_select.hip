@@ -1,0 +1,423 @@
+// kernels_select.hip -- batched top-k selection, exact re-rank and cross-shard merge.
+//
+// select:  per query, bitonic-sort the admitted (key,row) entries in LDS, keep the best kc,
+//          publish the kc-th entry as the next admission threshold.  The ordering it realises
+//          is the canonical form of BruteForceIndex.SearchVectors' bounded heap
+//          (internal/store/adaptive_index.go:176-222): ascending (distance, row position).
+// rerank:  recompute the kept candidates' distances in the reference's exact f32 order
+//          (internal/simd/simd_test.go:13-33, simd.go:138-163,365-479), order by
+//          (distance, row), verify that no row outside the candidate set can beat the k-th
+//          result (rigorous rounding-error bound), write results.
+// merge:   store.MergeSortedStreams (internal/store/result_merger.go:34-101) for S shards.
+#include "lb_device.h"
+
+#include <float.h>
+
+#pragma clang fp contract(off)
+
+namespace lb {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SEL_THREADS = 256;
+
+__device__ __forceinline__ uint32_t next_pow2(uint32_t v)
+{
+    if (v <= 2) return 2;
+    return 1u << (32 - __builtin_clz(v - 1));
+}
+
+// In-LDS bitonic sort of P (power of two) u64 keys, ascending, by the whole workgroup.
+__device__ __forceinline__ void bitonic_sort_u64(uint64_t *sh, uint32_t P, int tid, int nthreads)
+{
+    for (uint32_t k = 2; k <= P; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < (P >> 1); t += nthreads) {
+                const uint32_t i = 2 * t - (t & (j - 1));
+                const uint32_t l = i + j;
+                const uint64_t a = sh[i], b = sh[l];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) {
+                    sh[i] = b;
+                    sh[l] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ void init_cand_kernel(CandState cs, const int *qsel, int nsel)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < nsel) {
+        const int i = qsel ? qsel[j] : j;
+        cs.cnt[i] = 0;
+        cs.tau[i] = kEntryMax;
+        cs.flags[i] = 0;
+    }
+}
+
+void launch_init_cand(CandState cs, const int *qsel, int nsel, hipStream_t s)
+{
+    if (nsel <= 0) return;
+    hipLaunchKernelGGL(init_cand_kernel, dim3((nsel + 255) / 256), dim3(256), 0, s, cs, qsel, nsel);
+}
+
+// Kernels that carve more than 64 KB of dynamic LDS must opt in once.
+template <typename K>
+static void allow_big_lds(K kernel, size_t bytes)
+{
+    if (bytes > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(SEL_THREADS) void select_kernel(CandState cs, const int *qsel, int kc)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t sh[];
+    const int q = qsel ? qsel[blockIdx.x] : blockIdx.x;
+    const int tid = threadIdx.x;
+    const uint32_t raw = cs.cnt[q];
+    const uint32_t n = raw < cs.cap ? raw : cs.cap;
+    uint64_t *list = cs.lists + (size_t)q * cs.cap;
+    if (raw > cs.cap && tid == 0) atomicOr(&cs.flags[q], 1u);
+    if (n == 0) {
+        if (tid == 0) cs.tau[q] = kEntryMax;
+        return;
+    }
+    const uint32_t P = next_pow2(n);
+    for (uint32_t i = tid; i < P; i += SEL_THREADS) sh[i] = i < n ? list[i] : kEntryMax;
+    __syncthreads();
+    bitonic_sort_u64(sh, P, tid, SEL_THREADS);
+    const uint32_t keep = n < (uint32_t)kc ? n : (uint32_t)kc;
+    for (uint32_t i = tid; i < keep; i += SEL_THREADS) list[i] = sh[i];
+    if (tid == 0) {
+        cs.cnt[q] = keep;
+        cs.tau[q] = n >= (uint32_t)kc ? sh[kc - 1] : kEntryMax;
+    }
+}
+
+void launch_select(CandState cs, const int *qsel, int nsel, int kc, hipStream_t s)
+{
+    if (nsel <= 0) return;
+    const size_t shmem = (size_t)next_pow2_host(cs.cap) * sizeof(uint64_t);
+    allow_big_lds(select_kernel, shmem);
+    hipLaunchKernelGGL(select_kernel, dim3(nsel), dim3(SEL_THREADS), shmem, s, cs, qsel, kc);
+}
+
+// ---------------------------------------------------------------------------
+// exact-order accumulators (same as kernels_scan.hip)
+template <int ORDER>
+struct AccR {
+    float s[ORDER == ORDER_UNROLL4 ? 4 : 1];
+    __device__ __forceinline__ void zero()
+    {
+#pragma unroll
+        for (int i = 0; i < (ORDER == ORDER_UNROLL4 ? 4 : 1); i++) s[i] = 0.f;
+    }
+    template <int T>
+    __device__ __forceinline__ void add(float v)
+    {
+        if (ORDER == ORDER_UNROLL4) s[T] = s[T] + v;
+        else s[0] = s[0] + v;
+    }
+    __device__ __forceinline__ void add_tail(float v) { s[0] = s[0] + v; }
+    __device__ __forceinline__ float total() const
+    {
+        if (ORDER == ORDER_UNROLL4) {
+            float t = s[0] + s[1];
+            t = t + s[2];
+            t = t + s[3];
+            return t;
+        }
+        return s[0];
+    }
+};
+
+struct RerankArgs {
+    const float *X;
+    int D;
+    const float *Q;
+    const float *qna;
+    CandState cs;
+    int kc, k;
+    const uint32_t *maxnorm2;
+    const int64_t *ids;
+    float *out_dist;
+    int64_t *out_labels;
+    int aligned;
+};
+
+// One workgroup per query.  LDS: q[D] | sort keys u64[P] | cmp values f32[P]
+template <int METRIC, int ORDER>
+__global__ __launch_bounds__(SEL_THREADS) void rerank_kernel(RerankArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int qi = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int D = a.D;
+    const uint32_t nc = a.cs.cnt[qi];
+    const uint32_t P = next_pow2(nc > 0 ? nc : 1);
+    const int Dpad = (D + 3) & ~3;
+    float *sq = reinterpret_cast<float *>(smem);
+    // all LDS in the one dynamic region (16-B aligned carve offsets, no static __shared__)
+    uint64_t *skey = reinterpret_cast<uint64_t *>(smem + (size_t)Dpad * 4);
+    const uint32_t Pmax = next_pow2((uint32_t)a.kc);
+    float *scmp = reinterpret_cast<float *>(skey + Pmax);
+    unsigned int &s_count = *reinterpret_cast<unsigned int *>(scmp + Pmax);
+    float &s_w = *reinterpret_cast<float *>(scmp + Pmax + 1);
+
+    const float *q = a.Q + (int64_t)qi * D;
+    for (int i = tid; i < D; i += SEL_THREADS) sq[i] = q[i];
+    if (tid == 0) { s_count = 0; s_w = 0.f; }
+    __syncthreads();
+
+    const uint64_t *list = a.cs.lists + (size_t)qi * a.cs.cap;
+    const int dmain = D & ~3;
+    const float na = (METRIC == METRIC_COS) ? a.qna[qi] : 0.f;
+
+    for (uint32_t c = tid; c < P; c += SEL_THREADS) {
+        if (c >= nc) {
+            skey[c] = kEntryMax;
+            scmp[c] = FLT_MAX;
+            continue;
+        }
+        const uint32_t row = entry_row(list[c]);
+        const float *x = a.X + (int64_t)row * D;
+        AccR<ORDER> acc, nb;
+        acc.zero();
+        nb.zero();
+        for (int i = 0; i < dmain; i += 4) {
+            float x0, x1, x2, x3;
+            if (a.aligned) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(x + i);
+                x0 = v.x; x1 = v.y; x2 = v.z; x3 = v.w;
+            } else {
+                x0 = x[i]; x1 = x[i + 1]; x2 = x[i + 2]; x3 = x[i + 3];
+            }
+            const f32x4 qv = *reinterpret_cast<const f32x4 *>(&sq[i]);
+            if (METRIC == METRIC_COS) {
+                nb.template add<0>(x0 * x0);
+                nb.template add<1>(x1 * x1);
+                nb.template add<2>(x2 * x2);
+                nb.template add<3>(x3 * x3);
+            }
+            if (METRIC == METRIC_L2) {
+                const float e0 = qv.x - x0, e1 = qv.y - x1, e2 = qv.z - x2, e3 = qv.w - x3;
+                acc.template add<0>(e0 * e0);
+                acc.template add<1>(e1 * e1);
+                acc.template add<2>(e2 * e2);
+                acc.template add<3>(e3 * e3);
+            } else {
+                acc.template add<0>(qv.x * x0);
+                acc.template add<1>(qv.y * x1);
+                acc.template add<2>(qv.z * x2);
+                acc.template add<3>(qv.w * x3);
+            }
+        }
+        for (int i = dmain; i < D; i++) {
+            const float xv = x[i], qv = sq[i];
+            if (METRIC == METRIC_COS) nb.add_tail(xv * xv);
+            if (METRIC == METRIC_L2) {
+                const float e = qv - xv;
+                acc.add_tail(e * e);
+            } else {
+                acc.add_tail(qv * xv);
+            }
+        }
+        const float t = acc.total();
+        float dist, cmp;
+        if (METRIC == METRIC_L2) {
+            dist = (float)sqrt((double)t);
+            cmp = t; // compare in d^2 space
+        } else if (METRIC == METRIC_COS) {
+            const float nbt = nb.total();
+            if (D == 0 || na == 0.0f || nbt == 0.0f) dist = 1.0f;
+            else dist = 1.0f - __fdiv_rn(t, (float)sqrt((double)na * (double)nbt));
+            cmp = dist;
+        } else {
+            dist = -t;
+            cmp = dist;
+        }
+        skey[c] = pack_entry(dist, row);
+        scmp[c] = cmp;
+        if (c == (uint32_t)a.kc - 1) s_w = cmp; // the candidate with the worst approximate key
+    }
+    __syncthreads();
+
+    // ---- containment check (only meaningful when the list is full: rows were left out) ----
+    // Any row y outside the list has approx_key(y) >= approx_key(c_last); with rounding-error
+    // bound E on both evaluations, exact_cmp(y) >= w - E.  If at least k candidates satisfy
+    // cmp < w - E (strictly), the true top-k lies inside the list.
+    if (nc >= (uint32_t)a.kc && nc > (uint32_t)a.k) {
+        const float u = 5.9604645e-8f; // 2^-24
+        const float gam = 1.05f * (float)(D + 8) * u;
+        const float xmax2 = __builtin_bit_cast(float, *a.maxnorm2);
+        const float xmax = sqrtf(xmax2) * 1.000001f;
+        const float w = s_w;
+        float T;
+        bool skip = false;
+        if (METRIC == METRIC_L2) {
+            float nq2 = 0.f;
+            for (int i = 0; i < D; i++) nq2 += sq[i] * sq[i];
+            const float nqn = sqrtf(nq2) * 1.000001f;
+            T = w * (1.0f - 3.0f * gam) - 2.2f * gam * (xmax2 + 2.0f * nqn * xmax);
+        } else if (METRIC == METRIC_COS) {
+            T = w - 8.5f * gam;
+            skip = (na == 0.0f); // all distances are exactly 1.0; selection by row is exact
+        } else {
+            float nq2 = 0.f;
+            for (int i = 0; i < D; i++) nq2 += sq[i] * sq[i];
+            const float nqn = sqrtf(nq2) * 1.000001f;
+            T = w - 4.4f * gam * nqn * xmax;
+        }
+        T = T - fabsf(T) * 1e-6f;
+        unsigned int local = 0;
+        for (uint32_t c = tid; c < nc; c += SEL_THREADS) local += (scmp[c] < T) ? 1u : 0u;
+        if (local) atomicAdd(&s_count, local);
+        __syncthreads();
+        if (tid == 0 && !skip && s_count < (unsigned int)a.k) atomicOr(&a.cs.flags[qi], 2u);
+    }
+
+    bitonic_sort_u64(skey, P, tid, SEL_THREADS);
+
+    for (int r = tid; r < a.k; r += SEL_THREADS) {
+        float d = FLT_MAX;
+        int64_t lab = -1;
+        if ((uint32_t)r < nc) {
+            const uint64_t e = skey[r];
+            d = entry_key(e);
+            const uint32_t row = entry_row(e);
+            lab = a.ids ? a.ids[row] : (int64_t)row;
+        }
+        a.out_dist[(int64_t)qi * a.k + r] = d;
+        a.out_labels[(int64_t)qi * a.k + r] = lab;
+    }
+}
+
+void launch_rerank(int metric, int order, const float *X, int D, const float *Q, int nq,
+                   const float *qna, CandState cs, int kc, int k, const uint32_t *d_maxnorm2,
+                   const int64_t *ids, float *out_dist, int64_t *out_labels, hipStream_t s)
+{
+    if (nq <= 0) return;
+    RerankArgs a;
+    a.X = X; a.D = D; a.Q = Q; a.qna = qna; a.cs = cs; a.kc = kc; a.k = k;
+    a.maxnorm2 = d_maxnorm2; a.ids = ids; a.out_dist = out_dist; a.out_labels = out_labels;
+    a.aligned = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+    const int Dpad = (D + 3) & ~3;
+    const size_t P = next_pow2_host((uint32_t)kc);
+    const size_t shmem = (size_t)Dpad * 4 + P * 8 + P * 4 + 16;
+    dim3 grid(nq), block(SEL_THREADS);
+    allow_big_lds(rerank_kernel<METRIC_L2, ORDER_SEQ>, shmem);
+    allow_big_lds(rerank_kernel<METRIC_L2, ORDER_UNROLL4>, shmem);
+    allow_big_lds(rerank_kernel<METRIC_COS, ORDER_SEQ>, shmem);
+    allow_big_lds(rerank_kernel<METRIC_COS, ORDER_UNROLL4>, shmem);
+    allow_big_lds(rerank_kernel<METRIC_DOT, ORDER_SEQ>, shmem);
+    allow_big_lds(rerank_kernel<METRIC_DOT, ORDER_UNROLL4>, shmem);
+#define LB_RR(M)                                                                                   \
+    do {                                                                                           \
+        if (order == ORDER_UNROLL4) hipLaunchKernelGGL((rerank_kernel<M, ORDER_UNROLL4>), grid, block, shmem, s, a); \
+        else hipLaunchKernelGGL((rerank_kernel<M, ORDER_SEQ>), grid, block, shmem, s, a);           \
+    } while (0)
+    if (metric == METRIC_L2) LB_RR(METRIC_L2);
+    else if (metric == METRIC_COS) LB_RR(METRIC_COS);
+    else LB_RR(METRIC_DOT);
+#undef LB_RR
+}
+
+// ---------------------------------------------------------------------------
+// scan path: lists already hold exact distances, sorted by the last select.
+__global__ void emit_lists_kernel(CandState cs, const int *qsel, int nsel, int k, const int64_t *ids,
+                                  float *out_dist, int64_t *out_labels)
+{
+    const int j = blockIdx.x;
+    if (j >= nsel) return;
+    const int q = qsel ? qsel[j] : j;
+    const uint32_t n = cs.cnt[q];
+    const uint64_t *list = cs.lists + (size_t)q * cs.cap;
+    for (int r = threadIdx.x; r < k; r += blockDim.x) {
+        float d = FLT_MAX;
+        int64_t lab = -1;
+        if ((uint32_t)r < n) {
+            const uint64_t e = list[r];
+            d = entry_key(e);
+            const uint32_t row = entry_row(e);
+            lab = ids ? ids[row] : (int64_t)row;
+        }
+        out_dist[(int64_t)q * k + r] = d;
+        out_labels[(int64_t)q * k + r] = lab;
+    }
+}
+
+void launch_emit_lists(CandState cs, const int *qsel, int nsel, int k, const int64_t *ids,
+                       float *out_dist, int64_t *out_labels, hipStream_t s)
+{
+    if (nsel <= 0) return;
+    hipLaunchKernelGGL(emit_lists_kernel, dim3(nsel), dim3(128), 0, s, cs, qsel, nsel, k, ids, out_dist,
+                       out_labels);
+}
+
+// ---------------------------------------------------------------------------
+// Cross-shard merge: per query S*k (dist,label) pairs -> k smallest by (dist, label).
+// Labels are i64, compared as unsigned so the -1 padding sorts last.
+__global__ __launch_bounds__(SEL_THREADS) void merge_topk_kernel(int nshards, int64_t nq, int k,
+                                                                 const float *dist_in,
+                                                                 const int64_t *lab_in,
+                                                                 float *dist_out, int64_t *lab_out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int64_t q = blockIdx.x;
+    const int tid = threadIdx.x;
+    const uint32_t n = (uint32_t)(nshards * k);
+    const uint32_t P = next_pow2(n);
+    uint64_t *slab = reinterpret_cast<uint64_t *>(smem);
+    uint32_t *skey = reinterpret_cast<uint32_t *>(slab + P);
+    for (uint32_t i = tid; i < P; i += SEL_THREADS) {
+        if (i < n) {
+            const int s = i / k, r = i % k;
+            const int64_t src = ((int64_t)s * nq + q) * k + r;
+            skey[i] = f32_sortable(dist_in[src] + 0.0f);
+            slab[i] = (uint64_t)lab_in[src];
+        } else {
+            skey[i] = 0xffffffffu;
+            slab[i] = ~0ull;
+        }
+    }
+    __syncthreads();
+    for (uint32_t kk = 2; kk <= P; kk <<= 1) {
+        for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < (P >> 1); t += SEL_THREADS) {
+                const uint32_t i = 2 * t - (t & (j - 1));
+                const uint32_t l = i + j;
+                const uint32_t ka = skey[i], kb = skey[l];
+                const uint64_t la = slab[i], lb2 = slab[l];
+                const bool gt = ka > kb || (ka == kb && la > lb2);
+                const bool up = (i & kk) == 0;
+                if (gt == up) {
+                    skey[i] = kb; skey[l] = ka;
+                    slab[i] = lb2; slab[l] = la;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int r = tid; r < k; r += SEL_THREADS) {
+        dist_out[q * k + r] = sortable_f32(skey[r]);
+        lab_out[q * k + r] = (int64_t)slab[r];
+    }
+}
+
+void launch_merge_topk(int nshards, int64_t nq, int k, const float *dist_in, const int64_t *lab_in,
+                       float *dist_out, int64_t *lab_out, hipStream_t s)
+{
+    if (nq <= 0 || k <= 0) return;
+    const size_t P = next_pow2_host((uint32_t)(nshards * k));
+    const size_t shmem = P * 12;
+    allow_big_lds(merge_topk_kernel, shmem);
+    hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)nq), dim3(SEL_THREADS), shmem, s, nshards, nq,
+                       k, dist_in, lab_in, dist_out, lab_out);
+}
+
+} // namespace lb

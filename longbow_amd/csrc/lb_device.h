@@ -1,0 +1,104 @@
+// lb_device.h -- shared device helpers and kernel-launcher prototypes (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lb {
+
+// ---------------------------------------------------------------------------
+// Candidate entries: (key f32, row u32) packed into one u64 so that unsigned
+// integer order == ascending (key, row).  All selection works on these.
+// ---------------------------------------------------------------------------
+constexpr uint64_t kEntryMax = ~0ull;
+
+__host__ __device__ __forceinline__ uint32_t f32_sortable(float f)
+{
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ __forceinline__ float sortable_f32(uint32_t s)
+{
+    uint32_t u = (s & 0x80000000u) ? (s & 0x7fffffffu) : ~s;
+    return __builtin_bit_cast(float, u);
+}
+__host__ __device__ __forceinline__ uint64_t pack_entry(float key, uint32_t row)
+{
+    return ((uint64_t)f32_sortable(key + 0.0f) << 32) | row; // +0.0f: -0 -> +0
+}
+__host__ __device__ __forceinline__ float entry_key(uint64_t e) { return sortable_f32((uint32_t)(e >> 32)); }
+__host__ __device__ __forceinline__ uint32_t entry_row(uint64_t e) { return (uint32_t)e; }
+
+inline uint32_t next_pow2_host(uint32_t v)
+{
+    uint32_t p = 2;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+enum : int { METRIC_L2 = 0, METRIC_COS = 1, METRIC_DOT = 2 };
+enum : int { ORDER_SEQ = 0, ORDER_UNROLL4 = 1 };
+
+// Per-search candidate state, one slot per query (all in HBM).
+struct CandState {
+    uint64_t *lists; // [nq][cap] entries; [0,cnt) valid
+    uint32_t *cnt;   // [nq] appended so far (may exceed cap -> overflow)
+    uint64_t *tau;   // [nq] admission threshold: entry admitted iff e < tau
+    uint32_t *flags; // [nq] bit0 = list overflowed, bit1 = containment bound failed
+    uint32_t cap;
+};
+
+// ---------------------------------------------------------------------------
+// Launchers (implemented in kernels_*.hip).  All are asynchronous on `s`.
+// ---------------------------------------------------------------------------
+
+// per-row ||x||^2 and 1/||x|| (0 if the norm is 0); max ||x||^2 folded into *d_maxnorm2 (float bits)
+void launch_row_norms(const float *X, int64_t n, int D, float *norm2, float *rnorm,
+                      uint32_t *d_maxnorm2, hipStream_t s);
+
+// candidate generation: f32 MFMA inner products of queries [nq][D] x rows [row_begin,row_end)
+// -> metric key -> admit (key,row) < tau[q] into the query's list.
+void launch_gemm_filter(int metric, const float *X, const float *norm2, const float *rnorm,
+                        int64_t row_begin, int64_t row_end, int D, const float *Q, int nq,
+                        const uint8_t *mask, CandState cs, hipStream_t s);
+
+// per query: sort the list, keep the best kc, tau = kc-th entry (or max), flag overflow.
+// qsel (nullable): only these query slots.
+void launch_select(CandState cs, const int *qsel, int nsel, int kc, hipStream_t s);
+
+// exact-order distances of the kept candidates, final ordering, containment check, output.
+void launch_rerank(int metric, int order, const float *X, int D, const float *Q, int nq,
+                   const float *qna, CandState cs, int kc, int k, const uint32_t *d_maxnorm2,
+                   const int64_t *ids, float *out_dist, int64_t *out_labels, hipStream_t s);
+
+// ||q||^2 per selected query slot in the requested accumulation order (cosine).
+void launch_query_norms(int order, const float *Q, const int *qsel, int nsel, int D, float *qna,
+                        hipStream_t s);
+
+// exact-order scan (nsel <= 8): distances of every row in [row_begin,row_end) for query slots
+// qsel[0..nsel) (indices into Q, or identity when qsel==nullptr), admitted against tau.
+// If all_out != nullptr writes every distance to all_out[slot*ld + row] instead (simd batch API).
+void launch_scan(int metric, int order, bool raw_dot, const float *X, int64_t row_begin,
+                 int64_t row_end, int D, const float *Q, const int *qsel, int nsel,
+                 const float *qna, const uint8_t *mask, CandState cs, float *all_out, int64_t ld,
+                 hipStream_t s);
+
+// after the last select of the scan path: lists already hold exact distances.
+void launch_emit_lists(CandState cs, const int *qsel, int nsel, int k, const int64_t *ids,
+                       float *out_dist, int64_t *out_labels, hipStream_t s);
+
+void launch_init_cand(CandState cs, const int *qsel, int nsel, hipStream_t s);
+
+void launch_merge_topk(int nshards, int64_t nq, int k, const float *dist_in, const int64_t *lab_in,
+                       float *dist_out, int64_t *lab_out, hipStream_t s);
+
+void launch_fill_uniform(float *dst, int64_t n, uint64_t seed, int64_t offset, hipStream_t s);
+void launch_fill_codes(uint8_t *dst, int64_t n, uint64_t seed, int64_t offset, hipStream_t s);
+
+// PQ
+void launch_build_adc_table(const float *codebooks, int M, int K, int sub, const float *Q, int nq,
+                            float *tables, hipStream_t s);
+void launch_adc_scan(const float *tables, int M, const uint8_t *codes, int64_t row_begin,
+                     int64_t row_end, int nq, const uint8_t *mask, CandState cs, float *all_out,
+                     int64_t ld, hipStream_t s);
+
+} // namespace lb

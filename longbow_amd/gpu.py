@@ -1,0 +1,164 @@
+"""Mirror of internal/gpu: Index{Add, Search, Close}, GPUConfig, NewIndex, NewIndexWithConfig
+(internal/gpu/interface.go:3-19, gpu_enabled.go:8-21, faiss_gpu.go:44-167), over the C ABI.
+
+Superset used by the batched path: SearchBatch, metric selection, device-resident
+add/search (pointers are plain ints, e.g. torch_tensor.data_ptr()).
+"""
+import ctypes as C
+import threading
+
+import numpy as np
+
+from . import _lib
+from ._lib import GPUNotAvailable, LongbowGPUError  # noqa: F401
+from .simd import MetricType, Order
+
+ErrGPUNotAvailable = GPUNotAvailable
+
+
+class GPUConfig:
+    def __init__(self, DeviceID=0, Dimension=128, Metric=MetricType.Euclidean):
+        self.DeviceID = DeviceID
+        self.Dimension = Dimension
+        self.Metric = Metric
+
+
+class Index:
+    """gpu.Index backed by lb_gpu_index (HIP)."""
+
+    def __init__(self, cfg: GPUConfig):
+        if cfg.Dimension <= 0:
+            raise ValueError(f"dimension must be positive, got {cfg.Dimension}")  # faiss_gpu.go:46-48
+        lib = _lib.require_gpu(cfg.DeviceID)
+        st = C.c_int(0)
+        h = lib.lb_gpu_index_new(cfg.DeviceID, cfg.Dimension, int(cfg.Metric), C.byref(st))
+        if not h:
+            _lib.check(st.value or 7)
+        self._lib = lib
+        self._h = C.c_void_p(h)
+        self.dim = cfg.Dimension
+        self.device = cfg.DeviceID
+        self.metric = MetricType(int(cfg.Metric))
+        self._lock = threading.Lock()
+        self._closed = False
+
+    # -- gpu.Index ---------------------------------------------------------------
+    def Add(self, ids, vectors):
+        """Add(ids []int64, vectors []float32) error  (faiss_gpu.go:75-104)"""
+        self._live()
+        vectors = np.ascontiguousarray(vectors, np.float32).reshape(-1)
+        if vectors.size % self.dim != 0:
+            raise ValueError(f"vector data length {vectors.size} not divisible by dimension {self.dim}")
+        n = vectors.size // self.dim
+        idp = None
+        if ids is not None:
+            ids = np.ascontiguousarray(ids, np.int64)
+            if ids.size != n:
+                raise ValueError(f"id count {ids.size} does not match vector count {n}")
+            idp = ids.ctypes.data
+        _lib.check(self._lib.lb_gpu_index_add(self._h, n, vectors.ctypes.data, idp), self._h)
+
+    def Search(self, vector, k):
+        """Search(vector []float32, k int) (ids []int64, distances []float32, err)  (faiss_gpu.go:107-144)"""
+        self._live()
+        vector = np.ascontiguousarray(vector, np.float32).reshape(-1)
+        if vector.size != self.dim:
+            raise ValueError(f"query vector dimension {vector.size} does not match index dimension {self.dim}")
+        ids, dist = self.SearchBatch(vector[None, :], k)
+        return ids[0], dist[0]
+
+    def Close(self):
+        """idempotent (faiss_gpu.go:147-167)"""
+        with self._lock:
+            if self._closed:
+                return
+            self._lib.lb_gpu_index_free(self._h)
+            self._h = None
+            self._closed = True
+
+    # -- superset ----------------------------------------------------------------
+    def SearchBatch(self, queries, k):
+        self._live()
+        queries = np.ascontiguousarray(queries, np.float32)
+        if queries.ndim != 2 or queries.shape[1] != self.dim:
+            raise ValueError(f"query vector dimension {queries.shape[-1]} does not match index dimension {self.dim}")
+        nq = queries.shape[0]
+        dist = np.empty((nq, k), np.float32)
+        labels = np.empty((nq, k), np.int64)
+        _lib.check(self._lib.lb_gpu_index_search(self._h, nq, queries.ctypes.data, k, dist.ctypes.data,
+                                                 labels.ctypes.data), self._h)
+        return labels, dist
+
+    def add_device(self, n, d_vectors, d_ids=None):
+        self._live()
+        _lib.check(self._lib.lb_gpu_index_add_device(self._h, n, d_vectors, d_ids), self._h)
+
+    def search_device(self, nq, d_queries, k, d_dist, d_labels, stream=None):
+        self._live()
+        _lib.check(self._lib.lb_gpu_index_search_device(self._h, nq, d_queries, k, d_dist, d_labels, stream),
+                   self._h)
+
+    def reserve(self, n_total):
+        self._live()
+        _lib.check(self._lib.lb_gpu_index_reserve(self._h, n_total), self._h)
+
+    def set_order(self, order):
+        self._live()
+        _lib.check(self._lib.lb_gpu_index_set_order(self._h, int(Order(order))), self._h)
+
+    def set_filter(self, mask):
+        self._live()
+        if mask is None:
+            _lib.check(self._lib.lb_gpu_index_set_filter(self._h, None, 0), self._h)
+            return
+        mask = np.ascontiguousarray(mask, np.uint8)
+        _lib.check(self._lib.lb_gpu_index_set_filter(self._h, mask.ctypes.data, mask.size), self._h)
+
+    def set_profiling(self, on):
+        self._live()
+        _lib.check(self._lib.lb_gpu_index_set_profiling(self._h, 1 if on else 0), self._h)
+
+    def last_timing(self):
+        """{class: (ms, launches)} of the last search: gemm, select, rerank, scan, total"""
+        self._live()
+        ms = (C.c_float * 5)()
+        n = (C.c_int * 5)()
+        _lib.check(self._lib.lb_gpu_index_last_timing(self._h, ms, n), self._h)
+        names = ["gemm", "select", "rerank", "scan", "total"]
+        return {names[i]: (float(ms[i]), int(n[i])) for i in range(5)}
+
+    @property
+    def ntotal(self):
+        self._live()
+        return int(self._lib.lb_gpu_index_ntotal(self._h))
+
+    @property
+    def last_fallbacks(self):
+        self._live()
+        return int(self._lib.lb_gpu_index_last_fallbacks(self._h))
+
+    def _live(self):
+        if self._closed:
+            raise LongbowGPUError(2)  # "index is closed"
+
+    def __del__(self):  # runtime.SetFinalizer(idx, Close)  (faiss_gpu.go:69)
+        try:
+            self.Close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.Close()
+
+
+def NewIndex():
+    """gpu.NewIndex(): device 0, dimension 128 (gpu_enabled.go:8-14)"""
+    return NewIndexWithConfig(GPUConfig(DeviceID=0, Dimension=128))
+
+
+def NewIndexWithConfig(cfg: GPUConfig):
+    """gpu.NewIndexWithConfig (gpu_enabled.go:17-21).  Raises ErrGPUNotAvailable without a device."""
+    return Index(cfg)
