@@ -416,7 +416,7 @@ void launch_row_norms(const float *X, int64_t n, int D, float *norm2, float *rno
 }
 
 // ---------------------------------------------------------------------------
-// Synthetic data: same counter-based generator as oracle/longbow_oracle.c.
+// Synthetic data: counter-based splitmix64 generator (the CPU checker restates the same formula).
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t splitmix64_at(uint64_t seed, uint64_t idx)
 {

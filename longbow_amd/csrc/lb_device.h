@@ -97,8 +97,10 @@ void launch_fill_codes(uint8_t *dst, int64_t n, uint64_t seed, int64_t offset, h
 // PQ
 void launch_build_adc_table(const float *codebooks, int M, int K, int sub, const float *Q, int nq,
                             float *tables, hipStream_t s);
-void launch_adc_scan(const float *tables, int M, const uint8_t *codes, int64_t row_begin,
-                     int64_t row_end, int nq, const uint8_t *mask, CandState cs, float *all_out,
-                     int64_t ld, hipStream_t s);
+// one query per launch: `table` is that query's [M*256] table; entries go to cs slot `slot`,
+// or (all_out != nullptr) every distance is written to all_out[row - out_base].
+void launch_adc_scan(const float *table, int M, const uint8_t *codes, int64_t row_begin, int64_t row_end,
+                     int slot, const uint8_t *mask, CandState cs, float *all_out, int64_t out_base,
+                     hipStream_t s);
 
 } // namespace lb

@@ -1,0 +1,100 @@
+"""Mirror of internal/pq's query-side interface (the ADC path), computed by HIP kernels.
+
+PQEncoder.{BuildADCTable, ADCDistanceBatch, Serialize/Deserialize blob}
+(internal/pq/adc_table.go:15-72, persistence.go:9-73).  Training (k-means) and Encode are
+offline steps in the reference and stay out of the GPU path: codebooks and codes are inputs.
+"""
+import ctypes as C
+import struct
+
+import numpy as np
+
+from . import _lib
+
+
+def serialize_codebooks(codebooks):
+    """PQEncoder.Serialize layout (persistence.go:9-35): u32 LE dims, M, K + M*K*SubDim f32 LE."""
+    cb = np.ascontiguousarray(codebooks, np.float32)
+    M, K, sub = cb.shape
+    return struct.pack("<III", M * sub, M, K) + cb.astype("<f4").tobytes()
+
+
+class PQEncoder:
+    """Query-side PQEncoder on the GPU, built from the reference's serialised blob."""
+
+    def __init__(self, blob, device=0):
+        lib = _lib.require_gpu(device)
+        st = C.c_int(0)
+        buf = bytes(blob)
+        h = lib.lb_gpu_pq_new(device, buf, len(buf), C.byref(st))
+        if not h:
+            if st.value == 1:
+                raise ValueError("invalid PQ data")  # persistence.go:39-56 error cases
+            _lib.check(st.value or 7)
+        self._lib = lib
+        self._h = C.c_void_p(h)
+        self.M = lib.lb_gpu_pq_m(self._h)
+        self.Dims = lib.lb_gpu_pq_dims(self._h)
+        self.K = 256
+        self.SubDim = self.Dims // self.M
+
+    def add_codes(self, codes):
+        codes = np.ascontiguousarray(codes, np.uint8).reshape(-1)
+        if codes.size % self.M:
+            raise ValueError("code length mismatch")
+        _lib.check(self._lib.lb_gpu_pq_add_codes(self._h, codes.size // self.M, codes.ctypes.data), self._h, pq=True)
+
+    def add_codes_device(self, n, d_codes):
+        _lib.check(self._lib.lb_gpu_pq_add_codes_device(self._h, n, d_codes), self._h, pq=True)
+
+    @property
+    def ntotal(self):
+        return int(self._lib.lb_gpu_pq_ntotal(self._h))
+
+    def BuildADCTable(self, query):
+        query = np.ascontiguousarray(query, np.float32).reshape(-1)
+        if query.size != self.Dims:
+            raise ValueError("query dimension mismatch")  # adc_table.go:16-18
+        table = np.empty(self.M * self.K, np.float32)
+        _lib.check(self._lib.lb_gpu_pq_build_adc_table(self._h, query.ctypes.data, table.ctypes.data), self._h, pq=True)
+        return table
+
+    def ADCDistanceBatch(self, table, results, row0=0):
+        """distances of stored codes [row0, row0+len(results)) -> results (adc_table.go:57-72)"""
+        if results.size == 0:
+            return
+        table = np.ascontiguousarray(table, np.float32)
+        if table.size != self.M * self.K:
+            raise ValueError("invalid table size")  # adc_table.go:64-66
+        if row0 + results.size > self.ntotal:
+            raise ValueError("flatCodes buffer too small")  # adc_table.go:61-63
+        _lib.check(self._lib.lb_gpu_pq_adc_distance_batch(self._h, table.ctypes.data, row0, results.size,
+                                                           results.ctypes.data), self._h, pq=True)
+
+    def Search(self, queries, k):
+        queries = np.ascontiguousarray(queries, np.float32)
+        if queries.ndim == 1:
+            queries = queries[None, :]
+        if queries.shape[1] != self.Dims:
+            raise ValueError("query dimension mismatch")
+        nq = queries.shape[0]
+        dist = np.empty((nq, k), np.float32)
+        labels = np.empty((nq, k), np.int64)
+        _lib.check(self._lib.lb_gpu_pq_search(self._h, nq, queries.ctypes.data, k, dist.ctypes.data,
+                                              labels.ctypes.data), self._h, pq=True)
+        return labels, dist
+
+    def search_device(self, nq, d_queries, k, d_dist, d_labels, stream=None):
+        _lib.check(self._lib.lb_gpu_pq_search_device(self._h, nq, d_queries, k, d_dist, d_labels, stream),
+                   self._h, pq=True)
+
+    def Close(self):
+        if self._h:
+            self._lib.lb_gpu_pq_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.Close()
+        except Exception:
+            pass

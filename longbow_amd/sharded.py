@@ -1,0 +1,147 @@
+"""Corpus sharding across the GPUs of one node + cross-shard top-k merge.
+
+One process per GPU (torch.distributed; backend "nccl" == RCCL over xGMI).  The corpus is
+partitioned by Longbow's RingSharder (internal/store/sharding_strategy.go:40-127, built as
+NewRingSharder(numShards, 40) in internal/store/sharded_hnsw.go:158); every rank searches the
+same query batch over its shard with the HIP index, ONE all-gather moves the per-shard top-k
+(B*k*(4+8) bytes per rank), and every rank merges with the HIP merge kernel -- the device form
+of ShardedHNSW's concat+sort (sharded_hnsw.go:494-503) / MergeSortedStreams
+(internal/store/result_merger.go:34-101).
+
+The search and merge steps are injectable so that the collective plumbing can be exercised on
+CPU (gloo) in tests with the oracle standing in for the GPU; the defaults are the HIP path and
+raise without a GPU.
+"""
+import numpy as np
+
+from . import _lib
+from .simd import MetricType
+
+FNV_OFFSET = np.uint32(2166136261)
+FNV_PRIME = np.uint32(16777619)
+
+
+def fnv1a32_bytes(data: bytes) -> int:
+    h = 2166136261
+    for b in data:
+        h ^= b
+        h = (h * 16777619) & 0xFFFFFFFF
+    return h
+
+
+class RingSharder:
+    """store.RingSharder: consistent hashing of VectorIDs onto a fixed set of shards."""
+
+    def __init__(self, num_shards, vnodes=40):
+        if vnodes <= 0:
+            vnodes = 20  # sharding_strategy.go:51-53
+        self.num_shards = num_shards
+        self.vnodes = vnodes
+        ring = {}
+        hashes = []
+        for s in range(num_shards):           # addShard order (sharding_strategy.go:58-75)
+            for v in range(vnodes):
+                h = fnv1a32_bytes(f"{s}:{v}".encode())  # strconv.Itoa(shard)+":"+strconv.Itoa(vnode)
+                ring[h] = s                    # Go map assignment: a later equal hash overwrites
+                hashes.append(h)
+        hashes.sort()
+        self.sorted_hashes = np.array(hashes, np.uint32)
+        self.owners = np.array([ring[h] for h in hashes], np.int32)
+
+    @staticmethod
+    def hash_ids(ids):
+        """hashID (sharding_strategy.go:86-101): FNV-1a-32 over the 8 little-endian bytes of uint64(id)."""
+        v = np.asarray(ids).astype(np.uint64)
+        h = np.full(v.shape, FNV_OFFSET, np.uint32)
+        with np.errstate(over="ignore"):
+            for i in range(8):
+                b = ((v >> np.uint64(8 * i)) & np.uint64(0xFF)).astype(np.uint32)
+                h = (h ^ b) * FNV_PRIME
+        return h
+
+    def GetShards(self, ids):
+        if self.sorted_hashes.size == 0:
+            return np.zeros(np.asarray(ids).shape, np.int32)
+        h = self.hash_ids(ids)
+        idx = np.searchsorted(self.sorted_hashes, h, side="left")  # sort.Search(first >= h)
+        idx[idx == self.sorted_hashes.size] = 0                     # wrap (sharding_strategy.go:113-115)
+        return self.owners[idx]
+
+    def GetShard(self, vid):
+        return int(self.GetShards(np.array([vid], np.uint64))[0])
+
+    def ActiveShards(self):
+        return self.num_shards
+
+
+def _hip_merge(device):
+    def merge(nshards, nq, k, dist_all, lab_all, dist_out, lab_out, stream):
+        lib = _lib.require_gpu(device)
+        _lib.check(lib.lb_gpu_merge_topk_device(device, nshards, nq, k, dist_all.data_ptr(), lab_all.data_ptr(),
+                                                dist_out.data_ptr(), lab_out.data_ptr(), stream))
+    return merge
+
+
+class ShardedSearcher:
+    """One rank's view of a corpus sharded over `world_size` GPUs."""
+
+    def __init__(self, index, rank, world_size, group=None, device=None, local_search=None, merge=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.index = index
+        self.rank, self.world = rank, world_size
+        self.group = group
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self._local_search = local_search
+        self._merge = merge
+        self._bufs = {}
+
+    def _buffers(self, nq, k):
+        key = (nq, k)
+        if key not in self._bufs:
+            t = self.torch
+            dev = self.device
+            self._bufs[key] = dict(
+                d=t.empty((nq, k), dtype=t.float32, device=dev), l=t.empty((nq, k), dtype=t.int64, device=dev),
+                da=t.empty((self.world, nq, k), dtype=t.float32, device=dev),
+                la=t.empty((self.world, nq, k), dtype=t.int64, device=dev),
+                do=t.empty((nq, k), dtype=t.float32, device=dev), lo=t.empty((nq, k), dtype=t.int64, device=dev))
+        return self._bufs[key]
+
+    def search(self, queries, k):
+        """queries: [nq, dim] float32 tensor on this rank's device (identical on all ranks).
+        Returns (labels [nq,k] int64, dist [nq,k] float32): global top-k, identical on all ranks."""
+        t = self.torch
+        nq = queries.shape[0]
+        b = self._buffers(nq, k)
+        if self._local_search is not None:
+            lab, d = self._local_search(queries, k)
+            b["l"].copy_(t.as_tensor(lab))
+            b["d"].copy_(t.as_tensor(d))
+            stream = None
+        else:
+            stream = t.cuda.current_stream(self.device).cuda_stream
+            self.index.search_device(nq, queries.data_ptr(), k, b["d"].data_ptr(), b["l"].data_ptr(), stream)
+        if self.world > 1:
+            # the one exchange step: per-shard top-k, ids travel with distances
+            if self.dist.get_backend(self.group) == "nccl":  # RCCL: one fused all-gather per tensor
+                self.dist.all_gather_into_tensor(b["da"], b["d"], group=self.group)
+                self.dist.all_gather_into_tensor(b["la"], b["l"], group=self.group)
+            else:  # gloo (CPU tests)
+                self.dist.all_gather([b["da"][r] for r in range(self.world)], b["d"], group=self.group)
+                self.dist.all_gather([b["la"][r] for r in range(self.world)], b["l"], group=self.group)
+        else:
+            b["da"][0].copy_(b["d"])
+            b["la"][0].copy_(b["l"])
+        merge = self._merge if self._merge is not None else _hip_merge(self.device.index or 0)
+        merge(self.world, nq, k, b["da"], b["la"], b["do"], b["lo"], stream)
+        return b["lo"], b["do"]
+
+
+def partition_rows(ids, num_shards, vnodes=40):
+    """row -> shard for a whole corpus; also returns per-shard counts (skew report)."""
+    ring = RingSharder(num_shards, vnodes)
+    owner = ring.GetShards(ids)
+    counts = np.bincount(owner, minlength=num_shards)
+    return owner, counts

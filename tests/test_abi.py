@@ -1,0 +1,76 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/longbow_gpu.h
+declares; the host mirror fails loudly (no CPU fallback) when there is no GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "longbow_gpu.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(lb_(?:gpu|simd)_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from longbow_amd import _lib, build
+    build.build()
+    lib = ctypes.CDLL(_lib.SO_PATH)
+    declared = _declared_symbols()
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in longbow_gpu.h but not exported"
+    bound = {s[0] for s in _lib.SIGNATURES}
+    assert bound == set(declared), (bound ^ set(declared))
+    _lib.load()
+
+
+def test_version_and_status_strings():
+    from longbow_amd import _lib
+    lib = _lib.load()
+    assert b"gfx950" in lib.lb_gpu_version()
+    assert lib.lb_gpu_status_string(2) == b"index is closed"
+    assert lib.lb_gpu_status_string(3) == b"GPU not available"
+
+
+def test_no_cpu_fallback_without_gpu():
+    """ErrGPUNotAvailable semantics (internal/gpu/stub.go:10-18) when no device is visible."""
+    from longbow_amd import _lib, gpu, simd
+    lib = _lib.load()
+    if lib.lb_gpu_device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(gpu.ErrGPUNotAvailable):
+        gpu.NewIndex()
+    with pytest.raises(gpu.ErrGPUNotAvailable):
+        gpu.NewIndexWithConfig(gpu.GPUConfig(DeviceID=0, Dimension=128))
+    with pytest.raises(gpu.ErrGPUNotAvailable):
+        simd.EuclideanDistanceBatchFlat(np.zeros(4, np.float32), np.zeros(8, np.float32), 2, 4, np.zeros(2, np.float32))
+    st = ctypes.c_int(0)
+    assert not lib.lb_gpu_index_new(0, 128, 0, ctypes.byref(st))
+    assert st.value == 3
+    # argument validation happens before the device check
+    assert not lib.lb_gpu_index_new(0, -1, 0, ctypes.byref(st)) and st.value == 1
+    assert lib.lb_gpu_merge_topk_device(0, 2, 1, 10, 1, 1, 1, 1, None) == 3
+
+
+def test_invalid_dimension_is_an_error():
+    """gpu_test.go:49-55 TestGPUIndex_InvalidDimension"""
+    from longbow_amd import gpu
+    with pytest.raises(ValueError):
+        gpu.NewIndexWithConfig(gpu.GPUConfig(DeviceID=0, Dimension=-1))
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under longbow_amd/ may import, include or link it."""
+    banned = ("import oracle", "from oracle", "#include \"longbow_oracle", "#include <longbow_oracle",
+              "liblongbow_oracle", "oracle_c", "oracle_np", "lbo_")
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "longbow_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                for tok in banned:
+                    assert tok not in text, (f, tok)

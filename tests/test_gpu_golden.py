@@ -1,0 +1,179 @@
+"""The HIP path against the reference's own known-answer tests (tests/golden/reference_kats.json),
+called through the host mirror of internal/simd and internal/gpu -> C ABI -> kernels."""
+import numpy as np
+import pytest
+
+from tests.golden_util import approx_equal, dataset, pair_inputs
+from tests.gpu_util import gpu_or_skip, new_index
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+def _pair(simd, metric, a, b, order):
+    if metric == "euclidean":
+        return simd.EuclideanDistance(a, b, order)
+    if metric == "cosine":
+        return simd.CosineDistance(a, b, order)
+    if metric == "dot_raw":
+        return simd.DotProduct(a, b, order)
+    return -simd.DotProduct(a, b, order)
+
+
+def test_golden_pairs_on_gpu(golden, oracle):
+    gpu_or_skip()
+    from longbow_amd import simd
+    n = 0
+    for c in golden:
+        if c["op"] != "pair":
+            continue
+        a, b = pair_inputs(c)
+        for order in (simd.Order.Seq, simd.Order.Unroll4):
+            if c.get("order") == "unroll4" and order != simd.Order.Unroll4:
+                continue
+            got = _pair(simd, c["metric"], a, b, order)
+            if c.get("exact"):
+                assert float(got) == c["expected"], (c["name"], got)
+            else:
+                assert approx_equal(got, c["expected"], c["rel_tol"]), (c["name"], got, c["expected"])
+        n += 1
+    assert n >= 50
+
+
+def test_length_mismatch_is_an_error():
+    """simd_test.go:123-128,214-219"""
+    gpu_or_skip()
+    from longbow_amd import simd
+    for fn in (simd.EuclideanDistance, simd.CosineDistance, simd.DotProduct):
+        with pytest.raises(ValueError):
+            fn([1, 2, 3], [1, 2])
+    assert simd.EuclideanDistance([], []) == 0.0
+    assert simd.CosineDistance([], []) == 1.0
+
+
+def test_golden_batches_on_gpu(golden):
+    gpu_or_skip()
+    from longbow_amd import simd
+    for c in golden:
+        if c["op"] == "batch":
+            q = np.array(c["query"], F)
+            V = np.array(c["vectors"], F)
+            res = np.zeros(len(V), F)
+            fn = simd.CosineDistanceBatch if c["metric"] == "cosine" else simd.DotProductBatch
+            for order in (simd.Order.Seq, simd.Order.Unroll4):
+                fn(q, V, res, order)
+                assert np.all(np.abs(res - np.array(c["expected"], F)) <= c["abs_tol"]), c["name"]
+        elif c["op"] == "batch3":
+            q, V = dataset(c["gen"])
+            e = c["expected"]
+            r = np.zeros(len(V), F)
+            simd.EuclideanDistanceBatchFlat(q, V.reshape(-1), len(V), V.shape[1], r)  # UNROLL4 by default
+            assert np.array_equal(r, np.array(e["euclidean_unroll4"], F))
+            simd.EuclideanDistanceBatch(q, V, r, simd.Order.Seq)
+            assert np.array_equal(r, np.array(e["euclidean_seq"], F))
+            simd.CosineDistanceBatch(q, V, r)
+            assert np.array_equal(r, np.array(e["cosine"], F))
+            simd.DotProductBatch(q, V, r)
+            assert np.array_equal(r, np.array(e["dot_raw"], F))
+
+
+def test_batch_flat_error_behaviour():
+    """simd.go:204-217 error cases"""
+    gpu_or_skip()
+    from longbow_amd import simd
+    q = np.zeros(4, F)
+    with pytest.raises(ValueError):
+        simd.EuclideanDistanceBatchFlat(q, np.zeros(8, F), 2, 4, np.zeros(3, F))   # results length mismatch
+    with pytest.raises(ValueError):
+        simd.EuclideanDistanceBatchFlat(q, np.zeros(7, F), 2, 4, np.zeros(2, F))   # flatVectors too small
+    with pytest.raises(ValueError):
+        simd.EuclideanDistanceBatchFlat(np.zeros(3, F), np.zeros(8, F), 2, 4, np.zeros(2, F))  # query dim
+    simd.EuclideanDistanceBatchFlat(q, np.zeros(0, F), 0, 4, np.zeros(0, F))       # numVectors == 0 -> nil
+
+
+def test_golden_bruteforce_on_gpu(golden):
+    gpu_or_skip()
+    for c in golden:
+        if c["op"] != "search":
+            continue
+        X = dataset(c["gen"])
+        q = np.array(c["query"], F) if "query" in c else np.arange(X.shape[1], dtype=F)
+        idx = new_index(X.shape[1] if X.size else len(q), 0)
+        if X.shape[0]:
+            idx.Add(None, X)
+        ids, dist = idx.Search(q, c["k"])
+        cnt = int((ids >= 0).sum())
+        assert cnt == c["expect_count"], c["name"]          # k>N -> N results; empty -> 0
+        assert np.all(ids[cnt:] == -1) and np.all(dist[cnt:] == np.finfo(F).max)
+        assert np.all(np.diff(dist[:cnt]) >= 0)              # ascending
+        if "expected_ids" in c:
+            assert list(ids[:cnt]) == c["expected_ids"], c["name"]
+            assert np.array_equal(dist[:cnt], np.array(c["expected_dist"], F)), c["name"]
+        idx.Close()
+
+
+def test_gpu_index_basic(golden):
+    """internal/gpu/gpu_test.go:12-46 TestGPUIndex_Basic and the :57-83 bench fixture"""
+    gpu_or_skip()
+    from longbow_amd import gpu
+    for c in golden:
+        if c["op"] != "gpu_index":
+            continue
+        X = dataset(c["gen"])
+        idx = gpu.NewIndexWithConfig(gpu.GPUConfig(DeviceID=0, Dimension=X.shape[1]))
+        idx.Add(np.arange(len(X), dtype=np.int64), X.reshape(-1))
+        result_ids, distances = idx.Search(X[0], c["k"])
+        assert len(result_ids) == c["k"] and len(distances) == c["k"]
+        assert result_ids[0] == c["expect_first_id"]
+        assert distances[0] < c["expect_first_dist_lt"]
+        idx.Close()
+        idx.Close()  # idempotent
+        with pytest.raises(gpu.LongbowGPUError):
+            idx.Search(X[0], 5)  # "index is closed"
+
+
+def test_gpu_index_validation():
+    """faiss_gpu.go:83-90,115-117"""
+    gpu_or_skip()
+    from longbow_amd import gpu
+    idx = gpu.NewIndex()  # device 0, dim 128
+    assert idx.dim == 128
+    with pytest.raises(ValueError):
+        idx.Add(None, np.zeros(130, F))                      # not divisible by dimension
+    with pytest.raises(ValueError):
+        idx.Add(np.arange(3), np.zeros(256, F))              # id count mismatch
+    with pytest.raises(ValueError):
+        idx.Search(np.zeros(64, F), 5)                       # query dimension mismatch
+    idx.Close()
+
+
+def test_golden_merge_on_gpu(golden):
+    gpu_or_skip()
+    torch = pytest.importorskip("torch")
+    from longbow_amd import _lib
+    lib = _lib.load()
+    for c in golden:
+        if c["op"] != "merge":
+            continue
+        S = len(c["lists"])
+        k = max(1, max(len(l["ids"]) for l in c["lists"]))
+        d = np.full((S, 1, k), np.finfo(F).max, F)
+        l = np.full((S, 1, k), -1, np.int64)
+        for s, lst in enumerate(c["lists"]):
+            d[s, 0, :len(lst["ids"])] = lst["scores"]
+            l[s, 0, :len(lst["ids"])] = lst["ids"]
+        kk = min(c["k"], S * k)
+        # merge kernel emits k per query; emulate "limit K" by taking the first K of a wider merge
+        dd, ll = torch.from_numpy(d).cuda(), torch.from_numpy(l).cuda()
+        # pad every list to width >= kk so the output width can be kk
+        if k < kk:
+            pad_d = torch.full((S, 1, kk - k), float(np.finfo(F).max), device="cuda")
+            pad_l = torch.full((S, 1, kk - k), -1, dtype=torch.int64, device="cuda")
+            dd, ll = torch.cat([dd, pad_d], 2).contiguous(), torch.cat([ll, pad_l], 2).contiguous()
+        w = dd.shape[2]
+        do = torch.empty((1, w), device="cuda")
+        lo = torch.empty((1, w), dtype=torch.int64, device="cuda")
+        rc = lib.lb_gpu_merge_topk_device(0, S, 1, w, dd.data_ptr(), ll.data_ptr(), do.data_ptr(), lo.data_ptr(), None)
+        assert rc == 0
+        got = [int(x) for x in lo[0].cpu().numpy() if x >= 0][:c["k"]]
+        assert got == c["expected_ids"], c["name"]

@@ -1,0 +1,253 @@
+"""Parity of the HIP k-NN path with the CPU oracle on seeded inputs: index sets, order and
+distances BIT-EXACT (the north star asks for exact index sets and 1e-5 relative distances;
+the re-rank / scan kernels reproduce the oracle's f32 operation order, so equality holds)."""
+import threading
+
+import numpy as np
+import pytest
+
+from tests.gpu_util import assert_same, gpu_or_skip, new_index
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("order", [0, 1])
+@pytest.mark.parametrize("n,d,nq,k", [
+    (1, 8, 1, 1), (37, 3, 2, 5), (1000, 7, 1, 10), (5000, 33, 4, 10), (5000, 64, 8, 100),
+    (20000, 128, 17, 10), (20000, 128, 64, 10), (30000, 100, 130, 37), (70000, 96, 40, 100),
+    (4097, 16, 33, 3), (65537, 8, 20, 16),
+])
+def test_search_matches_oracle(oracle, metric, order, n, d, nq, k):
+    gpu_or_skip()
+    rng = np.random.default_rng(n * 31 + d * 7 + nq + metric)
+    X = rng.random((n, d), dtype=F) - F(0.25)
+    Q = rng.random((nq, d), dtype=F) - F(0.25)
+    idx = new_index(d, metric, order)
+    idx.Add(None, X)
+    lab, dist = idx.SearchBatch(Q, k)
+    oi, od = oracle.search_batch(metric, Q, X, k, order=order, nthreads=8)
+    assert_same(lab, dist, oi, od, f"metric={metric} order={order} n={n} d={d} nq={nq} k={k}")
+    idx.Close()
+
+
+def test_scan_and_batched_paths_agree(oracle):
+    """the same queries through the exact scan path (nq small) and the MFMA path (nq large)"""
+    gpu_or_skip()
+    rng = np.random.default_rng(99)
+    X = rng.random((50000, 256), dtype=F)
+    Q = rng.random((96, 256), dtype=F)
+    for metric in (0, 1, 2):
+        idx = new_index(256, metric)
+        idx.Add(None, X)
+        lab_b, dist_b = idx.SearchBatch(Q, 50)
+        assert idx.last_fallbacks == 0
+        for s in range(0, 96, 8):
+            lab_s, dist_s = idx.SearchBatch(Q[s:s + 8], 50)
+            assert np.array_equal(lab_s, lab_b[s:s + 8]) and np.array_equal(dist_s, dist_b[s:s + 8])
+        idx.Close()
+
+
+def test_append_ids_and_growth(oracle):
+    """Add APPENDS; ids are reported when given (SURVEY 8b ID semantics); mixed id/no-id adds"""
+    gpu_or_skip()
+    rng = np.random.default_rng(5)
+    d = 48
+    parts = [rng.random((n, d), dtype=F) for n in (10, 1500, 1, 4000, 700)]
+    X = np.concatenate(parts)
+    ids = np.arange(len(X), dtype=np.int64) * 5 + 11
+    Q = rng.random((20, d), dtype=F)
+    idx = new_index(d, 0)
+    pos = 0
+    for p in parts:
+        idx.Add(ids[pos:pos + len(p)], p)
+        pos += len(p)
+    assert idx.ntotal == len(X)
+    lab, dist = idx.SearchBatch(Q, 10)
+    oi, od = oracle.search_batch(0, Q, X, 10, ids=ids, nthreads=4)
+    assert_same(lab, dist, oi, od)
+    idx.Close()
+    # no ids first, ids later: earlier rows report their positions
+    idx = new_index(d, 2)
+    idx.Add(None, parts[1])
+    idx.Add(np.arange(len(parts[3]), dtype=np.int64) + 10**12, parts[3])
+    X2 = np.concatenate([parts[1], parts[3]])
+    ids2 = np.concatenate([np.arange(len(parts[1])), np.arange(len(parts[3])) + 10**12]).astype(np.int64)
+    lab, dist = idx.SearchBatch(Q[:3], 7)
+    oi, od = oracle.search_batch(2, Q[:3], X2, 7, ids=ids2)
+    assert_same(lab, dist, oi, od)
+    idx.Close()
+
+
+def test_k_larger_than_n_and_empty(oracle):
+    gpu_or_skip()
+    rng = np.random.default_rng(8)
+    X = rng.random((5, 16), dtype=F)
+    Q = rng.random((30, 16), dtype=F)
+    idx = new_index(16, 1)
+    lab, dist = idx.SearchBatch(Q, 4)            # empty index
+    assert np.all(lab == -1) and np.all(dist == np.finfo(F).max)
+    idx.Add(None, X)
+    for nq in (1, 30):
+        lab, dist = idx.SearchBatch(Q[:nq], 9)   # k > n: n hits then -1 / FLT_MAX padding
+        oi, od = oracle.search_batch(1, Q[:nq], X, 9)
+        assert_same(lab, dist, oi, od)
+        assert np.all(lab[:, 5:] == -1)
+    idx.Close()
+
+
+def test_ties_lowest_position_wins(oracle):
+    """duplicate rows and an all-zero query: canonical (distance, position) order"""
+    gpu_or_skip()
+    rng = np.random.default_rng(3)
+    base = rng.random((50, 32), dtype=F)
+    X = np.concatenate([base] * 40)              # every row appears 40 times
+    Q = np.concatenate([base[:20] + F(0.001), np.zeros((12, 32), F)])
+    for metric in (0, 1, 2):
+        idx = new_index(32, metric)
+        idx.Add(None, X)
+        for nq in (4, 32):
+            lab, dist = idx.SearchBatch(Q[:nq] if nq == 4 else Q, 25)
+            oi, od = oracle.search_batch(metric, Q[:nq] if nq == 4 else Q, X, 25, nthreads=4)
+            assert_same(lab, dist, oi, od, f"metric={metric} nq={nq}")
+        idx.Close()
+
+
+def test_zero_vectors_cosine(oracle):
+    """zero query / zero rows -> distance exactly 1.0 (simd_test.go:183-194)"""
+    gpu_or_skip()
+    rng = np.random.default_rng(4)
+    X = rng.random((3000, 24), dtype=F)
+    X[::7] = 0
+    Q = rng.random((40, 24), dtype=F)
+    Q[3] = 0
+    idx = new_index(24, 1)
+    idx.Add(None, X)
+    lab, dist = idx.SearchBatch(Q, 12)
+    oi, od = oracle.search_batch(1, Q, X, 12, nthreads=4)
+    assert_same(lab, dist, oi, od)
+    assert np.all(dist[3] == 1.0)
+    idx.Close()
+
+
+def test_filter_mask(oracle):
+    """metadata predicate mask (byte per row, 0 = excluded): SURVEY f-3"""
+    gpu_or_skip()
+    rng = np.random.default_rng(12)
+    X = rng.random((20000, 64), dtype=F)
+    Q = rng.random((48, 64), dtype=F)
+    meta = rng.integers(0, 100, 20000)
+    mask = (meta < 10).astype(np.uint8)          # 10 % selectivity, as config 5
+    for metric in (0, 2):
+        idx = new_index(64, metric)
+        idx.Add(None, X)
+        idx.set_filter(mask)
+        for qs in (Q[:5], Q):
+            lab, dist = idx.SearchBatch(qs, 20)
+            oi, od = oracle.search_batch(metric, qs, X, 20, mask=mask, nthreads=4)
+            assert_same(lab, dist, oi, od)
+            assert np.all(mask[lab] == 1)
+        idx.set_filter(None)
+        lab, dist = idx.SearchBatch(Q[:5], 20)
+        oi, od = oracle.search_batch(metric, Q[:5], X, 20)
+        assert_same(lab, dist, oi, od)
+        idx.Close()
+
+
+def test_adversarial_order_forces_list_overflow(oracle):
+    """rows sorted from worst to best: every row is admitted, the candidate lists overflow, and the
+    library must fall back to overflow-proof chunking and still be exact"""
+    gpu_or_skip()
+    rng = np.random.default_rng(21)
+    d = 32
+    q = rng.random(d, dtype=F)
+    X = rng.random((60000, d), dtype=F)
+    dist = oracle.batch_flat(0, q, X)
+    X = X[np.argsort(-dist)]                     # descending distance to q
+    Q = np.stack([q + F(1e-3) * rng.random(d, dtype=F) for _ in range(24)])
+    idx = new_index(d, 0)
+    idx.Add(None, X)
+    for qs in (Q[:2], Q):
+        lab, dd = idx.SearchBatch(qs, 10)
+        oi, od = oracle.search_batch(0, qs, X, 10, nthreads=4)
+        assert_same(lab, dd, oi, od)
+    assert idx.last_fallbacks > 0                 # the batched path did have to fall back
+    idx.Close()
+
+
+def test_near_duplicates_force_containment_fallback(oracle):
+    """a corpus of near-identical rows: approximate keys cannot separate rank k from rank kc, the
+    containment check must fail and the exact scan must take over"""
+    gpu_or_skip()
+    rng = np.random.default_rng(22)
+    d = 128
+    c = rng.random(d, dtype=F)
+    X = (c[None, :] + F(1e-6) * rng.standard_normal((30000, d)).astype(F)).astype(F)
+    Q = rng.random((20, d), dtype=F)
+    for metric in (0, 1, 2):
+        idx = new_index(d, metric)
+        idx.Add(None, X)
+        lab, dd = idx.SearchBatch(Q, 10)
+        oi, od = oracle.search_batch(metric, Q, X, 10, nthreads=8)
+        assert_same(lab, dd, oi, od, f"metric={metric}")
+        idx.Close()
+
+
+def test_concurrent_search_from_many_threads(oracle):
+    """Search takes the read lock: many goroutines search one index at once (faiss_gpu.go:108)"""
+    gpu_or_skip()
+    rng = np.random.default_rng(30)
+    X = rng.random((20000, 64), dtype=F)
+    idx = new_index(64, 0)
+    idx.Add(None, X)
+    Qs = [rng.random((nq, 64), dtype=F) for nq in (1, 3, 40, 1, 64, 2, 33, 5)]
+    exp = [oracle.search_batch(0, q, X, 10, nthreads=2) for q in Qs]
+    out = [None] * len(Qs)
+    errs = []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                out[i] = idx.SearchBatch(Qs[i], 10)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(Qs))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs
+    for (lab, dd), (oi, od) in zip(out, exp):
+        assert_same(lab, dd, oi, od)
+    idx.Close()
+
+
+def test_large_k(oracle):
+    gpu_or_skip()
+    rng = np.random.default_rng(41)
+    X = rng.random((30000, 32), dtype=F)
+    Q = rng.random((20, 32), dtype=F)
+    idx = new_index(32, 0)
+    idx.Add(None, X)
+    for k in (1000, 2048):
+        for qs in (Q[:2], Q):
+            lab, dd = idx.SearchBatch(qs, k)
+            oi, od = oracle.search_batch(0, qs, X, k, nthreads=4)
+            assert_same(lab, dd, oi, od, f"k={k}")
+    from longbow_amd import gpu
+    with pytest.raises(gpu.LongbowGPUError):
+        idx.SearchBatch(Q[:1], 5000)
+    idx.Close()
+
+
+def test_fill_uniform_matches_oracle(oracle):
+    gpu_or_skip()
+    torch = pytest.importorskip("torch")
+    from longbow_amd import _lib
+    lib = _lib.load()
+    t = torch.empty(100003, device="cuda")
+    assert lib.lb_gpu_fill_uniform_device(0, t.data_ptr(), t.numel(), 12345, 77, None) == 0
+    assert np.array_equal(t.cpu().numpy(), oracle.fill_uniform(100003, 12345, 77))
+    c = torch.empty(5000, dtype=torch.uint8, device="cuda")
+    assert lib.lb_gpu_fill_codes_device(0, c.data_ptr(), c.numel(), 7, 3, None) == 0
+    assert np.array_equal(c.cpu().numpy(), oracle.fill_codes(5000, 7, 3))

@@ -1,0 +1,73 @@
+"""N>1 path on CPU: two gloo ranks, RingSharder partition, all-gather of per-shard top-k, merge.
+The GPU search/merge steps are replaced by the oracle here (test infrastructure) -- what is
+under test is the partitioning and the collective plumbing of longbow_amd.sharded."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.distributed as dist  # noqa: E402
+import torch.multiprocessing as mp  # noqa: E402
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, metric, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from longbow_amd.sharded import RingSharder, ShardedSearcher
+    from oracle import oracle_c as oc
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(123)
+        n, d, nq, k = 4000, 32, 9, 10
+        X = rng.random((n, d), dtype=np.float32)
+        Q = rng.random((nq, d), dtype=np.float32)
+        ids = np.arange(n, dtype=np.int64) * 3 + 5  # user ids != positions
+        owner = RingSharder(world, 40).GetShards(ids.astype(np.uint64))
+        mine = np.nonzero(owner == rank)[0]
+        Xl, idl = X[mine], ids[mine]
+
+        def local_search(queries, kk):
+            oi, od = oc.search_batch(metric, queries.numpy(), Xl, kk, ids=idl)
+            return oi, od
+
+        def merge(nshards, nqq, kk, dist_all, lab_all, dist_out, lab_out, stream):
+            for b in range(nqq):
+                dd = dist_all[:, b, :].reshape(-1).numpy()
+                ll = lab_all[:, b, :].reshape(-1).numpy().astype(np.uint64)
+                order = np.lexsort((ll, dd))[:kk]
+                dist_out[b] = torch.from_numpy(dd[order])
+                lab_out[b] = torch.from_numpy(ll[order].astype(np.int64))
+
+        s = ShardedSearcher(None, rank, world, device=torch.device("cpu"), local_search=local_search, merge=merge)
+        lab, dd = s.search(torch.from_numpy(Q), k)
+        gi, gd = oc.search_batch(metric, Q, X, k, ids=ids)
+        ok = bool(np.array_equal(lab.numpy(), gi) and np.array_equal(dd.numpy(), gd))
+        q.put((rank, ok, int(len(mine))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("metric", [0, 2])
+def test_two_rank_sharded_search_equals_global(metric, oracle):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, metric, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    assert sum(n for _, _, n in res) == 4000
