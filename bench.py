@@ -28,6 +28,22 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X dense f32 MFMA (MI355X_MICROARCH.md, chi
 PEAK_HBM_GBS = 8000.0          # HBM3E spec
 
 
+def host_cores():
+    """CPU threads this process may really use: min(affinity, cgroup v2 cpu.max quota)."""
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return cores
+
+
 def shard_ids(rank, world, rows):
     """first `rows` vector ids (ascending) that Longbow's ring assigns to shard `rank`"""
     from longbow_amd.sharded import RingSharder
@@ -194,18 +210,14 @@ def main():
         from oracle import oracle_c as oc
         Xh = X.cpu().numpy()
         Qh = Q.cpu().numpy()
-        cores = os.cpu_count() or 1
-        try:
-            cores = len(os.sched_getaffinity(0))
-        except Exception:
-            pass
+        cores = host_cores()
         sub = np.arange(0, B, max(1, B // 16))[:16]
         oi, od = oc.search_batch(METRIC_COSINE, Qh[sub], Xh, K, nthreads=cores)
         ok = bool(np.array_equal(oi, lab_h[sub]) and np.array_equal(od, dist_h[sub]))
         result["parity"] = {"checked_queries": int(len(sub)), "index_sets_equal": bool(np.array_equal(oi, lab_h[sub])),
                             "distances_bit_equal": bool(np.array_equal(od, dist_h[sub])), "ok": ok}
         if not args.no_cpu_baseline:
-            nqc = args.cpu_queries or 4 * cores
+            nqc = args.cpu_queries or 16 * cores  # 16 full-corpus scans per thread: tens of core-seconds
             nqc = min(nqc, B)
             secs, bi, bd = oc.cpu_baseline(METRIC_COSINE, Qh[:nqc], Xh, K, nthreads=cores, simd=1)
             agree = float((bi == lab_h[:nqc]).mean())

@@ -29,8 +29,6 @@ namespace {
 constexpr int kScanMaxQ = 8;          // queries per scan launch (register accumulators)
 constexpr int kGemmMinQ = 17;         // below this the exact scan path is used for everything
 constexpr int kMaxBatch = 4096;       // queries per internal batch (workspace sizing)
-constexpr int64_t kChunk0 = 4096;     // bootstrap chunk: every row is admitted
-constexpr int64_t kChunk1 = 65536;    // second chunk: admits ~kc*ln(16)
 constexpr size_t kStageBytes = 32u << 20; // pinned staging slab (x2)
 
 struct HipErr {
@@ -232,17 +230,16 @@ void run_scan_path(lb_gpu_index *h, Workspace *w, hipStream_t s, const float *d_
         int64_t pos = 0;
         int step = 0;
         while (pos < n) {
-            int64_t end;
-            if (safe) end = std::min<int64_t>(n, pos + (int64_t)(w->cap - (uint32_t)kkeep));
-            else end = step == 0 ? std::min(n, kChunk0) : step == 1 ? std::min(n, kChunk1) : n;
+            const int64_t end = chunk_end_host(step, pos, n, kkeep, w->cap, safe);
+            const bool boot = step == 0;
             {
                 ProfScope p(w, s, prof, 3);
                 launch_scan(metric, order, false, h->d_X, pos, end, h->dim, d_q, use_sel, gn, w->d_qna,
-                            mask, w->cs, nullptr, 0, s);
+                            mask, w->cs, boot, nullptr, 0, s);
             }
             {
                 ProfScope p(w, s, prof, 1);
-                launch_select(w->cs, use_sel, gn, kkeep, s);
+                launch_select(w->cs, use_sel, gn, kkeep, boot ? (uint32_t)(end - pos) : 0u, s);
             }
             pos = end;
             step++;
@@ -309,15 +306,16 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     int64_t pos = 0;
     int step = 0;
     while (pos < n) {
-        const int64_t end = step == 0 ? std::min(n, kChunk0) : step == 1 ? std::min(n, kChunk1) : n;
+        const int64_t end = chunk_end_host(step, pos, n, kc, w->cap, false);
+        const bool boot = step == 0;
         {
             ProfScope p(w, s, prof, 0);
             launch_gemm_filter(metric, h->d_X, h->d_norm2, h->d_rnorm, pos, end, h->dim, d_q, nq, mask,
-                               w->cs, s);
+                               w->cs, boot, s);
         }
         {
             ProfScope p(w, s, prof, 1);
-            launch_select(w->cs, nullptr, nq, kc, s);
+            launch_select(w->cs, nullptr, nq, kc, boot ? (uint32_t)(end - pos) : 0u, s);
         }
         pos = end;
         step++;
@@ -721,7 +719,7 @@ int lb_simd_distance_batch_flat_device(int device, int metric, int order, const 
     }
     CandState cs{};
     launch_scan(metric, order, /*raw_dot=*/true, d_flat, 0, n, dims, d_query, nullptr, 1, d_qna, nullptr, cs,
-                d_results, n, s);
+                false, d_results, n, s);
     hipError_t e = hipStreamSynchronize(s);
     if (d_qna) (void)hipFree(d_qna);
     return e == hipSuccess ? LB_OK : LB_ERR_HIP;

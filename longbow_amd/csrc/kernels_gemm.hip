@@ -35,6 +35,7 @@ struct GemmArgs {
     const uint8_t *mask;
     CandState cs;
     int n_row_tiles, n_q_tiles;
+    int boot; // bootstrap chunk: store every row at list[row - row_begin], no test, no atomics
 };
 
 __device__ __forceinline__ int swz_off(int row, int chunk)
@@ -42,12 +43,17 @@ __device__ __forceinline__ int swz_off(int row, int chunk)
     return row * BK + ((chunk ^ ((row >> 1) & 7)) << 2);
 }
 
-template <bool ALIGNED>
+// MODE 2: D % 32 == 0 and 16-B aligned rows -> unconditional 16-B loads
+// MODE 1: D % 4 == 0 and aligned -> 16-B loads, chunks past D read as zero
+// MODE 0: anything else -> guarded scalar loads
+template <int MODE>
 __device__ __forceinline__ f32x4 load_chunk(const float *base, int64_t row, int D, int k)
 {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     const float *p = base + row * (int64_t)D + k;
-    if (ALIGNED) {
+    if (MODE == 2) {
+        v = *reinterpret_cast<const f32x4 *>(p);
+    } else if (MODE == 1) {
         if (k < D) v = *reinterpret_cast<const f32x4 *>(p);
     } else {
         if (k + 0 < D) v.x = p[0];
@@ -58,7 +64,7 @@ __device__ __forceinline__ f32x4 load_chunk(const float *base, int64_t row, int 
     return v;
 }
 
-template <int METRIC, bool ALIGNED>
+template <int METRIC, int ALIGNED>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_filter_kernel(GemmArgs a)
 {
     // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so the
@@ -123,9 +129,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_filter_kernel(GemmArgs a
     }
     __syncthreads();
 
+    // Main loop.  Per K-step (BK = 32): the next stage's global loads are issued first, the
+    // fragment reads of sub-step s+1 are issued before the 16 MFMAs of sub-step s (register
+    // double buffer), and the LDS write of the next stage happens in the middle of the MFMA
+    // stream (its target buffer was released by the barrier that ended the previous K-step), so
+    // the only serial section left at the end of a K-step is the barrier itself.
     for (int kt = 0; kt < nk; kt++) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) {
+        const bool has_next = kt + 1 < nk;
+        if (has_next) {
             const int k0 = (kt + 1) * BK;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
@@ -135,15 +147,23 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_filter_kernel(GemmArgs a
         }
         const float *As = lds[cur][0];
         const float *Bs = lds[cur][1];
+        f32x4 fa[2][2], fb[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            fa[0][t] = *reinterpret_cast<const f32x4 *>(&As[swz_off(wr * 64 + t * 32 + l31, h)]);
+            fb[0][t] = *reinterpret_cast<const f32x4 *>(&Bs[swz_off(wc * 64 + t * 32 + l31, h)]);
+        }
 #pragma unroll
         for (int s = 0; s < 4; s++) {
-            const int ch = 2 * s + h; // the two lane halves take alternate 16-B chunks; the
-                                      // same k permutation is applied to A and B.
-            f32x4 fa[2], fb[2];
+            const int cb = s & 1, nb = cb ^ 1;
+            if (s < 3) {
+                const int ch = 2 * (s + 1) + h; // the two lane halves take alternate 16-B chunks;
+                                                // the same k permutation is applied to A and B.
 #pragma unroll
-            for (int t = 0; t < 2; t++) {
-                fa[t] = *reinterpret_cast<const f32x4 *>(&As[swz_off(wr * 64 + t * 32 + l31, ch)]);
-                fb[t] = *reinterpret_cast<const f32x4 *>(&Bs[swz_off(wc * 64 + t * 32 + l31, ch)]);
+                for (int t = 0; t < 2; t++) {
+                    fa[nb][t] = *reinterpret_cast<const f32x4 *>(&As[swz_off(wr * 64 + t * 32 + l31, ch)]);
+                    fb[nb][t] = *reinterpret_cast<const f32x4 *>(&Bs[swz_off(wc * 64 + t * 32 + l31, ch)]);
+                }
             }
 #pragma unroll
             for (int e = 0; e < 4; e++)
@@ -151,15 +171,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_filter_kernel(GemmArgs a
                 for (int tm = 0; tm < 2; tm++)
 #pragma unroll
                     for (int tn = 0; tn < 2; tn++)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[tm][e], fb[tn][e],
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb][tm][e], fb[cb][tn][e],
                                                                           acc[tm][tn], 0, 0, 0);
-        }
-        if (kt + 1 < nk) {
-            const int nxt = cur ^ 1;
+            if (s == 1 && has_next) {
+                const int nxt = cur ^ 1;
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                *reinterpret_cast<f32x4 *>(&lds[nxt][0][swz_off(st_row[i], st_ch[i])]) = ra[i];
-                *reinterpret_cast<f32x4 *>(&lds[nxt][1][swz_off(st_row[i], st_ch[i])]) = rb[i];
+                for (int i = 0; i < 4; i++) {
+                    *reinterpret_cast<f32x4 *>(&lds[nxt][0][swz_off(st_row[i], st_ch[i])]) = ra[i];
+                    *reinterpret_cast<f32x4 *>(&lds[nxt][1][swz_off(st_row[i], st_ch[i])]) = rb[i];
+                }
             }
         }
         __syncthreads();
@@ -188,7 +208,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_filter_kernel(GemmArgs a
                     else if (METRIC == METRIC_COS) key = -dot * a.rnorm[ri];
                     else key = -dot;
                     const uint64_t ent = pack_entry(key, (uint32_t)ri);
-                    if (ent < tau) {
+                    if (a.boot) {
+                        if (qok) list[ri - a.row_begin] = (a.mask && !a.mask[ri]) ? kEntryMax : ent;
+                    } else if (ent < tau) {
                         if (a.mask && !a.mask[ri]) continue;
                         uint32_t pos = atomicAdd(&a.cs.cnt[qj], 1u);
                         if (pos < a.cs.cap) list[pos] = ent;
@@ -201,10 +223,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_filter_kernel(GemmArgs a
 
 void launch_gemm_filter(int metric, const float *X, const float *norm2, const float *rnorm,
                         int64_t row_begin, int64_t row_end, int D, const float *Q, int nq,
-                        const uint8_t *mask, CandState cs, hipStream_t s)
+                        const uint8_t *mask, CandState cs, bool boot, hipStream_t s)
 {
     if (row_end <= row_begin || nq <= 0) return;
     GemmArgs a;
+    a.boot = boot ? 1 : 0;
     a.X = X; a.norm2 = norm2; a.rnorm = rnorm;
     a.row_begin = row_begin; a.row_end = row_end; a.D = D;
     a.Q = Q; a.nq = nq; a.mask = mask; a.cs = cs;
@@ -214,16 +237,18 @@ void launch_gemm_filter(int metric, const float *X, const float *norm2, const fl
     dim3 grid((unsigned)(groups * 8 * a.n_q_tiles));
     const bool aligned = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0) &&
                          ((reinterpret_cast<uintptr_t>(Q) & 15) == 0);
+    const int mode = !aligned ? 0 : (D % BK == 0 ? 2 : 1);
 #define LB_GEMM(M, AL) hipLaunchKernelGGL((gemm_filter_kernel<M, AL>), grid, dim3(GEMM_THREADS), 0, s, a)
-    if (aligned) {
-        if (metric == METRIC_L2) LB_GEMM(METRIC_L2, true);
-        else if (metric == METRIC_COS) LB_GEMM(METRIC_COS, true);
-        else LB_GEMM(METRIC_DOT, true);
-    } else {
-        if (metric == METRIC_L2) LB_GEMM(METRIC_L2, false);
-        else if (metric == METRIC_COS) LB_GEMM(METRIC_COS, false);
-        else LB_GEMM(METRIC_DOT, false);
-    }
+#define LB_GEMM_M(M)                 \
+    do {                             \
+        if (mode == 2) LB_GEMM(M, 2); \
+        else if (mode == 1) LB_GEMM(M, 1); \
+        else LB_GEMM(M, 0);           \
+    } while (0)
+    if (metric == METRIC_L2) LB_GEMM_M(METRIC_L2);
+    else if (metric == METRIC_COS) LB_GEMM_M(METRIC_COS);
+    else LB_GEMM_M(METRIC_DOT);
+#undef LB_GEMM_M
 #undef LB_GEMM
 }
 

@@ -62,6 +62,7 @@ struct AdcArgs {
     CandState cs;
     float *all_out; // indexed by absolute row - out_base
     int64_t out_base;
+    int boot;
 };
 
 template <bool VEC16>
@@ -97,9 +98,11 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(AdcArgs a)
         if (a.all_out) {
             a.all_out[row - a.out_base] = dist;
         } else {
-            if (a.mask && !a.mask[row]) continue;
+            const bool masked = a.mask && !a.mask[row];
             const uint64_t ent = pack_entry(dist, (uint32_t)row);
-            if (ent < tau) {
+            if (a.boot) {
+                a.cs.lists[(size_t)a.slot * a.cs.cap + (row - a.row_begin)] = masked ? kEntryMax : ent;
+            } else if (!masked && ent < tau) {
                 uint32_t pos = atomicAdd(&a.cs.cnt[a.slot], 1u);
                 if (pos < a.cs.cap) a.cs.lists[(size_t)a.slot * a.cs.cap + pos] = ent;
             }
@@ -108,11 +111,12 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(AdcArgs a)
 }
 
 void launch_adc_scan(const float *table, int M, const uint8_t *codes, int64_t row_begin, int64_t row_end,
-                     int slot, const uint8_t *mask, CandState cs, float *all_out, int64_t out_base,
-                     hipStream_t s)
+                     int slot, const uint8_t *mask, CandState cs, bool boot, float *all_out,
+                     int64_t out_base, hipStream_t s)
 {
     if (row_end <= row_begin) return;
     AdcArgs a;
+    a.boot = boot ? 1 : 0;
     a.table = table; a.M = M; a.codes = codes; a.row_begin = row_begin; a.row_end = row_end;
     a.slot = slot; a.mask = mask; a.cs = cs; a.all_out = all_out; a.out_base = out_base;
     const size_t shmem = (size_t)M * 256 * sizeof(float);

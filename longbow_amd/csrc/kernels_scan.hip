@@ -37,6 +37,7 @@ struct ScanArgs {
     int64_t ld;
     int raw_dot;
     int aligned;
+    int boot;
 };
 
 template <int ORDER>
@@ -184,7 +185,13 @@ __global__ __launch_bounds__(SC_ROWS) void scan_kernel(ScanArgs a)
             __syncthreads();
         }
 
-        if (valid && (a.all_out != nullptr || a.mask == nullptr || a.mask[myrow])) {
+        const bool masked_out = valid && a.all_out == nullptr && a.mask != nullptr && !a.mask[myrow];
+        if (valid && a.boot && masked_out) {
+#pragma unroll
+            for (int j = 0; j < NQ; j++)
+                if (j < a.nsel) a.cs.lists[(size_t)qidx[j] * a.cs.cap + (myrow - a.row_begin)] = kEntryMax;
+        }
+        if (valid && !masked_out) {
             const float nbt = nb.total();
 #pragma unroll
             for (int j = 0; j < NQ; j++) {
@@ -207,8 +214,10 @@ __global__ __launch_bounds__(SC_ROWS) void scan_kernel(ScanArgs a)
                     a.all_out[(int64_t)j * a.ld + myrow] = dist;
                 } else {
                     const uint64_t ent = pack_entry(dist, (uint32_t)myrow);
-                    if (ent < tau[j]) {
-                        const int qj = qidx[j];
+                    const int qj = qidx[j];
+                    if (a.boot) {
+                        a.cs.lists[(size_t)qj * a.cs.cap + (myrow - a.row_begin)] = ent;
+                    } else if (ent < tau[j]) {
                         uint32_t pos = atomicAdd(&a.cs.cnt[qj], 1u);
                         if (pos < a.cs.cap) a.cs.lists[(size_t)qj * a.cs.cap + pos] = ent;
                     }
@@ -228,7 +237,12 @@ __global__ __launch_bounds__(256) void scan_generic_kernel(ScanArgs a)
     const int dmain = D & ~3;
     for (int64_t row = a.row_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < a.row_end;
          row += (int64_t)gridDim.x * blockDim.x) {
-        if (a.all_out == nullptr && a.mask != nullptr && !a.mask[row]) continue;
+        if (a.all_out == nullptr && a.mask != nullptr && !a.mask[row]) {
+            if (a.boot)
+                for (int j = 0; j < a.nsel; j++)
+                    a.cs.lists[(size_t)(a.qsel ? a.qsel[j] : j) * a.cs.cap + (row - a.row_begin)] = kEntryMax;
+            continue;
+        }
         const float *x = a.X + row * (int64_t)D;
         for (int j = 0; j < a.nsel; j++) {
             const int qj = a.qsel ? a.qsel[j] : j;
@@ -282,7 +296,9 @@ __global__ __launch_bounds__(256) void scan_generic_kernel(ScanArgs a)
                 a.all_out[(int64_t)j * a.ld + row] = dist;
             } else {
                 const uint64_t ent = pack_entry(dist, (uint32_t)row);
-                if (ent < a.cs.tau[qj]) {
+                if (a.boot) {
+                    a.cs.lists[(size_t)qj * a.cs.cap + (row - a.row_begin)] = ent;
+                } else if (ent < a.cs.tau[qj]) {
                     uint32_t pos = atomicAdd(&a.cs.cnt[qj], 1u);
                     if (pos < a.cs.cap) a.cs.lists[(size_t)qj * a.cs.cap + pos] = ent;
                 }
@@ -335,11 +351,12 @@ static void launch_scan_nq(int nq_t, dim3 grid, hipStream_t s, const ScanArgs &a
 
 void launch_scan(int metric, int order, bool raw_dot, const float *X, int64_t row_begin,
                       int64_t row_end, int D, const float *Q, const int *qsel, int nsel,
-                      const float *qna, const uint8_t *mask, CandState cs, float *all_out,
+                      const float *qna, const uint8_t *mask, CandState cs, bool boot, float *all_out,
                       int64_t ld, hipStream_t s)
 {
     if (row_end <= row_begin || nsel <= 0) return;
     ScanArgs a;
+    a.boot = boot ? 1 : 0;
     a.X = X; a.row_begin = row_begin; a.row_end = row_end; a.D = D;
     a.Q = Q; a.qsel = qsel; a.nsel = nsel; a.qna = qna; a.mask = mask; a.cs = cs;
     a.all_out = all_out; a.ld = ld; a.raw_dot = raw_dot ? 1 : 0;
@@ -401,7 +418,10 @@ __global__ __launch_bounds__(256) void row_norms_kernel(const float *X, int64_t 
     if (lane == 0) {
         norm2[row] = s;
         rnorm[row] = s > 0.f ? (float)(1.0 / sqrt((double)s)) : 0.f;
-        atomicMax(maxnorm2, __builtin_bit_cast(uint32_t, s)); // s >= 0: uint order == float order
+        // s >= 0: uint order == float order.  Read first: one contended atomic per row would
+        // serialise the whole kernel on a single address.
+        const uint32_t bits = __builtin_bit_cast(uint32_t, s);
+        if (bits > __hip_atomic_load(maxnorm2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(maxnorm2, bits);
     }
 }
 

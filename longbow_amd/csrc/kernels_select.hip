@@ -74,37 +74,128 @@ static void allow_big_lds(K kernel, size_t bytes)
 }
 
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(SEL_THREADS) void select_kernel(CandState cs, const int *qsel, int kc)
+// select: keep the kc smallest of n unique u64 entries, sorted.
+//   n <= 2*kc : bitonic sort of everything.
+//   otherwise : MSB radix select (8 passes of 8 bits over the LDS copy) finds the kc-th smallest
+//               entry exactly (entries are unique: the row is part of the key), the <= pivot
+//               entries are compacted and only those kc are sorted.
+// LDS: entries u64[P] | hist u32[256] | wave sums u32[4] | scalars
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(v, off);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(SEL_THREADS) void select_kernel(CandState cs, const int *qsel, int kc,
+                                                             uint32_t boot_rows)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t sh[];
     const int q = qsel ? qsel[blockIdx.x] : blockIdx.x;
     const int tid = threadIdx.x;
-    const uint32_t raw = cs.cnt[q];
-    const uint32_t n = raw < cs.cap ? raw : cs.cap;
+    const int lane = tid & 63, wave = tid >> 6;
+    // boot_rows > 0: the bootstrap chunk stored one entry per row without atomics
+    const uint32_t raw = boot_rows ? boot_rows : cs.cnt[q];
+    uint32_t n = raw < cs.cap ? raw : cs.cap;
     uint64_t *list = cs.lists + (size_t)q * cs.cap;
     if (raw > cs.cap && tid == 0) atomicOr(&cs.flags[q], 1u);
     if (n == 0) {
-        if (tid == 0) cs.tau[q] = kEntryMax;
+        if (tid == 0) { cs.tau[q] = kEntryMax; cs.cnt[q] = 0; }
         return;
     }
     const uint32_t P = next_pow2(n);
-    for (uint32_t i = tid; i < P; i += SEL_THREADS) sh[i] = i < n ? list[i] : kEntryMax;
+    uint32_t *hist = reinterpret_cast<uint32_t *>(sh + next_pow2(cs.cap));
+    uint32_t *wsum = hist + 256;
+    uint32_t *scal = wsum + 4; // [0]=bucket [1]=need [2]=out counter [3]=valid count
+
+    if (tid == 0) { scal[2] = 0; scal[3] = 0; }
+    uint32_t myvalid = 0;
+    for (uint32_t i = tid; i < P; i += SEL_THREADS) {
+        const uint64_t e = i < n ? list[i] : kEntryMax;
+        sh[i] = e;
+        myvalid += (e != kEntryMax) ? 1u : 0u;
+    }
     __syncthreads();
-    bitonic_sort_u64(sh, P, tid, SEL_THREADS);
+    if (boot_rows) { // masked-out rows of the bootstrap chunk hold kEntryMax: count the real ones
+        if (myvalid) atomicAdd(&scal[3], myvalid);
+        __syncthreads();
+        n = scal[3];
+        __syncthreads();
+        if (n == 0) {
+            if (tid == 0) { cs.tau[q] = kEntryMax; cs.cnt[q] = 0; }
+            return;
+        }
+    }
     const uint32_t keep = n < (uint32_t)kc ? n : (uint32_t)kc;
-    for (uint32_t i = tid; i < keep; i += SEL_THREADS) list[i] = sh[i];
+
+    if (P <= 2u * next_pow2((uint32_t)kc) || n <= (uint32_t)kc) {
+        bitonic_sort_u64(sh, P, tid, SEL_THREADS); // kEntryMax padding sorts last
+        for (uint32_t i = tid; i < keep; i += SEL_THREADS) list[i] = sh[i];
+        if (tid == 0) {
+            cs.cnt[q] = keep;
+            cs.tau[q] = n >= (uint32_t)kc ? sh[kc - 1] : kEntryMax;
+        }
+        return;
+    }
+
+    // ---- radix select of the kc-th smallest (1-based rank `need`) ----
+    uint64_t prefix = 0, mask = 0;
+    uint32_t need = (uint32_t)kc;
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        hist[tid] = 0; // SEL_THREADS == 256 bins
+        __syncthreads();
+        for (uint32_t i = tid; i < P; i += SEL_THREADS) {
+            const uint64_t e = sh[i];
+            if ((e & mask) == prefix) atomicAdd(&hist[(uint32_t)(e >> shift) & 0xffu], 1u);
+        }
+        __syncthreads();
+        const uint32_t h = hist[tid];
+        uint32_t incl = wave_incl_scan(h, lane);
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t base = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) base += (w < wave) ? wsum[w] : 0u;
+        incl += base;
+        const uint32_t excl = incl - h;
+        if (excl < need && need <= incl) { scal[0] = (uint32_t)tid; scal[1] = need - excl; }
+        __syncthreads();
+        prefix |= (uint64_t)scal[0] << shift;
+        mask |= 0xffull << shift;
+        need = scal[1];
+        __syncthreads();
+    }
+    const uint64_t pivot = prefix; // the kc-th smallest entry
+    // compact the kc entries <= pivot into the front of the global list (unordered), then sort them
+    __syncthreads();
+    for (uint32_t i = tid; i < P; i += SEL_THREADS) {
+        const uint64_t e = sh[i];
+        if (e <= pivot) {
+            const uint32_t pos = atomicAdd(&scal[2], 1u);
+            list[pos] = e; // pos < kc by construction
+        }
+    }
+    __syncthreads();
+    const uint32_t Pk = next_pow2((uint32_t)kc);
+    for (uint32_t i = tid; i < Pk; i += SEL_THREADS) sh[i] = i < (uint32_t)kc ? list[i] : kEntryMax;
+    __syncthreads();
+    bitonic_sort_u64(sh, Pk, tid, SEL_THREADS);
+    for (uint32_t i = tid; i < (uint32_t)kc; i += SEL_THREADS) list[i] = sh[i];
     if (tid == 0) {
-        cs.cnt[q] = keep;
-        cs.tau[q] = n >= (uint32_t)kc ? sh[kc - 1] : kEntryMax;
+        cs.cnt[q] = (uint32_t)kc;
+        cs.tau[q] = pivot;
     }
 }
 
-void launch_select(CandState cs, const int *qsel, int nsel, int kc, hipStream_t s)
+void launch_select(CandState cs, const int *qsel, int nsel, int kc, uint32_t boot_rows, hipStream_t s)
 {
     if (nsel <= 0) return;
-    const size_t shmem = (size_t)next_pow2_host(cs.cap) * sizeof(uint64_t);
+    const size_t shmem = (size_t)next_pow2_host(cs.cap) * sizeof(uint64_t) + (256 + 4 + 4) * sizeof(uint32_t);
     allow_big_lds(select_kernel, shmem);
-    hipLaunchKernelGGL(select_kernel, dim3(nsel), dim3(SEL_THREADS), shmem, s, cs, qsel, kc);
+    hipLaunchKernelGGL(select_kernel, dim3(nsel), dim3(SEL_THREADS), shmem, s, cs, qsel, kc, boot_rows);
 }
 
 // ---------------------------------------------------------------------------

@@ -35,6 +35,30 @@ inline uint32_t next_pow2_host(uint32_t v)
     return p;
 }
 
+// Chunk schedule shared by every top-k pipeline (host side).  Chunk 0 is the bootstrap chunk
+// (all rows stored, no atomics); every later chunk is sized so that, with the threshold left by
+// the previous select (pass rate ~ keep/pos on exchangeable data), about (cap-keep)/4 entries
+// are admitted.  safe = chunks that cannot overflow whatever the data order.
+inline int64_t chunk_end_host(int step, int64_t pos, int64_t n, int64_t keep, int64_t cap, bool safe)
+{
+    int64_t end;
+    if (step == 0) {
+        int64_t boot = 4 * keep > 2048 ? 4 * keep : 2048;
+        if (boot > cap) boot = cap;
+        end = boot;
+    } else if (safe) {
+        end = pos + (cap - keep);
+    } else {
+        const int64_t target = (cap - keep) / 4;
+        // rows = target * pos / keep, in 128-bit-safe steps
+        const double rows = (double)target * (double)pos / (double)(keep > 0 ? keep : 1);
+        end = rows > 4e18 ? n : pos + (int64_t)rows;
+        if (end <= pos) end = pos + 1;
+        if (n - end < end - pos) end = n; // do not leave a tail smaller than this chunk
+    }
+    return end < n ? end : n;
+}
+
 enum : int { METRIC_L2 = 0, METRIC_COS = 1, METRIC_DOT = 2 };
 enum : int { ORDER_SEQ = 0, ORDER_UNROLL4 = 1 };
 
@@ -57,13 +81,15 @@ void launch_row_norms(const float *X, int64_t n, int D, float *norm2, float *rno
 
 // candidate generation: f32 MFMA inner products of queries [nq][D] x rows [row_begin,row_end)
 // -> metric key -> admit (key,row) < tau[q] into the query's list.
+// boot: every row is stored at list[row - row_begin] (no admission test, no atomics).
 void launch_gemm_filter(int metric, const float *X, const float *norm2, const float *rnorm,
                         int64_t row_begin, int64_t row_end, int D, const float *Q, int nq,
-                        const uint8_t *mask, CandState cs, hipStream_t s);
+                        const uint8_t *mask, CandState cs, bool boot, hipStream_t s);
 
 // per query: sort the list, keep the best kc, tau = kc-th entry (or max), flag overflow.
-// qsel (nullable): only these query slots.
-void launch_select(CandState cs, const int *qsel, int nsel, int kc, hipStream_t s);
+// qsel (nullable): only these query slots.  boot_rows > 0: the list was filled by a bootstrap
+// launch (one entry per row at index row - row_begin, no atomics; masked rows hold kEntryMax).
+void launch_select(CandState cs, const int *qsel, int nsel, int kc, uint32_t boot_rows, hipStream_t s);
 
 // exact-order distances of the kept candidates, final ordering, containment check, output.
 void launch_rerank(int metric, int order, const float *X, int D, const float *Q, int nq,
@@ -79,8 +105,8 @@ void launch_query_norms(int order, const float *Q, const int *qsel, int nsel, in
 // If all_out != nullptr writes every distance to all_out[slot*ld + row] instead (simd batch API).
 void launch_scan(int metric, int order, bool raw_dot, const float *X, int64_t row_begin,
                  int64_t row_end, int D, const float *Q, const int *qsel, int nsel,
-                 const float *qna, const uint8_t *mask, CandState cs, float *all_out, int64_t ld,
-                 hipStream_t s);
+                 const float *qna, const uint8_t *mask, CandState cs, bool boot, float *all_out,
+                 int64_t ld, hipStream_t s);
 
 // after the last select of the scan path: lists already hold exact distances.
 void launch_emit_lists(CandState cs, const int *qsel, int nsel, int k, const int64_t *ids,
@@ -100,7 +126,7 @@ void launch_build_adc_table(const float *codebooks, int M, int K, int sub, const
 // one query per launch: `table` is that query's [M*256] table; entries go to cs slot `slot`,
 // or (all_out != nullptr) every distance is written to all_out[row - out_base].
 void launch_adc_scan(const float *table, int M, const uint8_t *codes, int64_t row_begin, int64_t row_end,
-                     int slot, const uint8_t *mask, CandState cs, float *all_out, int64_t out_base,
-                     hipStream_t s);
+                     int slot, const uint8_t *mask, CandState cs, bool boot, float *all_out,
+                     int64_t out_base, hipStream_t s);
 
 } // namespace lb

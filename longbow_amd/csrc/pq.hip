@@ -34,7 +34,6 @@ uint32_t rd_u32le(const uint8_t *p)
 {
     return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
 }
-constexpr int64_t kPqChunk0 = 4096, kPqChunk1 = 65536;
 } // namespace
 
 struct lb_gpu_pq {
@@ -213,7 +212,7 @@ int lb_gpu_pq_adc_distance_batch(lb_gpu_pq *p, const float *table, int64_t row0,
         LBP_HIP(hipMalloc(&d_r, (size_t)n * 4));
         LBP_HIP(hipMemcpy(d_t, table, (size_t)p->M * 256 * 4, hipMemcpyHostToDevice));
         CandState cs{};
-        launch_adc_scan(d_t, p->M, p->d_codes, row0, row0 + n, 0, nullptr, cs, d_r, row0, nullptr);
+        launch_adc_scan(d_t, p->M, p->d_codes, row0, row0 + n, 0, nullptr, cs, false, d_r, row0, nullptr);
         LBP_HIP(hipMemcpy(results, d_r, (size_t)n * 4, hipMemcpyDeviceToHost));
     } catch (const HipErrP &e) {
         rc = pq_fail(p, e);
@@ -254,11 +253,10 @@ int lb_gpu_pq_search_device(lb_gpu_pq *p, int64_t nq, const float *d_queries, in
             int64_t pos = 0;
             int step = 0;
             while (pos < p->n) {
-                int64_t end;
-                if (safe) end = std::min<int64_t>(p->n, pos + (int64_t)(cap - (uint32_t)k));
-                else end = step == 0 ? std::min(p->n, kPqChunk0) : step == 1 ? std::min(p->n, kPqChunk1) : p->n;
-                launch_adc_scan(tab, p->M, p->d_codes, pos, end, q, nullptr, sc.cs, nullptr, 0, s);
-                launch_select(sc.cs, sc.d_slots + q, 1, k, s);
+                const int64_t end = chunk_end_host(step, pos, p->n, k, cap, safe);
+                const bool boot = step == 0;
+                launch_adc_scan(tab, p->M, p->d_codes, pos, end, q, nullptr, sc.cs, boot, nullptr, 0, s);
+                launch_select(sc.cs, sc.d_slots + q, 1, k, boot ? (uint32_t)(end - pos) : 0u, s);
                 pos = end;
                 step++;
             }
