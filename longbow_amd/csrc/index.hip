@@ -24,6 +24,8 @@
 
 using namespace lb;
 
+namespace lb { extern int g_gemm_ablation; void read_clock_probe(unsigned long long out[8], bool reset); int debug_gemm_occupancy(); }
+
 namespace {
 
 constexpr int kScanMaxQ = 8;          // queries per scan launch (register accumulators)
@@ -701,6 +703,11 @@ int lb_gpu_index_last_timing(const lb_gpu_index *hc, float ms[5], int n_launch[5
     for (int i = 0; i < 5; i++) { ms[i] = h->prof_ms[i]; n_launch[i] = h->prof_n[i]; }
     return LB_OK;
 }
+
+// profiling aid, not part of the public header: selects a timing-only ablation of the GEMM kernel
+void lb_debug_set_gemm_ablation(int v) { lb::g_gemm_ablation = v; }
+int lb_debug_gemm_occupancy(void) { return lb::debug_gemm_occupancy(); }
+void lb_debug_read_clock_probe(unsigned long long *out, int reset) { lb::read_clock_probe(out, reset != 0); }
 
 // ---- simd batch interface ---------------------------------------------------------
 int lb_simd_distance_batch_flat_device(int device, int metric, int order, const float *d_query,

@@ -24,6 +24,8 @@ constexpr int BN = 128; // queries per tile   (MFMA B operand, output cols = lan
 constexpr int BK = 32;
 constexpr int GEMM_THREADS = 256;
 
+__device__ unsigned long long g_clock_probe[8]; // profiling aid (ABL == 5 only)
+
 struct GemmArgs {
     const float *X;
     const float *norm2;
@@ -64,12 +66,18 @@ __device__ __forceinline__ f32x4 load_chunk(const float *base, int64_t row, int 
     return v;
 }
 
-template <int METRIC, int ALIGNED>
+// ABL: timing-only ablations for profiling (results are wrong unless ABL == 0):
+//   1 = no barriers, 2 = no global loads / LDS writes in the loop, 3 = no fragment reads in the loop,
+//   4 = MFMA only (1+2+3), 5 = normal + clock stamps (shader cycles vs 100 MHz real time),
+//   6 = no epilogue at all, 7 = epilogue pass 1 only (no atomics / stores)
+template <int METRIC, int ALIGNED, int ABL = 0>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_filter_kernel(GemmArgs a)
 {
     // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so the
     // n_q_tiles query tiles of one corpus tile are issued back-to-back on ONE XCD and the
     // corpus tile is pulled from HBM into that XCD's L2 once.  Placement only affects speed.
+    uint64_t stamp_entry = 0;
+    if (ABL == 5) stamp_entry = __builtin_amdgcn_s_memtime();
     const int b = blockIdx.x;
     const int xcd = b & 7;
     const int in_xcd = b >> 3;
@@ -77,7 +85,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_filter_kernel(GemmArgs a
     const int rt = (in_xcd / a.n_q_tiles) * 8 + xcd;
     if (rt >= a.n_row_tiles) return;
 
-    __shared__ __attribute__((aligned(16))) float lds[2][2][BM * BK]; // [stage][A|B]
+    // one LDS object: [stage][A|B][BM*BK] f32 tiles, then the tile's per-row side inputs
+    // (norm / 1/norm and the predicate byte), fetched once at kernel entry
+    __shared__ __attribute__((aligned(16))) float lds_all[2 * 2 * BM * BK + BM + BM / 4];
+    float(*lds)[2][BM * BK] = reinterpret_cast<float(*)[2][BM * BK]>(lds_all);
+    float *s_aux = lds_all + 2 * 2 * BM * BK;
+    uint8_t *s_vis = reinterpret_cast<uint8_t *>(s_aux + BM);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -89,6 +102,24 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_filter_kernel(GemmArgs a
     const int q0 = qt * BN;
     const int64_t last_row = a.row_end - 1;
     const int last_q = a.nq - 1;
+
+    if (tid < BM) {
+        int64_t ri = row0 + tid;
+        if (ri > last_row) ri = last_row;
+        s_aux[tid] = METRIC == METRIC_L2 ? a.norm2[ri] : (METRIC == METRIC_COS ? a.rnorm[ri] : 0.f);
+        const bool in_range = row0 + tid <= last_row;
+        s_vis[tid] = (in_range && (!a.mask || a.mask[ri])) ? (uint8_t)1 : (uint8_t)0;
+    }
+    // admission thresholds of this lane's two queries, split into (key, row)
+    float tau_key[2];
+    uint32_t tau_row[2];
+#pragma unroll
+    for (int tn = 0; tn < 2; tn++) {
+        const int qj = q0 + wc * 64 + tn * 32 + l31;
+        const uint64_t t = (qj < a.nq && !a.boot) ? a.cs.tau[qj] : 0ull;
+        tau_key[tn] = entry_key(t);
+        tau_row[tn] = entry_row(t);
+    }
 
     // staging assignment: 4 chunks of 16 B per operand per thread
     int st_row[4], st_ch[4];
@@ -129,6 +160,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_filter_kernel(GemmArgs a
     }
     __syncthreads();
 
+    uint64_t stamp_t0 = 0, stamp_r0 = 0;
+    if (ABL == 5) { stamp_t0 = __builtin_amdgcn_s_memtime(); stamp_r0 = __builtin_amdgcn_s_memrealtime(); }
     // Main loop.  Per K-step (BK = 32): the next stage's global loads are issued first, the
     // fragment reads of sub-step s+1 are issued before the 16 MFMAs of sub-step s (register
     // double buffer), and the LDS write of the next stage happens in the middle of the MFMA
@@ -136,7 +169,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_filter_kernel(GemmArgs a
     // the only serial section left at the end of a K-step is the barrier itself.
     for (int kt = 0; kt < nk; kt++) {
         const int cur = kt & 1;
-        const bool has_next = kt + 1 < nk;
+        const bool has_next = (ABL == 2 || ABL == 4) ? false : (kt + 1 < nk);
         if (has_next) {
             const int k0 = (kt + 1) * BK;
 #pragma unroll
@@ -148,15 +181,23 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_filter_kernel(GemmArgs a
         const float *As = lds[cur][0];
         const float *Bs = lds[cur][1];
         f32x4 fa[2][2], fb[2][2];
+        if ((ABL != 3 && ABL != 4) || kt == 0) {
 #pragma unroll
-        for (int t = 0; t < 2; t++) {
-            fa[0][t] = *reinterpret_cast<const f32x4 *>(&As[swz_off(wr * 64 + t * 32 + l31, h)]);
-            fb[0][t] = *reinterpret_cast<const f32x4 *>(&Bs[swz_off(wc * 64 + t * 32 + l31, h)]);
+            for (int t = 0; t < 2; t++) {
+                fa[0][t] = *reinterpret_cast<const f32x4 *>(&As[swz_off(wr * 64 + t * 32 + l31, h)]);
+                fb[0][t] = *reinterpret_cast<const f32x4 *>(&Bs[swz_off(wc * 64 + t * 32 + l31, h)]);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; t++) { fa[0][t] = ra[t]; fb[0][t] = rb[t]; }
         }
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             const int cb = s & 1, nb = cb ^ 1;
-            if (s < 3) {
+            if (ABL == 3 || ABL == 4) {
+#pragma unroll
+                for (int t = 0; t < 2; t++) { fa[nb][t] = fa[cb][t] + 1.0f; fb[nb][t] = fb[cb][t]; }
+            } else if (s < 3) {
                 const int ch = 2 * (s + 1) + h; // the two lane halves take alternate 16-B chunks;
                                                 // the same k permutation is applied to A and B.
 #pragma unroll
@@ -182,44 +223,145 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_filter_kernel(GemmArgs a
                 }
             }
         }
-        __syncthreads();
+        if (ABL != 1 && ABL != 4) __syncthreads();
+    }
+    if (ABL == 5 && threadIdx.x == 0) {
+        const uint64_t t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        atomicAdd((unsigned long long *)&g_clock_probe[0], (unsigned long long)(t1 - stamp_t0));
+        atomicAdd((unsigned long long *)&g_clock_probe[1], (unsigned long long)(r1 - stamp_r0));
+        atomicAdd((unsigned long long *)&g_clock_probe[2], 1ull);
+        atomicAdd((unsigned long long *)&g_clock_probe[3], (unsigned long long)(stamp_t0 - stamp_entry));
+        stamp_t0 = t1; // reuse: epilogue start
     }
 
     // ---- epilogue: key + admission -------------------------------------------------
     // C layout (32x32): col = lane&31 (query), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+    // All per-row side inputs (norm / mask) are fetched up front in one burst: a load per
+    // element inside the admission loop would serialise 64 L2 round trips per lane.
+    if (ABL == 6) {
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
+    float aux[2][4][4];
+    uint32_t vbits = 0; // bit (tm*16 + g*4 + e): row visible (in range and not masked out)
+#pragma unroll
+    for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int lr = wr * 64 + tm * 32 + 8 * g + 4 * h; // 4 consecutive local rows
+            const f32x4 av = *reinterpret_cast<const f32x4 *>(&s_aux[lr]);
+            const uint32_t vv = *reinterpret_cast<const uint32_t *>(&s_vis[lr]); // 4 bytes of 0/1
+            aux[tm][g][0] = av.x; aux[tm][g][1] = av.y; aux[tm][g][2] = av.z; aux[tm][g][3] = av.w;
+            // gather the four 0/1 bytes into 4 adjacent bits
+            const uint32_t nib = (vv & 1u) | ((vv >> 7) & 2u) | ((vv >> 14) & 4u) | ((vv >> 21) & 8u);
+            vbits |= nib << (tm * 16 + g * 4);
+        }
+    auto key_of = [&](float dot, float ax) -> float {
+        if (METRIC == METRIC_L2) return fmaf(-2.0f, dot, ax);
+        if (METRIC == METRIC_COS) return -dot * ax;
+        return -dot;
+    };
+    const uint32_t rloc0 = (uint32_t)(row0 + wr * 64 + 4 * h); // lane's first row (fits u32: N < 2^32)
 #pragma unroll
     for (int tn = 0; tn < 2; tn++) {
         const int qj = q0 + wc * 64 + tn * 32 + l31;
         const bool qok = qj < a.nq;
-        const uint64_t tau = qok ? a.cs.tau[qj] : 0ull;
         uint64_t *list = a.cs.lists + (size_t)(qok ? qj : 0) * a.cs.cap;
+        if (a.boot) {
+            // bootstrap chunk: entry of row r goes to list[r - row_begin]; a lane's 4 consecutive
+            // rows are 32 contiguous bytes -> two 16-B stores
+            if (qok) {
 #pragma unroll
-        for (int tm = 0; tm < 2; tm++) {
+                for (int tm = 0; tm < 2; tm++)
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int64_t rbase = row0 + wr * 64 + tm * 32 + 8 * g + 4 * h;
+                    for (int g = 0; g < 4; g++) {
+                        const int64_t rbase = row0 + wr * 64 + tm * 32 + 8 * g + 4 * h;
+                        uint64_t ent[4];
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            ent[e] = ((vbits >> (tm * 16 + g * 4 + e)) & 1u)
+                                         ? pack_entry(key_of(acc[tm][tn][4 * g + e], aux[tm][g][e]), (uint32_t)(rbase + e))
+                                         : kEntryMax;
+                        uint64_t *dst = list + (rbase - a.row_begin);
+                        if (rbase + 3 < a.row_end) {
+                            typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+                            u64x2 v0 = {ent[0], ent[1]}, v1 = {ent[2], ent[3]};
+                            *reinterpret_cast<u64x2 *>(dst) = v0;
+                            *reinterpret_cast<u64x2 *>(dst + 2) = v1;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; e++)
+                                if (rbase + e < a.row_end) dst[e] = ent[e];
+                        }
+                    }
+            }
+            continue;
+        }
+        // pass 1 (branch-free): which of this lane's 32 elements pass the admission test
+        //   entry < tau  <=>  key < tau_key, or equal keys and a lower row
+        // (float compares treat -0 == +0, matching the +0-canonical packed keys; tau of an
+        //  out-of-range query decodes to NaN, so nothing passes).
+        const float tk = tau_key[tn];
+        const uint32_t tr = tau_row[tn];
+        uint32_t bits = 0;
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+            for (int g = 0; g < 4; g++)
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    const int64_t ri = rbase + e;
-                    if (ri >= a.row_end) continue;
-                    const float dot = acc[tm][tn][4 * g + e];
-                    float key;
-                    if (METRIC == METRIC_L2) key = fmaf(-2.0f, dot, a.norm2[ri]);
-                    else if (METRIC == METRIC_COS) key = -dot * a.rnorm[ri];
-                    else key = -dot;
-                    const uint64_t ent = pack_entry(key, (uint32_t)ri);
-                    if (a.boot) {
-                        if (qok) list[ri - a.row_begin] = (a.mask && !a.mask[ri]) ? kEntryMax : ent;
-                    } else if (ent < tau) {
-                        if (a.mask && !a.mask[ri]) continue;
-                        uint32_t pos = atomicAdd(&a.cs.cnt[qj], 1u);
-                        if (pos < a.cs.cap) list[pos] = ent;
-                    }
+                    const float key = key_of(acc[tm][tn][4 * g + e], aux[tm][g][e]);
+                    const uint32_t ri = rloc0 + (uint32_t)(tm * 32 + 8 * g + e);
+                    const uint32_t lt = (uint32_t)(key < tk) | ((uint32_t)(key == tk) & (uint32_t)(ri < tr));
+                    bits |= lt << (tm * 16 + g * 4 + e);
                 }
-            }
+        bits &= vbits;
+        if (ABL == 7) { asm volatile("" ::"v"(bits)); continue; }
+        // ONE returning atomic per lane reserves the slots; the stores are fire-and-forget
+        if (bits) {
+            uint32_t pos = atomicAdd(&a.cs.cnt[qj], (uint32_t)__builtin_popcount(bits));
+#pragma unroll
+            for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        if (bits & (1u << (tm * 16 + g * 4 + e))) {
+                            const uint32_t ri = rloc0 + (uint32_t)(tm * 32 + 8 * g + e);
+                            if (pos < a.cs.cap)
+                                list[pos] = pack_entry(key_of(acc[tm][tn][4 * g + e], aux[tm][g][e]), ri);
+                            pos++;
+                        }
+                    }
         }
     }
+    if (ABL == 5) {
+        __syncthreads();
+        if (threadIdx.x == 0)
+            atomicAdd((unsigned long long *)&g_clock_probe[4], (unsigned long long)(__builtin_amdgcn_s_memtime() - stamp_t0));
+    }
 }
+
+void read_clock_probe(unsigned long long out[8], bool reset)
+{
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clock_probe), 8 * sizeof(unsigned long long));
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_clock_probe), z, sizeof z);
+    }
+}
+
+int debug_gemm_occupancy()
+{
+    int nb = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_filter_kernel<METRIC_COS, 2, 0>, GEMM_THREADS, 0);
+    return nb;
+}
+
+int g_gemm_ablation = 0; // profiling aid (tools/ablate_gemm.py); never set by the product path
 
 void launch_gemm_filter(int metric, const float *X, const float *norm2, const float *rnorm,
                         int64_t row_begin, int64_t row_end, int D, const float *Q, int nq,
@@ -238,6 +380,18 @@ void launch_gemm_filter(int metric, const float *X, const float *norm2, const fl
     const bool aligned = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0) &&
                          ((reinterpret_cast<uintptr_t>(Q) & 15) == 0);
     const int mode = !aligned ? 0 : (D % BK == 0 ? 2 : 1);
+    if (g_gemm_ablation > 0 && metric == METRIC_COS && mode == 2) {
+        switch (g_gemm_ablation) {
+        case 1: hipLaunchKernelGGL((gemm_filter_kernel<METRIC_COS, 2, 1>), grid, dim3(GEMM_THREADS), 0, s, a); return;
+        case 2: hipLaunchKernelGGL((gemm_filter_kernel<METRIC_COS, 2, 2>), grid, dim3(GEMM_THREADS), 0, s, a); return;
+        case 3: hipLaunchKernelGGL((gemm_filter_kernel<METRIC_COS, 2, 3>), grid, dim3(GEMM_THREADS), 0, s, a); return;
+        case 4: hipLaunchKernelGGL((gemm_filter_kernel<METRIC_COS, 2, 4>), grid, dim3(GEMM_THREADS), 0, s, a); return;
+        case 5: hipLaunchKernelGGL((gemm_filter_kernel<METRIC_COS, 2, 5>), grid, dim3(GEMM_THREADS), 0, s, a); return;
+        case 6: hipLaunchKernelGGL((gemm_filter_kernel<METRIC_COS, 2, 6>), grid, dim3(GEMM_THREADS), 0, s, a); return;
+        case 7: hipLaunchKernelGGL((gemm_filter_kernel<METRIC_COS, 2, 7>), grid, dim3(GEMM_THREADS), 0, s, a); return;
+        default: break;
+        }
+    }
 #define LB_GEMM(M, AL) hipLaunchKernelGGL((gemm_filter_kernel<M, AL>), grid, dim3(GEMM_THREADS), 0, s, a)
 #define LB_GEMM_M(M)                 \
     do {                             \
