@@ -71,7 +71,10 @@ SIGNATURES = [
 
 
 def load():
-    """dlopen the HIP library and bind every declared symbol (no GPU needed for this)."""
+    """dlopen the HIP library and bind every declared symbol (no GPU needed for this).
+
+    Note for processes that also use PyTorch-ROCm (bench.py, sharded search): import torch BEFORE
+    the first call here.  torch ships its own HIP runtime and must initialise first."""
     global _lib
     if _lib is not None:
         return _lib

@@ -14,6 +14,8 @@
 // (row>>1)&7 so the ds_read_b128 fragment reads are bank-conflict free.
 #include "lb_device.h"
 
+#include <cstdlib>
+
 namespace lb {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -70,7 +72,10 @@ __device__ __forceinline__ f32x4 load_chunk(const float *base, int64_t row, int 
 //   1 = no barriers, 2 = no global loads / LDS writes in the loop, 3 = no fragment reads in the loop,
 //   4 = MFMA only (1+2+3), 5 = normal + clock stamps (shader cycles vs 100 MHz real time),
 //   6 = no epilogue at all, 7 = epilogue pass 1 only (no atomics / stores)
-template <int METRIC, int ALIGNED, int ABL = 0>
+// GLDS: stage tiles with direct-to-LDS DMA loads (global_load_lds_dwordx4; needs ALIGNED == 2).
+// The LDS image is lane-linear per wave instruction (base + lane*16), so the chunk swizzle is
+// applied to the per-lane SOURCE address; the image is identical to the register-staged one.
+template <int METRIC, int ALIGNED, int ABL = 0, bool GLDS = false>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_filter_kernel(GemmArgs a)
 {
     // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so the
@@ -147,16 +152,51 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_filter_kernel(GemmArgs a
     const int nk = (a.D + BK - 1) / BK;
     f32x4 ra[4], rb[4];
 
-    // prologue: stage 0
+    // GLDS staging: wave w issues instructions 4w..4w+3 per operand; instruction j fills LDS rows
+    // 8j..8j+7 (1 KiB); lane l lands at (row 8j + l/8, chunk position l%8) and therefore fetches
+    // source chunk (l%8) ^ ((row>>1)&7) of that row.
+    const float *gsrcA[4], *gsrcB[4];
+    if (GLDS) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        ra[i] = load_chunk<ALIGNED>(a.X, st_xrow[i], a.D, st_ch[i] * 4);
-        rb[i] = load_chunk<ALIGNED>(a.Q, st_qrow[i], a.D, st_ch[i] * 4);
+        for (int i = 0; i < 4; i++) {
+            const int j = wave * 4 + i;
+            const int row = j * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            int64_t xr = row0 + row;
+            if (xr > last_row) xr = last_row;
+            int qr = q0 + row;
+            if (qr > last_q) qr = last_q;
+            gsrcA[i] = a.X + xr * (int64_t)a.D + 4 * c;
+            gsrcB[i] = a.Q + (int64_t)qr * a.D + 4 * c;
+        }
     }
+    auto glds_stage = [&](int stage, int k0) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        *reinterpret_cast<f32x4 *>(&lds[0][0][swz_off(st_row[i], st_ch[i])]) = ra[i];
-        *reinterpret_cast<f32x4 *>(&lds[0][1][swz_off(st_row[i], st_ch[i])]) = rb[i];
+        for (int i = 0; i < 4; i++) {
+            const int j = wave * 4 + i;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(gsrcA[i] + k0),
+                (__attribute__((address_space(3))) void *)(&lds[stage][0][j * 8 * BK]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(gsrcB[i] + k0),
+                (__attribute__((address_space(3))) void *)(&lds[stage][1][j * 8 * BK]), 16, 0, 0);
+        }
+    };
+
+    // prologue: stage 0
+    if (GLDS) {
+        glds_stage(0, 0);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            ra[i] = load_chunk<ALIGNED>(a.X, st_xrow[i], a.D, st_ch[i] * 4);
+            rb[i] = load_chunk<ALIGNED>(a.Q, st_qrow[i], a.D, st_ch[i] * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            *reinterpret_cast<f32x4 *>(&lds[0][0][swz_off(st_row[i], st_ch[i])]) = ra[i];
+            *reinterpret_cast<f32x4 *>(&lds[0][1][swz_off(st_row[i], st_ch[i])]) = rb[i];
+        }
     }
     __syncthreads();
 
@@ -172,10 +212,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_filter_kernel(GemmArgs a
         const bool has_next = (ABL == 2 || ABL == 4) ? false : (kt + 1 < nk);
         if (has_next) {
             const int k0 = (kt + 1) * BK;
+            if (GLDS) {
+                glds_stage(cur ^ 1, k0);
+            } else {
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                ra[i] = load_chunk<ALIGNED>(a.X, st_xrow[i], a.D, k0 + st_ch[i] * 4);
-                rb[i] = load_chunk<ALIGNED>(a.Q, st_qrow[i], a.D, k0 + st_ch[i] * 4);
+                for (int i = 0; i < 4; i++) {
+                    ra[i] = load_chunk<ALIGNED>(a.X, st_xrow[i], a.D, k0 + st_ch[i] * 4);
+                    rb[i] = load_chunk<ALIGNED>(a.Q, st_qrow[i], a.D, k0 + st_ch[i] * 4);
+                }
             }
         }
         const float *As = lds[cur][0];
@@ -214,7 +258,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_filter_kernel(GemmArgs a
                     for (int tn = 0; tn < 2; tn++)
                         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb][tm][e], fb[cb][tn][e],
                                                                           acc[tm][tn], 0, 0, 0);
-            if (s == 1 && has_next) {
+            if (!GLDS && s == 1 && has_next) {
                 const int nxt = cur ^ 1;
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
@@ -361,6 +405,7 @@ int debug_gemm_occupancy()
     return nb;
 }
 
+int g_gemm_glds = 0;     // A/B switch (tools/ablate_gemm.py): -1 = register staging
 int g_gemm_ablation = 0; // profiling aid (tools/ablate_gemm.py); never set by the product path
 
 void launch_gemm_filter(int metric, const float *X, const float *norm2, const float *rnorm,
@@ -391,6 +436,15 @@ void launch_gemm_filter(int metric, const float *X, const float *norm2, const fl
         case 7: hipLaunchKernelGGL((gemm_filter_kernel<METRIC_COS, 2, 7>), grid, dim3(GEMM_THREADS), 0, s, a); return;
         default: break;
         }
+    }
+    // direct-to-LDS staging is the default for the aligned, D % 32 == 0 case (LB_GEMM_GLDS=0 or
+    // g_gemm_glds = -1 selects the register-staged pipeline for A/B runs)
+    static const bool env_noglds = [] { const char *e = getenv("LB_GEMM_GLDS"); return e && e[0] == '0'; }();
+    if (g_gemm_glds >= 0 && !env_noglds && g_gemm_ablation == 0 && mode == 2) {
+        if (metric == METRIC_L2) hipLaunchKernelGGL((gemm_filter_kernel<METRIC_L2, 2, 0, true>), grid, dim3(GEMM_THREADS), 0, s, a);
+        else if (metric == METRIC_COS) hipLaunchKernelGGL((gemm_filter_kernel<METRIC_COS, 2, 0, true>), grid, dim3(GEMM_THREADS), 0, s, a);
+        else hipLaunchKernelGGL((gemm_filter_kernel<METRIC_DOT, 2, 0, true>), grid, dim3(GEMM_THREADS), 0, s, a);
+        return;
     }
 #define LB_GEMM(M, AL) hipLaunchKernelGGL((gemm_filter_kernel<M, AL>), grid, dim3(GEMM_THREADS), 0, s, a)
 #define LB_GEMM_M(M)                 \

@@ -3,6 +3,14 @@ import sys
 
 import pytest
 
+# torch bundles its own HIP runtime; when it is going to be used in the same process as
+# liblongbow_gpu.so it has to be loaded FIRST, otherwise its later initialisation finds the
+# device already claimed by the system runtime ("No HIP GPUs are available").
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -17,11 +17,13 @@ od = torch.empty((B, K), device="cuda"); ol = torch.empty((B, K), dtype=torch.in
 raw = C.CDLL(_lib.SO_PATH); raw.lb_debug_set_gemm_ablation.argtypes = [C.c_int]
 idx.set_profiling(True)
 print('occupancy API: blocks/CU =', raw.lb_debug_gemm_occupancy(), flush=True)
-names = {0: "baseline", 1: "no barrier", 2: "no global loads/LDS writes", 3: "no fragment reads", 4: "MFMA only", 5: "baseline + clock stamps", 6: "no epilogue", 7: "epilogue pass 1 only"}
+raw.lb_debug_set_gemm_glds.argtypes = [C.c_int]
+names = {-1: "GLDS staging (default)", 0: "register staging", 1: "no barrier", 2: "no global loads/LDS writes", 3: "no fragment reads", 4: "MFMA only", 5: "baseline + clock stamps", 6: "no epilogue", 7: "epilogue pass 1 only"}
 res = {k: [] for k in names}
 for rnd in range(4):
     for v in names:
-        raw.lb_debug_set_gemm_ablation(v)
+        raw.lb_debug_set_gemm_glds(0 if v == -1 else -1)
+        raw.lb_debug_set_gemm_ablation(max(v, 0))
         try:
             idx.search_device(B, Q.data_ptr(), K, od.data_ptr(), ol.data_ptr())
         except Exception as e:
@@ -29,6 +31,7 @@ for rnd in range(4):
         if rnd > 0:
             res[v].append(idx.last_timing()["gemm"][0])
 raw.lb_debug_set_gemm_ablation(0)
+raw.lb_debug_set_gemm_glds(0)
 probe = (C.c_ulonglong * 8)()
 raw.lb_debug_read_clock_probe(probe, 1)
 if probe[1]:
