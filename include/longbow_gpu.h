@@ -109,6 +109,19 @@ int lb_gpu_index_search_device(lb_gpu_index *h, int64_t nq, const float *d_queri
  * NULL clears it.  Rows with mask 0 never appear in results. */
 int lb_gpu_index_set_filter(lb_gpu_index *h, const uint8_t *mask, int64_t n);
 
+/* simd.CompareOp values (internal/simd/simd.go:38-45) */
+typedef enum { LB_CMP_EQ = 0, LB_CMP_NEQ = 1, LB_CMP_GT = 2, LB_CMP_GE = 3, LB_CMP_LT = 4, LB_CMP_LE = 5 } lb_compare_op;
+
+/* Evaluate a metadata predicate ON THE DEVICE straight into the index's row mask: the GPU form of
+ * query.int64FilterOp/float32FilterOp.MatchBitmap (internal/query/filter_evaluator.go:79-115,205-241).
+ * column has ntotal values (host pointer, e.g. an Arrow Int64/Float32 values buffer); validity is the
+ * Arrow validity bitmap (LSB first; NULL = no nulls; nulls never match); combine 0 replaces the
+ * mask, 1 ANDs into it (FilterEvaluator's AND chain, simd.AndBytes). */
+int lb_gpu_index_filter_int64(lb_gpu_index *h, const int64_t *column, int64_t n, int64_t value, int op,
+                              const uint8_t *validity, int64_t validity_offset, int combine);
+int lb_gpu_index_filter_float32(lb_gpu_index *h, const float *column, int64_t n, float value, int op,
+                                const uint8_t *validity, int64_t validity_offset, int combine);
+
 /* Per-search telemetry of the most recent search on this handle (for benches):
  * number of queries that needed the exact-scan fallback. */
 int64_t lb_gpu_index_last_fallbacks(const lb_gpu_index *h);
@@ -124,6 +137,12 @@ int lb_simd_distance_batch_flat(int device, int metric, int order, const float *
 int lb_simd_distance_batch_flat_device(int device, int metric, int order, const float *d_query,
                                        const float *d_flat, int64_t n, int dims,
                                        float *d_results, void *stream);
+
+/* simd.MatchInt64 / simd.MatchFloat32 (internal/simd/simd.go:570-761): dst[i] = src[i] OP val ? 1 : 0,
+ * and simd.AndBytes (simd.go:119-125): dst[i] &= src[i].  Host pointers. */
+int lb_simd_match_int64(int device, const int64_t *src, int64_t n, int64_t value, int op, uint8_t *dst);
+int lb_simd_match_float32(int device, const float *src, int64_t n, float value, int op, uint8_t *dst);
+int lb_simd_and_bytes(int device, uint8_t *dst, const uint8_t *src, int64_t n);
 
 /* ---- internal/pq on the GPU ---------------------------------------------------
  * Codebooks arrive as the reference's serialised blob (internal/pq/persistence.go:9-35:

@@ -47,7 +47,12 @@ SIGNATURES = [
     ("lb_gpu_index_search", _i, [_vp, _i64, _vp, _i, _vp, _vp]),
     ("lb_gpu_index_search_device", _i, [_vp, _i64, _vp, _i, _vp, _vp, _vp]),
     ("lb_gpu_index_set_filter", _i, [_vp, _vp, _i64]),
+    ("lb_gpu_index_filter_int64", _i, [_vp, _vp, _i64, _i64, _i, _vp, _i64, _i]),
+    ("lb_gpu_index_filter_float32", _i, [_vp, _vp, _i64, C.c_float, _i, _vp, _i64, _i]),
     ("lb_gpu_index_last_fallbacks", _i64, [_vp]),
+    ("lb_simd_match_int64", _i, [_i, _vp, _i64, _i64, _i, _vp]),
+    ("lb_simd_match_float32", _i, [_i, _vp, _i64, C.c_float, _i, _vp]),
+    ("lb_simd_and_bytes", _i, [_i, _vp, _vp, _i64]),
     ("lb_simd_distance_batch_flat", _i, [_i, _i, _i, _vp, _vp, _i64, _i, _vp]),
     ("lb_simd_distance_batch_flat_device", _i, [_i, _i, _i, _vp, _vp, _i64, _i, _vp, _vp]),
     ("lb_gpu_pq_new", _vp, [_i, _vp, _sz, _ip]),

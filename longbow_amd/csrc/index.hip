@@ -432,6 +432,70 @@ bool device_ok(int device)
 
 } // namespace
 
+template <typename T>
+static int filter_column(lb_gpu_index *h, const T *column, int64_t n, T value, int op, const uint8_t *validity,
+                         int64_t voff, int combine)
+{
+    if (!h || op < 0 || op > 5 || voff < 0) return LB_ERR_INVALID_ARG;
+    std::unique_lock<std::shared_mutex> g(h->mu);
+    if (h->closed) return LB_ERR_CLOSED;
+    if (n != h->n || (n > 0 && !column)) {
+        h->set_error("filter column has %lld values, index has %lld rows", (long long)n, (long long)h->n);
+        return LB_ERR_INVALID_ARG;
+    }
+    if (n == 0) { h->has_mask = true; return LB_OK; }
+    T *d_col = nullptr;
+    uint8_t *d_val = nullptr;
+    int rc = LB_OK;
+    try {
+        LB_HIP(hipSetDevice(h->device));
+        LB_HIP(hipMalloc(&d_col, (size_t)n * sizeof(T)));
+        LB_HIP(hipMemcpy(d_col, column, (size_t)n * sizeof(T), hipMemcpyHostToDevice));
+        if (validity) {
+            const size_t vb = (size_t)((voff + n + 7) / 8);
+            LB_HIP(hipMalloc(&d_val, vb));
+            LB_HIP(hipMemcpy(d_val, validity, vb, hipMemcpyHostToDevice));
+        }
+        const int comb = (combine && h->has_mask) ? 1 : 0; // AND into "no filter" == replace
+        if constexpr (sizeof(T) == 8)
+            launch_match_int64(reinterpret_cast<const int64_t *>(d_col), n, (int64_t)value, op, d_val, voff, h->d_mask, comb, h->add_stream);
+        else
+            launch_match_float32(reinterpret_cast<const float *>(d_col), n, (float)value, op, d_val, voff, h->d_mask, comb, h->add_stream);
+        LB_HIP(hipStreamSynchronize(h->add_stream));
+        h->has_mask = true;
+    } catch (const HipErr &e) {
+        rc = fail_hip(h, e);
+    }
+    if (d_col) (void)hipFree(d_col);
+    if (d_val) (void)hipFree(d_val);
+    return rc;
+}
+
+
+template <typename T>
+static int match_host(int device, const T *src, int64_t n, T value, int op, uint8_t *dst)
+{
+    if (n < 0 || op < 0 || op > 5) return LB_ERR_INVALID_ARG;
+    if (n == 0) return LB_OK;
+    if (!src || !dst) return LB_ERR_INVALID_ARG;
+    if (!device_ok(device)) return LB_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return LB_ERR_HIP;
+    T *d_s = nullptr;
+    uint8_t *d_d = nullptr;
+    int rc = LB_OK;
+    if (hipMalloc(&d_s, (size_t)n * sizeof(T)) != hipSuccess || hipMalloc(&d_d, (size_t)n) != hipSuccess) rc = LB_ERR_OOM;
+    else if (hipMemcpy(d_s, src, (size_t)n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) rc = LB_ERR_HIP;
+    else {
+        if constexpr (sizeof(T) == 8) launch_match_int64(reinterpret_cast<const int64_t *>(d_s), n, (int64_t)value, op, nullptr, 0, d_d, 0, nullptr);
+        else launch_match_float32(reinterpret_cast<const float *>(d_s), n, (float)value, op, nullptr, 0, d_d, 0, nullptr);
+        if (hipMemcpy(dst, d_d, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) rc = LB_ERR_HIP;
+    }
+    if (d_s) (void)hipFree(d_s);
+    if (d_d) (void)hipFree(d_d);
+    return rc;
+}
+
+
 // ===========================================================================
 // C ABI
 // ===========================================================================
@@ -611,6 +675,49 @@ int lb_gpu_index_set_filter(lb_gpu_index *h, const uint8_t *mask, int64_t n)
         return fail_hip(h, e);
     }
     return LB_OK;
+}
+
+int lb_gpu_index_filter_int64(lb_gpu_index *h, const int64_t *column, int64_t n, int64_t value, int op,
+                              const uint8_t *validity, int64_t validity_offset, int combine)
+{
+    return filter_column<int64_t>(h, column, n, value, op, validity, validity_offset, combine);
+}
+
+int lb_gpu_index_filter_float32(lb_gpu_index *h, const float *column, int64_t n, float value, int op,
+                                const uint8_t *validity, int64_t validity_offset, int combine)
+{
+    return filter_column<float>(h, column, n, value, op, validity, validity_offset, combine);
+}
+
+int lb_simd_match_int64(int device, const int64_t *src, int64_t n, int64_t value, int op, uint8_t *dst)
+{
+    return match_host<int64_t>(device, src, n, value, op, dst);
+}
+
+int lb_simd_match_float32(int device, const float *src, int64_t n, float value, int op, uint8_t *dst)
+{
+    return match_host<float>(device, src, n, value, op, dst);
+}
+
+int lb_simd_and_bytes(int device, uint8_t *dst, const uint8_t *src, int64_t n)
+{
+    if (n < 0) return LB_ERR_INVALID_ARG;
+    if (n == 0) return LB_OK;
+    if (!dst || !src) return LB_ERR_INVALID_ARG;
+    if (!device_ok(device)) return LB_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return LB_ERR_HIP;
+    uint8_t *d_a = nullptr, *d_b = nullptr;
+    int rc = LB_OK;
+    if (hipMalloc(&d_a, (size_t)n) != hipSuccess || hipMalloc(&d_b, (size_t)n) != hipSuccess) rc = LB_ERR_OOM;
+    else if (hipMemcpy(d_a, dst, (size_t)n, hipMemcpyHostToDevice) != hipSuccess ||
+             hipMemcpy(d_b, src, (size_t)n, hipMemcpyHostToDevice) != hipSuccess) rc = LB_ERR_HIP;
+    else {
+        launch_and_bytes(d_a, d_b, n, nullptr);
+        if (hipMemcpy(dst, d_a, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) rc = LB_ERR_HIP;
+    }
+    if (d_a) (void)hipFree(d_a);
+    if (d_b) (void)hipFree(d_b);
+    return rc;
 }
 
 int64_t lb_gpu_index_last_fallbacks(const lb_gpu_index *h) { return h ? h->last_fallbacks.load() : 0; }

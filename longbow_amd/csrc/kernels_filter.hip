@@ -1,0 +1,107 @@
+// kernels_filter.hip -- metadata predicate masks (SURVEY f-3).
+//
+// simd.MatchInt64 / simd.MatchFloat32 (internal/simd/simd.go:570-761): dst[i] = (src[i] OP val) ? 1 : 0,
+// one byte per element, OP in {Eq, Neq, Gt, Ge, Lt, Le} (simd.CompareOp, simd.go:38-45);
+// simd.AndBytes (simd.go:119-125): dst[i] &= src[i];
+// nulls -> 0 as query.*FilterOp.MatchBitmap does (internal/query/filter_evaluator.go:106-114,232-240),
+// with the validity given as an Arrow LSB-first bitmap.
+// Pure HBM-bound byte/integer work: 16 elements per lane, 16-B mask stores.
+#include "lb_device.h"
+
+namespace lb {
+
+enum : int { OP_EQ = 0, OP_NEQ = 1, OP_GT = 2, OP_GE = 3, OP_LT = 4, OP_LE = 5 };
+
+template <typename T>
+__device__ __forceinline__ uint8_t cmp(T v, T val, int op)
+{
+    switch (op) {
+    case OP_EQ: return v == val;
+    case OP_NEQ: return v != val;
+    case OP_GT: return v > val;
+    case OP_GE: return v >= val;
+    case OP_LT: return v < val;
+    default: return v <= val;
+    }
+}
+
+// combine: 0 = dst = m, 1 = dst &= m
+template <typename T>
+__global__ __launch_bounds__(256) void match_kernel(const T *src, int64_t n, T val, int op,
+                                                    const uint8_t *validity, int64_t valid_offset,
+                                                    uint8_t *dst, int combine)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 16;
+    for (int64_t base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; base < n; base += stride) {
+        uint8_t m[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int64_t i = base + j;
+            uint8_t r = 0;
+            if (i < n) {
+                r = cmp<T>(src[i], val, op);
+                if (validity) {
+                    const int64_t b = i + valid_offset;
+                    r &= (validity[b >> 3] >> (b & 7)) & 1u;
+                }
+            }
+            m[j] = r;
+        }
+        if (base + 16 <= n && ((reinterpret_cast<uintptr_t>(dst + base) & 15) == 0)) {
+            uint4 out;
+            uint32_t w[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                w[k] = (uint32_t)m[4 * k] | ((uint32_t)m[4 * k + 1] << 8) | ((uint32_t)m[4 * k + 2] << 16) |
+                       ((uint32_t)m[4 * k + 3] << 24);
+            out = make_uint4(w[0], w[1], w[2], w[3]);
+            uint4 *p = reinterpret_cast<uint4 *>(dst + base);
+            if (combine) {
+                const uint4 old = *p;
+                out.x &= old.x; out.y &= old.y; out.z &= old.z; out.w &= old.w;
+            }
+            *p = out;
+        } else {
+            for (int j = 0; j < 16 && base + j < n; j++)
+                dst[base + j] = combine ? (uint8_t)(dst[base + j] & m[j]) : m[j];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void and_bytes_kernel(uint8_t *dst, const uint8_t *src, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] &= src[i];
+}
+
+static unsigned grid_for(int64_t n, int per_thread)
+{
+    int64_t blocks = (n + 256 * per_thread - 1) / (256 * per_thread);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
+void launch_match_int64(const int64_t *src, int64_t n, int64_t val, int op, const uint8_t *validity,
+                        int64_t valid_offset, uint8_t *dst, int combine, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(match_kernel<int64_t>, dim3(grid_for(n, 16)), dim3(256), 0, s, src, n, val, op, validity,
+                       valid_offset, dst, combine);
+}
+
+void launch_match_float32(const float *src, int64_t n, float val, int op, const uint8_t *validity,
+                          int64_t valid_offset, uint8_t *dst, int combine, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(match_kernel<float>, dim3(grid_for(n, 16)), dim3(256), 0, s, src, n, val, op, validity,
+                       valid_offset, dst, combine);
+}
+
+void launch_and_bytes(uint8_t *dst, const uint8_t *src, int64_t n, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(and_bytes_kernel, dim3(grid_for(n, 1)), dim3(256), 0, s, dst, src, n);
+}
+
+} // namespace lb

@@ -129,4 +129,11 @@ void launch_adc_scan(const float *table, int M, const uint8_t *codes, int64_t ro
                      int slot, const uint8_t *mask, CandState cs, bool boot, float *all_out,
                      int64_t out_base, hipStream_t s);
 
+// predicate masks (kernels_filter.hip): op = simd.CompareOp value; validity = Arrow LSB bitmap or null
+void launch_match_int64(const int64_t *src, int64_t n, int64_t val, int op, const uint8_t *validity,
+                        int64_t valid_offset, uint8_t *dst, int combine, hipStream_t s);
+void launch_match_float32(const float *src, int64_t n, float val, int op, const uint8_t *validity,
+                          int64_t valid_offset, uint8_t *dst, int combine, hipStream_t s);
+void launch_and_bytes(uint8_t *dst, const uint8_t *src, int64_t n, hipStream_t s);
+
 } // namespace lb

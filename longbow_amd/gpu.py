@@ -114,6 +114,28 @@ class Index:
         mask = np.ascontiguousarray(mask, np.uint8)
         _lib.check(self._lib.lb_gpu_index_set_filter(self._h, mask.ctypes.data, mask.size), self._h)
 
+    def filter_column(self, column, operator, value, validity=None, validity_offset=0, combine=False):
+        """Evaluate `column OP value` on the device into the row mask (query.Filter semantics,
+        internal/query/filter_evaluator.go:79-115,205-241).  column: int64 or float32, ntotal values;
+        validity: Arrow LSB validity bitmap bytes or None; combine=True ANDs into the current mask."""
+        from .simd import parse_operator
+        self._live()
+        op = int(parse_operator(operator))
+        column = np.ascontiguousarray(column)
+        vptr = None
+        if validity is not None:
+            validity = np.ascontiguousarray(np.frombuffer(validity, np.uint8) if not isinstance(validity, np.ndarray) else validity, np.uint8)
+            vptr = validity.ctypes.data
+        if column.dtype == np.int64:
+            rc = self._lib.lb_gpu_index_filter_int64(self._h, column.ctypes.data, column.size, int(value), op, vptr,
+                                                     validity_offset, 1 if combine else 0)
+        elif column.dtype == np.float32:
+            rc = self._lib.lb_gpu_index_filter_float32(self._h, column.ctypes.data, column.size, float(value), op,
+                                                       vptr, validity_offset, 1 if combine else 0)
+        else:
+            raise TypeError(f"unsupported filter column type {column.dtype} (int64 / float32)")
+        _lib.check(rc, self._h)
+
     def set_profiling(self, on):
         self._live()
         _lib.check(self._lib.lb_gpu_index_set_profiling(self._h, 1 if on else 0), self._h)

@@ -128,6 +128,13 @@ class ShardedSearcher:
             if self.dist.get_backend(self.group) == "nccl":  # RCCL: one fused all-gather per tensor
                 self.dist.all_gather_into_tensor(b["da"], b["d"], group=self.group)
                 self.dist.all_gather_into_tensor(b["la"], b["l"], group=self.group)
+            elif b["d"].is_cuda:  # gloo transport with device tensors (tests on one GPU): stage via host
+                hd = [t.empty(b["d"].shape, dtype=t.float32) for _ in range(self.world)]
+                hl = [t.empty(b["l"].shape, dtype=t.int64) for _ in range(self.world)]
+                self.dist.all_gather(hd, b["d"].cpu(), group=self.group)
+                self.dist.all_gather(hl, b["l"].cpu(), group=self.group)
+                b["da"].copy_(t.stack(hd))
+                b["la"].copy_(t.stack(hl))
             else:  # gloo (CPU tests)
                 self.dist.all_gather([b["da"][r] for r in range(self.world)], b["d"], group=self.group)
                 self.dist.all_gather([b["la"][r] for r in range(self.world)], b["l"], group=self.group)

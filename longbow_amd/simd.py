@@ -111,3 +111,55 @@ def DotProduct(a, b, order=Order.Seq, device=0):
     r = np.empty(1, np.float32)
     _batch_flat(MetricType.DotProduct, a, b, 1, a.size, r, order, device)
     return r[0]
+
+
+class CompareOp(enum.IntEnum):
+    """simd.CompareOp (internal/simd/simd.go:38-45)"""
+    Eq = 0
+    Neq = 1
+    Gt = 2
+    Ge = 3
+    Lt = 4
+    Le = 5
+
+
+_OPERATORS = {"=": CompareOp.Eq, "eq": CompareOp.Eq, "==": CompareOp.Eq, "!=": CompareOp.Neq, "neq": CompareOp.Neq,
+              ">": CompareOp.Gt, "gt": CompareOp.Gt, ">=": CompareOp.Ge, "ge": CompareOp.Ge,
+              "<": CompareOp.Lt, "lt": CompareOp.Lt, "<=": CompareOp.Le, "le": CompareOp.Le}
+
+
+def parse_operator(op):
+    """operator strings of query.Filter (internal/query/filter_evaluator.go:80-93)"""
+    if isinstance(op, str):
+        if op not in _OPERATORS:
+            raise ValueError(f"unsupported operator {op!r}")
+        return _OPERATORS[op]
+    return CompareOp(int(op))
+
+
+def MatchInt64(src, val, op, dst, device=0):
+    """simd.MatchInt64: dst[i] = 1 if src[i] OP val else 0"""
+    lib = _lib.require_gpu(device)
+    src = np.ascontiguousarray(src, np.int64)
+    if src.size != dst.size:
+        raise ValueError("simd: length mismatch")  # simd.go:573-575
+    _lib.check(lib.lb_simd_match_int64(device, src.ctypes.data, src.size, int(val), int(parse_operator(op)),
+                                       dst.ctypes.data))
+
+
+def MatchFloat32(src, val, op, dst, device=0):
+    lib = _lib.require_gpu(device)
+    src = np.ascontiguousarray(src, np.float32)
+    if src.size != dst.size:
+        raise ValueError("simd: length mismatch")
+    _lib.check(lib.lb_simd_match_float32(device, src.ctypes.data, src.size, float(val), int(parse_operator(op)),
+                                         dst.ctypes.data))
+
+
+def AndBytes(dst, src, device=0):
+    """simd.AndBytes: dst[i] &= src[i]"""
+    lib = _lib.require_gpu(device)
+    src = np.ascontiguousarray(src, np.uint8)
+    if src.size != dst.size:
+        raise ValueError("simd: length mismatch")  # simd.go:120-122
+    _lib.check(lib.lb_simd_and_bytes(device, dst.ctypes.data, src.ctypes.data, dst.size))

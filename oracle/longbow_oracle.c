@@ -532,6 +532,30 @@ int lbo_merge_sorted_streams(const int64_t *ids, const float *scores, const int 
 }
 
 /* ======================================================================
+ * Predicate masks
+ * ====================================================================== */
+#define LBO_MATCH_BODY                                   \
+    for (int64_t i = 0; i < n; i++) {                    \
+        int r;                                           \
+        switch (op) {                                    \
+        case 0: r = src[i] == val; break;                \
+        case 1: r = src[i] != val; break;                \
+        case 2: r = src[i] > val; break;                 \
+        case 3: r = src[i] >= val; break;                \
+        case 4: r = src[i] < val; break;                 \
+        default: r = src[i] <= val; break;               \
+        }                                                \
+        dst[i] = (uint8_t)r;                             \
+    }
+
+void lbo_match_int64(const int64_t *src, int64_t n, int64_t val, int op, uint8_t *dst) { LBO_MATCH_BODY }
+void lbo_match_float32(const float *src, int64_t n, float val, int op, uint8_t *dst) { LBO_MATCH_BODY }
+void lbo_and_bytes(uint8_t *dst, const uint8_t *src, int64_t n)
+{
+    for (int64_t i = 0; i < n; i++) dst[i] &= src[i];
+}
+
+/* ======================================================================
  * Synthetic data (shared definition with lb_gpu_fill_uniform)
  * ====================================================================== */
 static inline uint64_t splitmix64_at(uint64_t seed, uint64_t idx)

@@ -123,6 +123,13 @@ int lbo_ring_get_shard(const uint32_t *hashes, const int *owners, int npoints, u
 int lbo_merge_sorted_streams(const int64_t *ids, const float *scores, const int *lens,
                              int nlists, int k, int64_t *out_ids, float *out_scores);
 
+/* ---- predicate masks -------------------------------------------------------- */
+/* simd.MatchInt64 / MatchFloat32 (internal/simd/simd.go:570-761): dst[i] = src[i] OP val ? 1 : 0;
+ * op = simd.CompareOp (Eq=0, Neq, Gt, Ge, Lt, Le; simd.go:38-45).  simd.AndBytes (simd.go:119-125). */
+void lbo_match_int64(const int64_t *src, int64_t n, int64_t val, int op, uint8_t *dst);
+void lbo_match_float32(const float *src, int64_t n, float val, int op, uint8_t *dst);
+void lbo_and_bytes(uint8_t *dst, const uint8_t *src, int64_t n);
+
 /* ---- synthetic data ------------------------------------------------------ */
 /* Counter-based uniform [0,1) f32 generator shared bit-for-bit with the HIP
  * library (lb_gpu_fill_uniform): value(idx) = (splitmix64(seed ^ mix(idx)) >> 40) * 2^-24.

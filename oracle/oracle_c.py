@@ -78,6 +78,12 @@ def lib():
         L.lbo_ring_get_shard.argtypes = [_u32p, _i32p, C.c_int, C.c_uint64]
         L.lbo_merge_sorted_streams.restype = C.c_int
         L.lbo_merge_sorted_streams.argtypes = [_i64p, _f32p, _i32p, C.c_int, C.c_int, _i64p, _f32p]
+        L.lbo_match_int64.restype = None
+        L.lbo_match_int64.argtypes = [_i64p, C.c_int64, C.c_int64, C.c_int, _u8p]
+        L.lbo_match_float32.restype = None
+        L.lbo_match_float32.argtypes = [_f32p, C.c_int64, C.c_float, C.c_int, _u8p]
+        L.lbo_and_bytes.restype = None
+        L.lbo_and_bytes.argtypes = [_u8p, _u8p, C.c_int64]
         L.lbo_fill_uniform.restype = None
         L.lbo_fill_uniform.argtypes = [_f32p, C.c_int64, C.c_uint64, C.c_int64]
         L.lbo_fill_codes.restype = None
@@ -228,6 +234,27 @@ def merge_sorted_streams(lists, k):
     cnt = lib().lbo_merge_sorted_streams(np.ascontiguousarray(ids), np.ascontiguousarray(sc), lens,
                                          len(lists), k, oi, os_)
     return oi[:cnt].copy(), os_[:cnt].copy()
+
+
+def match_int64(src, val, op):
+    src = np.ascontiguousarray(src, np.int64)
+    dst = np.empty(src.size, np.uint8)
+    lib().lbo_match_int64(src, src.size, int(val), int(op), dst)
+    return dst
+
+
+def match_float32(src, val, op):
+    src = _f32(src)
+    dst = np.empty(src.size, np.uint8)
+    lib().lbo_match_float32(src, src.size, float(val), int(op), dst)
+    return dst
+
+
+def and_bytes(dst, src):
+    dst = np.ascontiguousarray(dst, np.uint8).copy()
+    src = np.ascontiguousarray(src, np.uint8)
+    lib().lbo_and_bytes(dst, src, dst.size)
+    return dst
 
 
 def fill_uniform(n, seed, offset=0):

@@ -281,3 +281,15 @@ def test_cpu_baseline_agrees_with_oracle(oracle):
         secs, bi, bd = oracle.cpu_baseline(metric, Q, X, 10, nthreads=2, simd=1)
         assert np.allclose(bd, od, rtol=1e-5, atol=1e-6)
         assert (bi == oi).mean() > 0.95
+
+
+def test_match_and_and_bytes(oracle):
+    a = np.array([1, 5, 5, -3, 9], np.int64)
+    exp = {0: [0, 1, 1, 0, 0], 1: [1, 0, 0, 1, 1], 2: [0, 0, 0, 0, 1], 3: [0, 1, 1, 0, 1], 4: [1, 0, 0, 1, 0], 5: [1, 1, 1, 1, 0]}
+    for op, e in exp.items():
+        assert list(oracle.match_int64(a, 5, op)) == e
+    f = np.array([0.5, np.nan, 2.0], F)
+    assert list(oracle.match_float32(f, 0.5, 0)) == [1, 0, 0]
+    assert list(oracle.match_float32(f, 0.5, 1)) == [0, 1, 1]   # NaN != x is true (Go / IEEE)
+    assert list(oracle.match_float32(f, 0.5, 3)) == [1, 0, 1]
+    assert list(oracle.and_bytes(np.array([1, 1, 0], np.uint8), np.array([1, 0, 1], np.uint8))) == [1, 0, 0]
