@@ -24,7 +24,7 @@
 
 using namespace lb;
 
-namespace lb { extern int g_gemm_ablation; extern int g_gemm_glds; void read_clock_probe(unsigned long long out[8], bool reset); int debug_gemm_occupancy(); }
+namespace lb { extern int g_adc_ablation; extern int g_gemm_ablation; extern int g_gemm_glds; void read_clock_probe(unsigned long long out[8], bool reset); int debug_gemm_occupancy(); }
 
 namespace {
 
@@ -814,6 +814,7 @@ int lb_gpu_index_last_timing(const lb_gpu_index *hc, float ms[5], int n_launch[5
 // profiling aid, not part of the public header: selects a timing-only ablation of the GEMM kernel
 void lb_debug_set_gemm_ablation(int v) { lb::g_gemm_ablation = v; }
 void lb_debug_set_gemm_glds(int v) { lb::g_gemm_glds = v; }
+void lb_debug_set_adc_ablation(int v) { lb::g_adc_ablation = v; }
 int lb_debug_gemm_occupancy(void) { return lb::debug_gemm_occupancy(); }
 void lb_debug_read_clock_probe(unsigned long long *out, int reset) { lb::read_clock_probe(out, reset != 0); }
 

@@ -65,7 +65,8 @@ struct AdcArgs {
     int boot;
 };
 
-template <bool VEC16>
+// ABL (profiling aid, wrong results): 1 = no LDS gathers, 2 = no global code loads
+template <bool VEC16, int ABL = 0>
 __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(AdcArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float tab[];
@@ -80,14 +81,17 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(AdcArgs a)
         if (VEC16) {
             const uint4 *c4 = reinterpret_cast<const uint4 *>(c);
             for (int g = 0; g < M / 16; g++) {
-                const uint4 v = c4[g];
+                uint4 v;
+                if (ABL == 2) v = make_uint4((uint32_t)row * 2654435761u, (uint32_t)row * 40503u + g, (uint32_t)(row >> 3) * 97u, (uint32_t)row ^ (g * 0x9e3779b9u));
+                else v = c4[g];
                 const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
 #pragma unroll
                     for (int b = 0; b < 4; b++) {
                         const int j = g * 16 + t * 4 + b;
-                        sum = sum + tab[j * 256 + ((w[t] >> (8 * b)) & 0xffu)];
+                        if (ABL == 1) sum = sum + (float)((w[t] >> (8 * b)) & 0xffu);
+                        else sum = sum + tab[j * 256 + ((w[t] >> (8 * b)) & 0xffu)];
                     }
                 }
             }
@@ -110,6 +114,116 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(AdcArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------
+// Coalesced variant (M % 16 == 0): per-lane 16-B loads at an M-byte stride touch ~48 cache lines per
+// wave instruction and cap the code stream at ~3.9 TB/s.  Here each wave pulls its 64 rows
+// (64*M contiguous bytes) with M/16 direct-to-LDS DMA instructions of 1 KiB each
+// (global_load_lds_dwordx4: full lines, no VGPR round trip) into a private staging slot, then every
+// lane reads back its own row (M/16 x ds_read_b128) and does the M table gathers.  The DMA of the
+// next 64 rows is issued as soon as the slot has been read, so it runs under the gather phase.
+// LDS: table M*256*4 B + 10 waves * 64*M B  (98,304 + 61,440 B at M = 96); one workgroup per CU.
+constexpr int ADC_DMA_WAVES = 8;
+constexpr int ADC_DMA_SLOTS = 1; // staged 64-row tiles per wave (measured: 8x1 2.21 ms, 10x1 2.33, 4x2 3.03 at C4)
+
+template <int MCH> // MCH = M / 16
+__global__ __launch_bounds__(ADC_DMA_WAVES * 64) void adc_scan_dma_kernel(AdcArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    constexpr int M = MCH * 16;
+    float *tab = smem_f;
+    unsigned char *stage_all = reinterpret_cast<unsigned char *>(smem_f + M * 256);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < M * 256; i += ADC_DMA_WAVES * 64) tab[i] = a.table[i];
+    __syncthreads();
+    unsigned char *stage = stage_all + wave * (ADC_DMA_SLOTS * 64 * M);
+    const uint64_t tau = a.all_out ? 0ull : a.cs.tau[a.slot];
+    const int64_t nrows = a.row_end - a.row_begin;
+    const int64_t ntiles = (nrows + 63) / 64;
+    const int64_t tstride = (int64_t)gridDim.x * ADC_DMA_WAVES;
+    const unsigned char *last16 = a.codes + a.row_end * (int64_t)M - 16;
+
+    auto issue = [&](int64_t tile, int slot) {
+        const unsigned char *src0 = a.codes + (a.row_begin + tile * 64) * (int64_t)M + lane * 16;
+#pragma unroll
+        for (int i = 0; i < MCH; i++) {
+            const unsigned char *src = src0 + i * 1024;
+            if (src > last16) src = last16; // tail tile: stay inside the buffer (rows past the end are discarded)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(stage + slot * (64 * M) + i * 1024),
+                                             16, 0, 0);
+        }
+    };
+
+    int64_t tile = (int64_t)blockIdx.x * ADC_DMA_WAVES + wave;
+    if (tile < ntiles) issue(tile, 0);
+    if (ADC_DMA_SLOTS == 2 && tile + tstride < ntiles) issue(tile + tstride, 1);
+    int slot = 0;
+    for (; tile < ntiles; tile += tstride, slot = (ADC_DMA_SLOTS == 2) ? (slot ^ 1) : 0) {
+        // two slots: the older of the (up to) two tiles in flight has landed once at most MCH DMAs remain
+        if (ADC_DMA_SLOTS == 2 && tile + tstride < ntiles) {
+            if (MCH == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else if (MCH == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (MCH == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else if (MCH == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (MCH == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const unsigned char *sl = stage + slot * (64 * M);
+        uint4 c[MCH];
+#pragma unroll
+        for (int i = 0; i < MCH; i++) c[i] = *reinterpret_cast<const uint4 *>(sl + lane * M + i * 16);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // slot fully read before it is refilled
+        if (tile + ADC_DMA_SLOTS * tstride < ntiles) issue(tile + ADC_DMA_SLOTS * tstride, slot);
+
+        const int64_t row = a.row_begin + tile * 64 + lane;
+        float sum = 0.f;
+#pragma unroll
+        for (int g = 0; g < MCH; g++) {
+            const uint32_t w[4] = {c[g].x, c[g].y, c[g].z, c[g].w};
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int b = 0; b < 4; b++)
+                    sum = sum + tab[(g * 16 + t * 4 + b) * 256 + ((w[t] >> (8 * b)) & 0xffu)];
+        }
+        if (row < a.row_end) {
+            const float dist = (float)sqrt((double)sum);
+            if (a.all_out) {
+                a.all_out[row - a.out_base] = dist;
+            } else {
+                const bool masked = a.mask && !a.mask[row];
+                const uint64_t ent = pack_entry(dist, (uint32_t)row);
+                if (a.boot) {
+                    a.cs.lists[(size_t)a.slot * a.cs.cap + (row - a.row_begin)] = masked ? kEntryMax : ent;
+                } else if (!masked && ent < tau) {
+                    uint32_t pos = atomicAdd(&a.cs.cnt[a.slot], 1u);
+                    if (pos < a.cs.cap) a.cs.lists[(size_t)a.slot * a.cs.cap + pos] = ent;
+                }
+            }
+        }
+    }
+}
+
+template <int MCH>
+static bool try_launch_adc_dma(const AdcArgs &a, hipStream_t s)
+{
+    constexpr int M = MCH * 16;
+    const size_t shmem = (size_t)M * 256 * 4 + (size_t)ADC_DMA_WAVES * ADC_DMA_SLOTS * 64 * M;
+    if (shmem > 160 * 1024) return false;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(adc_scan_dma_kernel<MCH>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    const int64_t ntiles = (a.row_end - a.row_begin + 63) / 64;
+    int64_t blocks = (ntiles + ADC_DMA_WAVES - 1) / ADC_DMA_WAVES;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL((adc_scan_dma_kernel<MCH>), dim3((unsigned)blocks), dim3(ADC_DMA_WAVES * 64), shmem, s, a);
+    return true;
+}
+
+int g_adc_ablation = 0; // profiling aid (tools/bench_pq.py)
+
 void launch_adc_scan(const float *table, int M, const uint8_t *codes, int64_t row_begin, int64_t row_end,
                      int slot, const uint8_t *mask, CandState cs, bool boot, float *all_out,
                      int64_t out_base, hipStream_t s)
@@ -124,6 +238,26 @@ void launch_adc_scan(const float *table, int M, const uint8_t *codes, int64_t ro
     int64_t blocks = (nrows + ADC_THREADS - 1) / ADC_THREADS;
     if (blocks > 256) blocks = 256; // one 1024-thread workgroup per CU holds the table once
     const bool vec = (M % 16 == 0) && ((reinterpret_cast<uintptr_t>(codes) & 15) == 0);
+    if (vec && !g_adc_ablation && (a.row_end - a.row_begin) >= 4096) {
+        bool ok = false;
+        switch (M / 16) {
+        case 1: ok = try_launch_adc_dma<1>(a, s); break;
+        case 2: ok = try_launch_adc_dma<2>(a, s); break;
+        case 3: ok = try_launch_adc_dma<3>(a, s); break;
+        case 4: ok = try_launch_adc_dma<4>(a, s); break;
+        case 6: ok = try_launch_adc_dma<6>(a, s); break;
+        case 8: ok = try_launch_adc_dma<8>(a, s); break;
+        default: break;
+        }
+        if (ok) return;
+    }
+    if (vec && g_adc_ablation) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(adc_scan_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(adc_scan_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (g_adc_ablation == 1) hipLaunchKernelGGL((adc_scan_kernel<true, 1>), dim3((unsigned)blocks), dim3(ADC_THREADS), shmem, s, a);
+        else hipLaunchKernelGGL((adc_scan_kernel<true, 2>), dim3((unsigned)blocks), dim3(ADC_THREADS), shmem, s, a);
+        return;
+    }
     if (vec) {
         if (shmem > 64 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(adc_scan_kernel<true>),
