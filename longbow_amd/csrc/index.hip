@@ -232,7 +232,7 @@ void run_scan_path(lb_gpu_index *h, Workspace *w, hipStream_t s, const float *d_
         int64_t pos = 0;
         int step = 0;
         while (pos < n) {
-            const int64_t end = chunk_end_host(step, pos, n, kkeep, w->cap, safe);
+            const int64_t end = chunk_end_host(step, pos, n, kkeep, w->cap, safe, /*big_boot=*/true);
             const bool boot = step == 0;
             {
                 ProfScope p(w, s, prof, 3);

@@ -307,23 +307,32 @@ __global__ __launch_bounds__(256) void scan_generic_kernel(ScanArgs a)
     }
 }
 
-// ||q||^2 per selected slot in the requested order (cosine only).  One lane per slot.
+// ||q||^2 per selected slot in the requested order (cosine only).  One 64-lane block per slot:
+// the query is staged in LDS with coalesced loads, then lane 0 runs the reference's f32 chain
+// (batched ds_read_b128, no dependent global loads).
 template <int ORDER>
-__global__ void query_norms_kernel(const float *Q, const int *qsel, int nsel, int D, float *qna)
+__global__ __launch_bounds__(64) void query_norms_kernel(const float *Q, const int *qsel, int nsel, int D, float *qna)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) float sq[];
+    const int j = blockIdx.x;
     if (j >= nsel) return;
     const float *q = Q + (int64_t)(qsel ? qsel[j] : j) * D;
+    const int Dpad = (D + 3) & ~3;
+    for (int i = threadIdx.x; i < Dpad; i += 64) sq[i] = i < D ? q[i] : 0.f;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     Acc<ORDER> a;
     a.zero();
     const int dmain = D & ~3;
+#pragma unroll 8
     for (int i = 0; i < dmain; i += 4) {
-        a.template add<0>(q[i] * q[i]);
-        a.template add<1>(q[i + 1] * q[i + 1]);
-        a.template add<2>(q[i + 2] * q[i + 2]);
-        a.template add<3>(q[i + 3] * q[i + 3]);
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(&sq[i]);
+        a.template add<0>(v.x * v.x);
+        a.template add<1>(v.y * v.y);
+        a.template add<2>(v.z * v.z);
+        a.template add<3>(v.w * v.w);
     }
-    for (int i = dmain; i < D; i++) a.add_tail(q[i] * q[i]);
+    for (int i = dmain; i < D; i++) a.add_tail(sq[i] * sq[i]);
     qna[j] = a.total();
 }
 
@@ -331,11 +340,12 @@ void launch_query_norms(int order, const float *Q, const int *qsel, int nsel, in
                         hipStream_t s)
 {
     if (nsel <= 0) return;
-    dim3 grid((nsel + 63) / 64), block(64);
+    dim3 grid(nsel), block(64);
+    const size_t shmem = (size_t)((D + 3) & ~3) * sizeof(float);
     if (order == ORDER_UNROLL4)
-        hipLaunchKernelGGL(query_norms_kernel<ORDER_UNROLL4>, grid, block, 0, s, Q, qsel, nsel, D, qna);
+        hipLaunchKernelGGL(query_norms_kernel<ORDER_UNROLL4>, grid, block, shmem, s, Q, qsel, nsel, D, qna);
     else
-        hipLaunchKernelGGL(query_norms_kernel<ORDER_SEQ>, grid, block, 0, s, Q, qsel, nsel, D, qna);
+        hipLaunchKernelGGL(query_norms_kernel<ORDER_SEQ>, grid, block, shmem, s, Q, qsel, nsel, D, qna);
 }
 
 template <int METRIC, int ORDER>

@@ -142,9 +142,35 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(CandState cs, const
     }
 
     // ---- radix select of the kc-th smallest (1-based rank `need`) ----
+    // Leading bytes shared by every real entry (distances live in a narrow range) need no pass.
+    unsigned long long *red = reinterpret_cast<unsigned long long *>(hist); // [0] = OR, [1] = AND of real entries
+    if (tid == 0) { red[0] = 0ull; red[1] = ~0ull; }
+    __syncthreads();
+    {
+        uint64_t o = 0, an = ~0ull;
+        for (uint32_t i = tid; i < P; i += SEL_THREADS) {
+            const uint64_t e = sh[i];
+            if (e != kEntryMax) { o |= e; an &= e; }
+        }
+        atomicOr(&red[0], (unsigned long long)o);
+        atomicAnd(&red[1], (unsigned long long)an);
+    }
+    __syncthreads();
+    const uint64_t diff = red[0] ^ red[1]; // bit positions that differ among real entries
+    const uint64_t common = red[1];
+    __syncthreads();
+    int first_shift = 56;
     uint64_t prefix = 0, mask = 0;
+    if (diff != 0ull) {
+        const int same_bytes = __builtin_clzll(diff) >> 3; // whole leading bytes identical
+        first_shift = 56 - 8 * same_bytes;
+        if (same_bytes > 0) {
+            mask = ~0ull << (64 - 8 * same_bytes);
+            prefix = common & mask;
+        }
+    }
     uint32_t need = (uint32_t)kc;
-    for (int shift = 56; shift >= 0; shift -= 8) {
+    for (int shift = first_shift; shift >= 0; shift -= 8) {
         hist[tid] = 0; // SEL_THREADS == 256 bins
         __syncthreads();
         for (uint32_t i = tid; i < P; i += SEL_THREADS) {

@@ -39,12 +39,14 @@ inline uint32_t next_pow2_host(uint32_t v)
 // (all rows stored, no atomics); every later chunk is sized so that, with the threshold left by
 // the previous select (pass rate ~ keep/pos on exchangeable data), about (cap-keep)/4 entries
 // are admitted.  safe = chunks that cannot overflow whatever the data order.
-inline int64_t chunk_end_host(int step, int64_t pos, int64_t n, int64_t keep, int64_t cap, bool safe)
+// big_boot: use the whole list as bootstrap chunk (scan pipelines: one select level fewer).
+inline int64_t chunk_end_host(int step, int64_t pos, int64_t n, int64_t keep, int64_t cap, bool safe,
+                              bool big_boot = false)
 {
     int64_t end;
     if (step == 0) {
         int64_t boot = 4 * keep > 2048 ? 4 * keep : 2048;
-        if (boot > cap) boot = cap;
+        if (boot > cap || big_boot) boot = cap;
         end = boot;
     } else if (safe) {
         end = pos + (cap - keep);

@@ -253,7 +253,7 @@ int lb_gpu_pq_search_device(lb_gpu_pq *p, int64_t nq, const float *d_queries, in
             int64_t pos = 0;
             int step = 0;
             while (pos < p->n) {
-                const int64_t end = chunk_end_host(step, pos, p->n, k, cap, safe);
+                const int64_t end = chunk_end_host(step, pos, p->n, k, cap, safe, /*big_boot=*/true);
                 const bool boot = step == 0;
                 launch_adc_scan(tab, p->M, p->d_codes, pos, end, q, nullptr, sc.cs, boot, nullptr, 0, s);
                 launch_select(sc.cs, sc.d_slots + q, 1, k, boot ? (uint32_t)(end - pos) : 0u, s);
