@@ -85,7 +85,12 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # LB_BENCH_FORCE_DIST=1 exercises the RCCL path (process group, all-gather, merge) even with one
+    # rank, so the multi-GPU code can be rehearsed on a single-GPU box.
+    use_dist = world > 1 or os.environ.get("LB_BENCH_FORCE_DIST") == "1"
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     lib = _lib.require_gpu(local_rank)
@@ -99,11 +104,11 @@ def main():
     idx = gpu.NewIndexWithConfig(gpu.GPUConfig(DeviceID=local_rank, Dimension=DIM, Metric=METRIC_COSINE))
     idx.reserve(rows)
     d_ids = None
-    if world > 1:
+    if use_dist:
         ids = torch.from_numpy(shard_ids(rank, world, rows)).to(dev)
         d_ids = ids.data_ptr()
     idx.add_device(rows, X.data_ptr(), d_ids)
-    searcher = ShardedSearcher(idx, rank, world, device=dev) if world > 1 else None
+    searcher = ShardedSearcher(idx, rank, world, device=dev, force_collective=use_dist) if use_dist else None
     out_d = torch.empty((B, K), device=dev)
     out_l = torch.empty((B, K), dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -115,7 +120,7 @@ def main():
         return out_l, out_d
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -134,7 +139,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     idx.set_profiling(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -152,7 +157,7 @@ def main():
         "config": {"workload": "1Mx768 float32 cosine, batch=1024 queries, k=100, brute-force",
                    "shard_rows": rows, "dim": DIM, "batch": B, "k": K, "metric": "cosine",
                    "global_rows": rows * world,
-                   "sharding": "RingSharder(n_gpus, 40) + RCCL all-gather merge" if world > 1 else "single shard",
+                   "sharding": "RingSharder(n_gpus, 40) + RCCL all-gather merge" if use_dist else "single shard",
                    "unit_of_value": "one query searched over one 1Mx768 shard"},
         "fallback_queries": int(fallbacks),
     }
@@ -230,7 +235,7 @@ def main():
     if rank == 0:
         print(json.dumps(result), flush=True)
     idx.Close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

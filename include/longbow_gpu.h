@@ -179,6 +179,12 @@ int lb_gpu_merge_topk_device(int device, int nshards, int64_t nq, int k, const f
                              const int64_t *d_labels_in, float *d_dist_out, int64_t *d_labels_out,
                              void *stream);
 
+/* Same merge over ONE gathered buffer (a single RCCL all-gather per batch): shard s's block starts at
+ * d_packed + s*block_bytes and holds nq*k int64 labels followed by nq*k f32 distances, the block
+ * size rounded up to 8 bytes: block_bytes = nq*k*8 + ceil(nq*k*4 / 8)*8. */
+int lb_gpu_merge_topk_packed_device(int device, int nshards, int64_t nq, int k, const void *d_packed,
+                                    float *d_dist_out, int64_t *d_labels_out, void *stream);
+
 /* ---- synthetic data (bench / tests) ------------------------------------------------
  * Counter-based uniform [0,1) f32 / uniform u8, bit-identical to the oracle's
  * lbo_fill_uniform / lbo_fill_codes. */

@@ -876,7 +876,26 @@ int lb_gpu_merge_topk_device(int device, int nshards, int64_t nq, int k, const f
     if (!d_dist_in || !d_labels_in || !d_dist_out || !d_labels_out) return LB_ERR_INVALID_ARG;
     if (!device_ok(device)) return LB_ERR_NO_DEVICE;
     if (hipSetDevice(device) != hipSuccess) return LB_ERR_HIP;
-    launch_merge_topk(nshards, nq, k, d_dist_in, d_labels_in, d_dist_out, d_labels_out, (hipStream_t)stream);
+    launch_merge_topk(nshards, nq, k, d_dist_in, d_labels_in, nq * k, nq * k, d_dist_out, d_labels_out,
+                      (hipStream_t)stream);
+    return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? LB_OK : LB_ERR_HIP;
+}
+
+int lb_gpu_merge_topk_packed_device(int device, int nshards, int64_t nq, int k, const void *d_packed,
+                                    float *d_dist_out, int64_t *d_labels_out, void *stream)
+{
+    if (nshards <= 0 || nq < 0 || k <= 0 || (int64_t)nshards * k > 8192) return LB_ERR_INVALID_ARG;
+    if (nq == 0) return LB_OK;
+    if (!d_packed || !d_dist_out || !d_labels_out) return LB_ERR_INVALID_ARG;
+    if (!device_ok(device)) return LB_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return LB_ERR_HIP;
+    // per shard: nq*k int64 labels followed by nq*k f32 distances (padded to 8 bytes)
+    const int64_t nk = nq * k;
+    const int64_t block_bytes = nk * 8 + ((nk * 4 + 7) / 8) * 8;
+    const char *base = reinterpret_cast<const char *>(d_packed);
+    launch_merge_topk(nshards, nq, k, reinterpret_cast<const float *>(base + nk * 8),
+                      reinterpret_cast<const int64_t *>(base), block_bytes / 4, block_bytes / 8, d_dist_out,
+                      d_labels_out, (hipStream_t)stream);
     return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? LB_OK : LB_ERR_HIP;
 }
 

@@ -482,6 +482,7 @@ void launch_emit_lists(CandState cs, const int *qsel, int nsel, int k, const int
 __global__ __launch_bounds__(SEL_THREADS) void merge_topk_kernel(int nshards, int64_t nq, int k,
                                                                  const float *dist_in,
                                                                  const int64_t *lab_in,
+                                                                 int64_t dist_stride, int64_t lab_stride,
                                                                  float *dist_out, int64_t *lab_out)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -494,9 +495,9 @@ __global__ __launch_bounds__(SEL_THREADS) void merge_topk_kernel(int nshards, in
     for (uint32_t i = tid; i < P; i += SEL_THREADS) {
         if (i < n) {
             const int s = i / k, r = i % k;
-            const int64_t src = ((int64_t)s * nq + q) * k + r;
-            skey[i] = f32_sortable(dist_in[src] + 0.0f);
-            slab[i] = (uint64_t)lab_in[src];
+            const int64_t off = q * k + r; // within one shard's [nq][k] block
+            skey[i] = f32_sortable(dist_in[(int64_t)s * dist_stride + off] + 0.0f);
+            slab[i] = (uint64_t)lab_in[(int64_t)s * lab_stride + off];
         } else {
             skey[i] = 0xffffffffu;
             slab[i] = ~0ull;
@@ -527,14 +528,14 @@ __global__ __launch_bounds__(SEL_THREADS) void merge_topk_kernel(int nshards, in
 }
 
 void launch_merge_topk(int nshards, int64_t nq, int k, const float *dist_in, const int64_t *lab_in,
-                       float *dist_out, int64_t *lab_out, hipStream_t s)
+                       int64_t dist_stride, int64_t lab_stride, float *dist_out, int64_t *lab_out, hipStream_t s)
 {
     if (nq <= 0 || k <= 0) return;
     const size_t P = next_pow2_host((uint32_t)(nshards * k));
     const size_t shmem = P * 12;
     allow_big_lds(merge_topk_kernel, shmem);
     hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)nq), dim3(SEL_THREADS), shmem, s, nshards, nq,
-                       k, dist_in, lab_in, dist_out, lab_out);
+                       k, dist_in, lab_in, dist_stride, lab_stride, dist_out, lab_out);
 }
 
 } // namespace lb

@@ -116,8 +116,9 @@ void launch_emit_lists(CandState cs, const int *qsel, int nsel, int k, const int
 
 void launch_init_cand(CandState cs, const int *qsel, int nsel, hipStream_t s);
 
+// shard s's [nq][k] blocks start at dist_in + s*dist_stride and lab_in + s*lab_stride (elements)
 void launch_merge_topk(int nshards, int64_t nq, int k, const float *dist_in, const int64_t *lab_in,
-                       float *dist_out, int64_t *lab_out, hipStream_t s);
+                       int64_t dist_stride, int64_t lab_stride, float *dist_out, int64_t *lab_out, hipStream_t s);
 
 void launch_fill_uniform(float *dst, int64_t n, uint64_t seed, int64_t offset, hipStream_t s);
 void launch_fill_codes(uint8_t *dst, int64_t n, uint64_t seed, int64_t offset, hipStream_t s);

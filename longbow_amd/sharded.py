@@ -85,7 +85,8 @@ def _hip_merge(device):
 class ShardedSearcher:
     """One rank's view of a corpus sharded over `world_size` GPUs."""
 
-    def __init__(self, index, rank, world_size, group=None, device=None, local_search=None, merge=None):
+    def __init__(self, index, rank, world_size, group=None, device=None, local_search=None, merge=None,
+                 force_collective=False):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -95,6 +96,7 @@ class ShardedSearcher:
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self._local_search = local_search
         self._merge = merge
+        self._force = force_collective  # run the all-gather even with one rank (rehearsal)
         self._bufs = {}
 
     def _buffers(self, nq, k):
@@ -115,6 +117,9 @@ class ShardedSearcher:
         t = self.torch
         nq = queries.shape[0]
         b = self._buffers(nq, k)
+        if self._local_search is None and self._merge is None:
+            return self._search_hip(queries, k, nq, b)
+        # injectable path (CPU/gloo tests, or mixed): separate tensors
         if self._local_search is not None:
             lab, d = self._local_search(queries, k)
             b["l"].copy_(t.as_tensor(lab))
@@ -123,19 +128,15 @@ class ShardedSearcher:
         else:
             stream = t.cuda.current_stream(self.device).cuda_stream
             self.index.search_device(nq, queries.data_ptr(), k, b["d"].data_ptr(), b["l"].data_ptr(), stream)
-        if self.world > 1:
-            # the one exchange step: per-shard top-k, ids travel with distances
-            if self.dist.get_backend(self.group) == "nccl":  # RCCL: one fused all-gather per tensor
-                self.dist.all_gather_into_tensor(b["da"], b["d"], group=self.group)
-                self.dist.all_gather_into_tensor(b["la"], b["l"], group=self.group)
-            elif b["d"].is_cuda:  # gloo transport with device tensors (tests on one GPU): stage via host
+        if self.world > 1 or self._force:
+            if b["d"].is_cuda:  # gloo transport with device tensors: stage via host
                 hd = [t.empty(b["d"].shape, dtype=t.float32) for _ in range(self.world)]
                 hl = [t.empty(b["l"].shape, dtype=t.int64) for _ in range(self.world)]
                 self.dist.all_gather(hd, b["d"].cpu(), group=self.group)
                 self.dist.all_gather(hl, b["l"].cpu(), group=self.group)
                 b["da"].copy_(t.stack(hd))
                 b["la"].copy_(t.stack(hl))
-            else:  # gloo (CPU tests)
+            else:
                 self.dist.all_gather([b["da"][r] for r in range(self.world)], b["d"], group=self.group)
                 self.dist.all_gather([b["la"][r] for r in range(self.world)], b["l"], group=self.group)
         else:
@@ -143,6 +144,32 @@ class ShardedSearcher:
             b["la"][0].copy_(b["l"])
         merge = self._merge if self._merge is not None else _hip_merge(self.device.index or 0)
         merge(self.world, nq, k, b["da"], b["la"], b["do"], b["lo"], stream)
+        return b["lo"], b["do"]
+
+    def _search_hip(self, queries, k, nq, b):
+        """product path: HIP search -> ONE all-gather of the packed (labels | distances) block -> HIP merge"""
+        t = self.torch
+        lib = _lib.require_gpu(self.device.index or 0)
+        nk = nq * k
+        block_words = nk + (nk * 4 + 7) // 8  # int64 words per shard block
+        key = ("packed", nq, k)
+        if key not in self._bufs:
+            self._bufs[key] = (t.empty(block_words, dtype=t.int64, device=self.device),
+                               t.empty(self.world * block_words, dtype=t.int64, device=self.device))
+        mine, allb = self._bufs[key]
+        stream = t.cuda.current_stream(self.device).cuda_stream
+        self.index.search_device(nq, queries.data_ptr(), k, mine.data_ptr() + nk * 8, mine.data_ptr(), stream)
+        backend = self.dist.get_backend(self.group) if (self.world > 1 or self._force) else None
+        if backend == "nccl":      # RCCL over xGMI: the one exchange step of the path
+            self.dist.all_gather_into_tensor(allb, mine, group=self.group)
+        elif backend is not None:  # gloo with device tensors (single-GPU rehearsal): stage via host
+            parts = [t.empty(block_words, dtype=t.int64) for _ in range(self.world)]
+            self.dist.all_gather(parts, mine.cpu(), group=self.group)
+            allb.copy_(t.cat(parts))
+        else:
+            allb.copy_(mine)
+        _lib.check(lib.lb_gpu_merge_topk_packed_device(self.device.index or 0, self.world, nq, k, allb.data_ptr(),
+                                                       b["do"].data_ptr(), b["lo"].data_ptr(), stream))
         return b["lo"], b["do"]
 
 
