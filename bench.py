@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--rows", type=int, default=N_ROWS)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fast", action="store_true", help="skip the split-bf16 candidate-mode leg")
     ap.add_argument("--cpu-queries", type=int, default=0, help="CPU baseline sample size (0 = 4 per core)")
     args = ap.parse_args()
 
@@ -149,6 +150,7 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * B * args.steps / elapsed
 
+    flops_per_step = 2.0 * B * rows * DIM
     result = {
         "metric": "k-NN queries/sec (batch=1024, k=100), 1Mx768 f32", "value": round(value, 1),
         "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -162,7 +164,6 @@ def main():
         "fallback_queries": int(fallbacks),
     }
 
-    # ---- roofline of the dominant kernel (gemm_filter_kernel: f32 MFMA candidate generation) ------
     flops_per_step = 2.0 * B * rows * DIM
     bytes_per_step = 4.0 * rows * DIM + 4.0 * B * DIM + 12.0 * B * K
     if gemm_ms > 0:
@@ -185,6 +186,44 @@ def main():
             "hbm_algorithmic_bytes_per_step": bytes_per_step,
             "hbm_frac_of_8TBs_at_step_rate": round(bytes_per_step / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
         }
+
+    # ---- secondary leg: split-bf16 candidate contraction (3 x bf16 MFMA), same exact results ----------
+    if not args.no_fast and not use_dist:
+        try:
+            idx.set_candidate_mode(1)
+            for _ in range(2):
+                step()
+            idx.set_profiling(True)
+            f_ms, f_launch, f_fb = 0.0, 0, 0
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+                tm = idx.last_timing()
+                f_ms += tm["gemm"][0]
+                f_launch += tm["gemm"][1]
+                f_fb += idx.last_fallbacks
+            torch.cuda.synchronize(dev)
+            f_el = time.perf_counter() - t1
+            idx.set_profiling(False)
+            labf, ddf = step()
+            same = bool(np.array_equal(labf.cpu().numpy(), lab_h) and np.array_equal(ddf.cpu().numpy(), dist_h))
+            ach = 3.0 * flops_per_step * args.steps / (f_ms * 1e-3) / 1e12 if f_ms > 0 else 0.0
+            result["split_bf16_candidates"] = {
+                "value": round(B * args.steps / f_el, 1), "unit": "queries/s", "ms_per_step": round(1e3 * f_el / args.steps, 4),
+                "results_identical_to_f32_mode": same, "fallback_queries": int(f_fb),
+                "roofline": {"bound": "mfma", "kernel": "gemm_filter_kernel<split>", "achieved": round(ach, 1),
+                             "peak": 2500.0, "unit": "TFLOP/s (bf16, 3 MFMA passes counted)", "frac": round(ach / 2500.0, 4),
+                             "kernel_ms_per_step": round(f_ms / args.steps, 4)},
+                "note": "opt-in lb_gpu_index_set_candidate_mode(1): candidates from hi*hi+hi*lo+lo*hi on bf16 MFMA; "
+                        "reported distances/ids still come from the exact f32 re-rank"}
+        except Exception as e:  # keep the primary line even if the optional leg fails
+            result["split_bf16_candidates"] = {"error": str(e)}
+        finally:
+            try:
+                idx.set_candidate_mode(0)
+            except Exception:
+                pass
 
     if rank == 0 and world == 1:
         # ---- p50 single-query latency (the DoExchange path is single-query) ------------------------

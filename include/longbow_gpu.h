@@ -76,6 +76,16 @@ void lb_gpu_index_free(lb_gpu_index *h);
 const char *lb_gpu_last_error(const lb_gpu_index *h);
 
 int lb_gpu_index_set_order(lb_gpu_index *h, int order);
+
+/* How the batched path generates candidates before the exact f32 re-rank (results are identical
+ * either way: the re-rank recomputes every reported distance in the reference's f32 order and a
+ * rounding-error bound proves the candidate set contains the true top-k, else the query is
+ * re-done by the exact scan):
+ *   LB_CAND_F32_MFMA   (default) q.x on the f32 MFMA (v_mfma_f32_32x32x2_f32)
+ *   LB_CAND_SPLIT_BF16 q.x as hi*hi + hi*lo + lo*hi on the bf16 MFMA over a split image of the corpus
+ *                      (x = hi + lo + O(2^-18)); costs a second N*dim*4-byte copy in HBM; dim % 32 == 0. */
+typedef enum { LB_CAND_F32_MFMA = 0, LB_CAND_SPLIT_BF16 = 1 } lb_candidate_mode;
+int lb_gpu_index_set_candidate_mode(lb_gpu_index *h, int mode);
 int64_t lb_gpu_index_ntotal(const lb_gpu_index *h);
 int lb_gpu_index_dim(const lb_gpu_index *h);
 

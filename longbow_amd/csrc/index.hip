@@ -56,6 +56,8 @@ struct Workspace {
     uint32_t cap = 0;
     CandState cs{};
     float *d_qna = nullptr;
+    float *d_qs = nullptr; // split-bf16 image of the query batch
+    size_t d_qs_bytes = 0;
     int *d_qsel = nullptr;
     uint32_t *h_flags = nullptr; // pinned
     int *h_qsel = nullptr;       // pinned
@@ -76,6 +78,7 @@ struct Workspace {
         if (cs.tau) (void)hipFree(cs.tau);
         if (cs.flags) (void)hipFree(cs.flags);
         if (d_qna) (void)hipFree(d_qna);
+        if (d_qs) (void)hipFree(d_qs);
         if (d_qsel) (void)hipFree(d_qsel);
         if (h_flags) (void)hipHostFree(h_flags);
         if (h_qsel) (void)hipHostFree(h_qsel);
@@ -106,6 +109,10 @@ struct lb_gpu_index {
     bool has_ids = false;
     uint8_t *d_mask = nullptr;
     bool has_mask = false;
+    // optional split-bf16 image of the corpus for the 3x-bf16 candidate contraction (same byte shape as d_X)
+    std::atomic<int> cand_mode{0};
+    float *d_Xs = nullptr;
+    int64_t xs_rows = 0; // rows of d_X already mirrored in d_Xs
 
     hipStream_t add_stream = nullptr;
     void *h_stage[2] = {nullptr, nullptr};
@@ -305,6 +312,26 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     // ---- batched path: MFMA candidate generation + exact re-rank --------------------
     launch_init_cand(w->cs, nullptr, nq, s);
     if (metric == LB_METRIC_COSINE) launch_query_norms(order, d_q, nullptr, nq, h->dim, w->d_qna, s);
+    // candidate contraction: exact f32 MFMA, or 3 x bf16 MFMA on the split images
+    const bool split = h->cand_mode.load() == 1 && h->d_Xs != nullptr && h->xs_rows == n && h->dim % 32 == 0;
+    const float *gx = h->d_X, *gq = d_q;
+    const float u24 = 5.9604645e-8f;
+    float gamma = 1.05f * (float)(h->dim + 8) * u24; // k-ordered f32 fma chain of length D
+    if (split) {
+        const size_t need = (size_t)nq * h->dim * sizeof(float);
+        if (w->d_qs_bytes < need) {
+            if (w->d_qs) (void)hipFree(w->d_qs);
+            w->d_qs = nullptr;
+            w->d_qs_bytes = 0;
+            LB_HIP(hipMalloc(&w->d_qs, need));
+            w->d_qs_bytes = need;
+        }
+        launch_split_bf16(d_q, w->d_qs, nq, h->dim, s);
+        gx = h->d_Xs;
+        gq = w->d_qs;
+        // 3D/16 MFMA accumulations + <=16-term block sums, plus the dropped lo*lo / residual terms
+        gamma = 1.05f * ((float)(3 * h->dim / 16 + 24) * u24 + 3.0f * 3.8146973e-6f);
+    }
     int64_t pos = 0;
     int step = 0;
     while (pos < n) {
@@ -312,8 +339,8 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         const bool boot = step == 0;
         {
             ProfScope p(w, s, prof, 0);
-            launch_gemm_filter(metric, h->d_X, h->d_norm2, h->d_rnorm, pos, end, h->dim, d_q, nq, mask,
-                               w->cs, boot, s);
+            launch_gemm_filter(metric, gx, h->d_norm2, h->d_rnorm, pos, end, h->dim, gq, nq, mask,
+                               w->cs, boot, split, s);
         }
         {
             ProfScope p(w, s, prof, 1);
@@ -324,7 +351,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     }
     {
         ProfScope p(w, s, prof, 2);
-        launch_rerank(metric, order, h->d_X, h->dim, d_q, nq, w->d_qna, w->cs, kc, k, h->d_maxnorm2,
+        launch_rerank(metric, order, h->d_X, h->dim, d_q, nq, w->d_qna, w->cs, kc, k, h->d_maxnorm2, gamma,
                       h->has_ids ? h->d_ids : nullptr, d_dist, d_lab, s);
     }
     std::vector<int> bad;
@@ -392,8 +419,15 @@ int grow(lb_gpu_index *h, int64_t need)
     if (h->d_mask) (void)hipFree(h->d_mask);
     h->d_X = nx; h->d_norm2 = n2; h->d_rnorm = rn; h->d_ids = ni; h->d_mask = nm;
     h->capacity = cap;
+    if (h->d_Xs) { // the mirror is rebuilt at the new capacity by the next sync_split_image
+        (void)hipFree(h->d_Xs);
+        h->d_Xs = nullptr;
+        h->xs_rows = 0;
+    }
     return LB_OK;
 }
+
+void sync_split_image(lb_gpu_index *h);
 
 __global__ void iota_ids_kernel(int64_t *ids, int64_t start, int64_t n)
 {
@@ -421,6 +455,25 @@ void finish_add(lb_gpu_index *h, int64_t n, const int64_t *ids_src, bool ids_on_
     LB_HIP(hipMemsetAsync(h->d_mask + start, 1, (size_t)n, s));
     LB_HIP(hipStreamSynchronize(s));
     h->n += n;
+    sync_split_image(h);
+}
+
+// bring the split-bf16 mirror up to date with d_X (no-op unless the mode is enabled)
+void sync_split_image(lb_gpu_index *h)
+{
+    if (h->cand_mode.load() != 1 || h->dim % 32 != 0 || h->n == 0) return;
+    if (h->d_Xs == nullptr || h->xs_rows > h->n) {
+        if (h->d_Xs) (void)hipFree(h->d_Xs);
+        h->d_Xs = nullptr;
+        h->xs_rows = 0;
+        LB_HIP(hipMalloc(&h->d_Xs, (size_t)h->capacity * h->dim * sizeof(float)));
+    }
+    if (h->xs_rows < h->n) {
+        launch_split_bf16(h->d_X + (size_t)h->xs_rows * h->dim, h->d_Xs + (size_t)h->xs_rows * h->dim,
+                          h->n - h->xs_rows, h->dim, h->add_stream);
+        LB_HIP(hipStreamSynchronize(h->add_stream));
+        h->xs_rows = h->n;
+    }
 }
 
 bool device_ok(int device)
@@ -564,6 +617,7 @@ void lb_gpu_index_free(lb_gpu_index *h)
         if (h->d_ids) (void)hipFree(h->d_ids);
         if (h->d_mask) (void)hipFree(h->d_mask);
         if (h->d_maxnorm2) (void)hipFree(h->d_maxnorm2);
+        if (h->d_Xs) (void)hipFree(h->d_Xs);
         for (int i = 0; i < 2; i++) {
             if (h->h_stage[i]) (void)hipHostFree(h->h_stage[i]);
             if (h->stage_ev[i]) (void)hipEventDestroy(h->stage_ev[i]);
@@ -584,6 +638,27 @@ int lb_gpu_index_set_order(lb_gpu_index *h, int order)
 {
     if (!h || (order != LB_ORDER_SEQ && order != LB_ORDER_UNROLL4)) return LB_ERR_INVALID_ARG;
     h->order.store(order);
+    return LB_OK;
+}
+
+int lb_gpu_index_set_candidate_mode(lb_gpu_index *h, int mode)
+{
+    if (!h || (mode != 0 && mode != 1)) return LB_ERR_INVALID_ARG;
+    std::unique_lock<std::shared_mutex> g(h->mu);
+    if (h->closed) return LB_ERR_CLOSED;
+    if (mode == 1 && h->dim % 32 != 0) {
+        h->set_error("split-bf16 candidates need dim %% 32 == 0 (dim = %d)", h->dim);
+        return LB_ERR_UNSUPPORTED;
+    }
+    try {
+        LB_HIP(hipSetDevice(h->device));
+        h->cand_mode.store(mode);
+        if (mode == 1) sync_split_image(h);
+        else if (h->d_Xs) { (void)hipFree(h->d_Xs); h->d_Xs = nullptr; h->xs_rows = 0; }
+    } catch (const HipErr &e) {
+        h->cand_mode.store(0);
+        return fail_hip(h, e);
+    }
     return LB_OK;
 }
 

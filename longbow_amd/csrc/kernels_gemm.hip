@@ -20,6 +20,7 @@ namespace lb {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int BM = 128; // corpus rows per tile (MFMA A operand, output rows)
 constexpr int BN = 128; // queries per tile   (MFMA B operand, output cols = lanes)
@@ -75,7 +76,12 @@ __device__ __forceinline__ f32x4 load_chunk(const float *base, int64_t row, int 
 // GLDS: stage tiles with direct-to-LDS DMA loads (global_load_lds_dwordx4; needs ALIGNED == 2).
 // The LDS image is lane-linear per wave instruction (base + lane*16), so the chunk swizzle is
 // applied to the per-lane SOURCE address; the image is identical to the register-staged one.
-template <int METRIC, int ALIGNED, int ABL = 0, bool GLDS = false>
+// SPLIT: X and Q are the split-bf16 images produced by split_bf16_kernel: per row and group of 32
+// k, 64 B of bf16 "hi" values followed by 64 B of bf16 "lo" values (x ~ hi + lo, |x-hi-lo| <=
+// 2^-18|x|).  The inner product is then hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (exact
+// bf16 products, f32 accumulation): ~f32-accurate candidate keys at 3/16 of the f32 MFMA cycles.
+// Staging, LDS image and epilogue are shared with the f32 kernel (same bytes per row and K-step).
+template <int METRIC, int ALIGNED, int ABL = 0, bool GLDS = false, bool SPLIT = false>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_filter_kernel(GemmArgs a)
 {
     // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so the
@@ -224,6 +230,36 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_filter_kernel(GemmArgs a
         }
         const float *As = lds[cur][0];
         const float *Bs = lds[cur][1];
+        if (SPLIT) {
+            // chunk c of a row's 128-B piece: c = 0..3 -> hi k-blocks (8 k each), c = 4..7 -> lo k-blocks.
+            // For the 16-k step ks, lane half h supplies k-block 2*ks + h (the MFMA's k = 8h + j).
+            bf16x8 ah[2][2], al[2][2], bh[2][2], bl[2][2]; // [buffer][tile]
+            auto ldfrag = [&](int buf, int ks) {
+                const int kb = 2 * ks + h;
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const int ra_ = wr * 64 + t * 32 + l31, rb_ = wc * 64 + t * 32 + l31;
+                    ah[buf][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(&As[swz_off(ra_, kb)]));
+                    al[buf][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(&As[swz_off(ra_, 4 + kb)]));
+                    bh[buf][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(&Bs[swz_off(rb_, kb)]));
+                    bl[buf][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(&Bs[swz_off(rb_, 4 + kb)]));
+                }
+            };
+            ldfrag(0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                const int cb = ks & 1;
+                if (ks < 1) ldfrag(cb ^ 1, ks + 1);
+#pragma unroll
+                for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+                    for (int tn = 0; tn < 2; tn++) {
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cb][tm], bh[cb][tn], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb][tm], bl[cb][tn], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb][tm], bh[cb][tn], acc[tm][tn], 0, 0, 0);
+                    }
+            }
+        } else {
         f32x4 fa[2][2], fb[2][2];
         if ((ABL != 3 && ABL != 4) || kt == 0) {
 #pragma unroll
@@ -266,6 +302,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_filter_kernel(GemmArgs a
                     *reinterpret_cast<f32x4 *>(&lds[nxt][1][swz_off(st_row[i], st_ch[i])]) = rb[i];
                 }
             }
+        }
         }
         if (ABL != 1 && ABL != 4) __syncthreads();
     }
@@ -398,6 +435,38 @@ void read_clock_probe(unsigned long long out[8], bool reset)
     }
 }
 
+// f32 [rows][D] -> split-bf16 image of the same byte shape (D % 32 == 0): per row and 32-k group,
+// 32 bf16 hi values (x rounded to nearest even) then 32 bf16 lo values (x - hi rounded).
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float *src, float *dst, int64_t n8)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4 *>(src + i * 8);
+        const f32x4 v1 = *reinterpret_cast<const f32x4 *>(src + i * 8 + 4);
+        const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const __bf16 hh = (__bf16)x[j];
+            hi[j] = hh;
+            lo[j] = (__bf16)(x[j] - (float)hh);
+        }
+        const int64_t grp = i >> 2; // 32-k group index over the flattened [rows*D/32]
+        const int kb = (int)(i & 3);
+        char *g = reinterpret_cast<char *>(dst) + grp * 128;
+        *reinterpret_cast<bf16x8 *>(g + kb * 16) = hi;
+        *reinterpret_cast<bf16x8 *>(g + 64 + kb * 16) = lo;
+    }
+}
+
+void launch_split_bf16(const float *src, float *dst, int64_t rows, int D, hipStream_t s)
+{
+    const int64_t n8 = rows * (int64_t)D / 8;
+    if (n8 <= 0) return;
+    int64_t blocks = (n8 + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, n8);
+}
+
 int debug_gemm_occupancy()
 {
     int nb = -1;
@@ -410,7 +479,7 @@ int g_gemm_ablation = 0; // profiling aid (tools/ablate_gemm.py); never set by t
 
 void launch_gemm_filter(int metric, const float *X, const float *norm2, const float *rnorm,
                         int64_t row_begin, int64_t row_end, int D, const float *Q, int nq,
-                        const uint8_t *mask, CandState cs, bool boot, hipStream_t s)
+                        const uint8_t *mask, CandState cs, bool boot, bool split, hipStream_t s)
 {
     if (row_end <= row_begin || nq <= 0) return;
     GemmArgs a;
@@ -440,6 +509,13 @@ void launch_gemm_filter(int metric, const float *X, const float *norm2, const fl
     // direct-to-LDS staging is the default for the aligned, D % 32 == 0 case (LB_GEMM_GLDS=0 or
     // g_gemm_glds = -1 selects the register-staged pipeline for A/B runs)
     static const bool env_noglds = [] { const char *e = getenv("LB_GEMM_GLDS"); return e && e[0] == '0'; }();
+    if (split) {
+        // X / Q are split-bf16 images (caller guarantees D % 32 == 0 and 16-B alignment)
+        if (metric == METRIC_L2) hipLaunchKernelGGL((gemm_filter_kernel<METRIC_L2, 2, 0, true, true>), grid, dim3(GEMM_THREADS), 0, s, a);
+        else if (metric == METRIC_COS) hipLaunchKernelGGL((gemm_filter_kernel<METRIC_COS, 2, 0, true, true>), grid, dim3(GEMM_THREADS), 0, s, a);
+        else hipLaunchKernelGGL((gemm_filter_kernel<METRIC_DOT, 2, 0, true, true>), grid, dim3(GEMM_THREADS), 0, s, a);
+        return;
+    }
     if (g_gemm_glds >= 0 && !env_noglds && g_gemm_ablation == 0 && mode == 2) {
         if (metric == METRIC_L2) hipLaunchKernelGGL((gemm_filter_kernel<METRIC_L2, 2, 0, true>), grid, dim3(GEMM_THREADS), 0, s, a);
         else if (metric == METRIC_COS) hipLaunchKernelGGL((gemm_filter_kernel<METRIC_COS, 2, 0, true>), grid, dim3(GEMM_THREADS), 0, s, a);

@@ -261,6 +261,7 @@ struct RerankArgs {
     CandState cs;
     int kc, k;
     const uint32_t *maxnorm2;
+    float gamma;
     const int64_t *ids;
     float *out_dist;
     int64_t *out_labels;
@@ -369,8 +370,10 @@ __global__ __launch_bounds__(SEL_THREADS) void rerank_kernel(RerankArgs a)
     // bound E on both evaluations, exact_cmp(y) >= w - E.  If at least k candidates satisfy
     // cmp < w - E (strictly), the true top-k lies inside the list.
     if (nc >= (uint32_t)a.kc && nc > (uint32_t)a.k) {
-        const float u = 5.9604645e-8f; // 2^-24
-        const float gam = 1.05f * (float)(D + 8) * u;
+        // ga: error bound of the candidate inner product per unit of |q||x| (host-provided, depends
+        // on the contraction: f32 fma chain or split-bf16); go: the same for the exact f32 re-rank sums
+        const float ga = a.gamma;
+        const float go = 1.05f * (float)(D + 8) * 5.9604645e-8f; // (D+8) * 2^-24
         const float xmax2 = __builtin_bit_cast(float, *a.maxnorm2);
         const float xmax = sqrtf(xmax2) * 1.000001f;
         const float w = s_w;
@@ -380,15 +383,17 @@ __global__ __launch_bounds__(SEL_THREADS) void rerank_kernel(RerankArgs a)
             float nq2 = 0.f;
             for (int i = 0; i < D; i++) nq2 += sq[i] * sq[i];
             const float nqn = sqrtf(nq2) * 1.000001f;
-            T = w * (1.0f - 3.0f * gam) - 2.2f * gam * (xmax2 + 2.0f * nqn * xmax);
+            // d^2 space: key error go*|x|^2 + 2*ga*|q||x| for each of c_last and the outsider;
+            // exact side relative go on each of the two d^2 values
+            T = w * (1.0f - 3.0f * go) - 2.2f * (go * xmax2 + 2.0f * ga * nqn * xmax);
         } else if (METRIC == METRIC_COS) {
-            T = w - 8.5f * gam;
+            T = w - 2.2f * (ga + 2.8f * go);
             skip = (na == 0.0f); // all distances are exactly 1.0; selection by row is exact
         } else {
             float nq2 = 0.f;
             for (int i = 0; i < D; i++) nq2 += sq[i] * sq[i];
             const float nqn = sqrtf(nq2) * 1.000001f;
-            T = w - 4.4f * gam * nqn * xmax;
+            T = w - 2.2f * (ga + go) * nqn * xmax;
         }
         T = T - fabsf(T) * 1e-6f;
         unsigned int local = 0;
@@ -415,13 +420,13 @@ __global__ __launch_bounds__(SEL_THREADS) void rerank_kernel(RerankArgs a)
 }
 
 void launch_rerank(int metric, int order, const float *X, int D, const float *Q, int nq,
-                   const float *qna, CandState cs, int kc, int k, const uint32_t *d_maxnorm2,
+                   const float *qna, CandState cs, int kc, int k, const uint32_t *d_maxnorm2, float gamma,
                    const int64_t *ids, float *out_dist, int64_t *out_labels, hipStream_t s)
 {
     if (nq <= 0) return;
     RerankArgs a;
     a.X = X; a.D = D; a.Q = Q; a.qna = qna; a.cs = cs; a.kc = kc; a.k = k;
-    a.maxnorm2 = d_maxnorm2; a.ids = ids; a.out_dist = out_dist; a.out_labels = out_labels;
+    a.maxnorm2 = d_maxnorm2; a.gamma = gamma; a.ids = ids; a.out_dist = out_dist; a.out_labels = out_labels;
     a.aligned = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
     const int Dpad = (D + 3) & ~3;
     const size_t P = next_pow2_host((uint32_t)kc);

@@ -86,7 +86,9 @@ void launch_row_norms(const float *X, int64_t n, int D, float *norm2, float *rno
 // boot: every row is stored at list[row - row_begin] (no admission test, no atomics).
 void launch_gemm_filter(int metric, const float *X, const float *norm2, const float *rnorm,
                         int64_t row_begin, int64_t row_end, int D, const float *Q, int nq,
-                        const uint8_t *mask, CandState cs, bool boot, hipStream_t s);
+                        const uint8_t *mask, CandState cs, bool boot, bool split, hipStream_t s);
+// f32 [rows][D] -> split-bf16 image (same byte shape; D % 32 == 0) consumed by the split GEMM
+void launch_split_bf16(const float *src, float *dst, int64_t rows, int D, hipStream_t s);
 
 // per query: sort the list, keep the best kc, tau = kc-th entry (or max), flag overflow.
 // qsel (nullable): only these query slots.  boot_rows > 0: the list was filled by a bootstrap
@@ -94,8 +96,9 @@ void launch_gemm_filter(int metric, const float *X, const float *norm2, const fl
 void launch_select(CandState cs, const int *qsel, int nsel, int kc, uint32_t boot_rows, hipStream_t s);
 
 // exact-order distances of the kept candidates, final ordering, containment check, output.
+// gamma: relative rounding-error bound of the candidate inner products (depends on the contraction)
 void launch_rerank(int metric, int order, const float *X, int D, const float *Q, int nq,
-                   const float *qna, CandState cs, int kc, int k, const uint32_t *d_maxnorm2,
+                   const float *qna, CandState cs, int kc, int k, const uint32_t *d_maxnorm2, float gamma,
                    const int64_t *ids, float *out_dist, int64_t *out_labels, hipStream_t s);
 
 // ||q||^2 per selected query slot in the requested accumulation order (cosine).

@@ -106,6 +106,11 @@ class Index:
         self._live()
         _lib.check(self._lib.lb_gpu_index_set_order(self._h, int(Order(order))), self._h)
 
+    def set_candidate_mode(self, mode):
+        """0 = f32 MFMA candidates (default), 1 = split-bf16 (3 x bf16 MFMA) candidates; results identical"""
+        self._live()
+        _lib.check(self._lib.lb_gpu_index_set_candidate_mode(self._h, int(mode)), self._h)
+
     def set_filter(self, mask):
         self._live()
         if mask is None:

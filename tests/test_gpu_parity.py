@@ -251,3 +251,32 @@ def test_fill_uniform_matches_oracle(oracle):
     c = torch.empty(5000, dtype=torch.uint8, device="cuda")
     assert lib.lb_gpu_fill_codes_device(0, c.data_ptr(), c.numel(), 7, 3, None) == 0
     assert np.array_equal(c.cpu().numpy(), oracle.fill_codes(5000, 7, 3))
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_split_bf16_candidates_give_identical_results(oracle, metric):
+    """candidate mode 1 (3 x bf16 MFMA on the split image) must change nothing but speed: the exact
+    re-rank + containment proof (or the scan fallback) make the results equal the oracle bit for bit"""
+    gpu_or_skip()
+    rng = np.random.default_rng(77 + metric)
+    for (n, d, nq, k) in ((30000, 64, 40, 10), (50000, 256, 130, 50), (20000, 96, 33, 100)):
+        X = (rng.random((n, d), dtype=F) - F(0.3)) * F(3.0)
+        Q = (rng.random((nq, d), dtype=F) - F(0.3)) * F(3.0)
+        idx = new_index(d, metric)
+        idx.Add(None, X[: n // 2])
+        idx.set_candidate_mode(1)          # mirror built for existing rows ...
+        idx.Add(None, X[n // 2:])          # ... and kept in sync by later adds
+        lab, dist = idx.SearchBatch(Q, k)
+        oi, od = oracle.search_batch(metric, Q, X, k, nthreads=8)
+        assert_same(lab, dist, oi, od, f"split metric={metric} n={n} d={d}")
+        fb = idx.last_fallbacks
+        idx.set_candidate_mode(0)
+        lab0, dist0 = idx.SearchBatch(Q, k)
+        assert np.array_equal(lab0, lab) and np.array_equal(dist0, dist)
+        assert fb <= nq // 4
+        idx.Close()
+    idx = new_index(48, metric)            # dim % 32 != 0 -> unsupported, index keeps working in f32 mode
+    from longbow_amd import gpu
+    with pytest.raises(gpu.LongbowGPUError):
+        idx.set_candidate_mode(1)
+    idx.Close()
