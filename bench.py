@@ -129,6 +129,7 @@ def main():
         step()
     idx.set_profiling(True)  # HIP events on the search stream around each kernel class
     gemm_ms, gemm_launches, fallbacks = 0.0, 0, 0
+    cls_ms = {"gemm": 0.0, "select": 0.0, "rerank": 0.0, "scan": 0.0, "total": 0.0}
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -136,6 +137,8 @@ def main():
         tm = idx.last_timing()
         gemm_ms += tm["gemm"][0]
         gemm_launches += tm["gemm"][1]
+        for c in cls_ms:
+            cls_ms[c] += tm[c][0]
         fallbacks += idx.last_fallbacks
     barrier()
     elapsed = time.perf_counter() - t0
@@ -162,6 +165,7 @@ def main():
                    "sharding": "RingSharder(n_gpus, 40) + RCCL all-gather merge" if use_dist else "single shard",
                    "unit_of_value": "one query searched over one 1Mx768 shard"},
         "fallback_queries": int(fallbacks),
+        "device_ms_per_step": {c: round(v / args.steps, 4) for c, v in cls_ms.items()},
     }
 
     flops_per_step = 2.0 * B * rows * DIM

@@ -494,7 +494,16 @@ void launch_gemm_filter(int metric, const float *X, const float *norm2, const fl
     const bool aligned = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0) &&
                          ((reinterpret_cast<uintptr_t>(Q) & 15) == 0);
     const int mode = !aligned ? 0 : (D % BK == 0 ? 2 : 1);
-    if (g_gemm_ablation > 0 && metric == METRIC_COS && mode == 2) {
+    if (split && g_gemm_ablation > 0 && metric == METRIC_COS) {
+        switch (g_gemm_ablation) {
+        case 1: hipLaunchKernelGGL((gemm_filter_kernel<METRIC_COS, 2, 1, true, true>), grid, dim3(GEMM_THREADS), 0, s, a); return;
+        case 2: hipLaunchKernelGGL((gemm_filter_kernel<METRIC_COS, 2, 2, true, true>), grid, dim3(GEMM_THREADS), 0, s, a); return;
+        case 5: hipLaunchKernelGGL((gemm_filter_kernel<METRIC_COS, 2, 5, true, true>), grid, dim3(GEMM_THREADS), 0, s, a); return;
+        case 6: hipLaunchKernelGGL((gemm_filter_kernel<METRIC_COS, 2, 6, true, true>), grid, dim3(GEMM_THREADS), 0, s, a); return;
+        default: break;
+        }
+    }
+    if (!split && g_gemm_ablation > 0 && metric == METRIC_COS && mode == 2) {
         switch (g_gemm_ablation) {
         case 1: hipLaunchKernelGGL((gemm_filter_kernel<METRIC_COS, 2, 1>), grid, dim3(GEMM_THREADS), 0, s, a); return;
         case 2: hipLaunchKernelGGL((gemm_filter_kernel<METRIC_COS, 2, 2>), grid, dim3(GEMM_THREADS), 0, s, a); return;

@@ -268,6 +268,67 @@ struct RerankArgs {
     int aligned;
 };
 
+// Shared tail of the re-rank kernels: containment check, final (distance,row) ordering, output.
+template <int METRIC>
+__device__ __forceinline__ void rerank_finish(const RerankArgs &a, int qi, int tid, uint32_t nc, uint32_t P,
+                                              const float *sq, uint64_t *skey, const float *scmp,
+                                              unsigned int &s_count, float &s_w, float na)
+{
+    const int D = a.D;
+    // ---- containment check (only meaningful when the list is full: rows were left out) ----
+    // Any row y outside the list has approx_key(y) >= approx_key(c_last); with rounding-error
+    // bound E on both evaluations, exact_cmp(y) >= w - E.  If at least k candidates satisfy
+    // cmp < w - E (strictly), the true top-k lies inside the list.
+    if (nc >= (uint32_t)a.kc && nc > (uint32_t)a.k) {
+        // ga: error bound of the candidate inner product per unit of |q||x| (host-provided, depends
+        // on the contraction: f32 fma chain or split-bf16); go: the same for the exact f32 re-rank sums
+        const float ga = a.gamma;
+        const float go = 1.05f * (float)(D + 8) * 5.9604645e-8f; // (D+8) * 2^-24
+        const float xmax2 = __builtin_bit_cast(float, *a.maxnorm2);
+        const float xmax = sqrtf(xmax2) * 1.000001f;
+        const float w = s_w;
+        float T;
+        bool skip = false;
+        if (METRIC == METRIC_L2) {
+            float nq2 = 0.f;
+            for (int i = 0; i < D; i++) nq2 += sq[i] * sq[i];
+            const float nqn = sqrtf(nq2) * 1.000001f;
+            // d^2 space: key error go*|x|^2 + 2*ga*|q||x| for each of c_last and the outsider;
+            // exact side relative go on each of the two d^2 values
+            T = w * (1.0f - 3.0f * go) - 2.2f * (go * xmax2 + 2.0f * ga * nqn * xmax);
+        } else if (METRIC == METRIC_COS) {
+            T = w - 2.2f * (ga + 2.8f * go);
+            skip = (na == 0.0f); // all distances are exactly 1.0; selection by row is exact
+        } else {
+            float nq2 = 0.f;
+            for (int i = 0; i < D; i++) nq2 += sq[i] * sq[i];
+            const float nqn = sqrtf(nq2) * 1.000001f;
+            T = w - 2.2f * (ga + go) * nqn * xmax;
+        }
+        T = T - fabsf(T) * 1e-6f;
+        unsigned int local = 0;
+        for (uint32_t c = tid; c < nc; c += SEL_THREADS) local += (scmp[c] < T) ? 1u : 0u;
+        if (local) atomicAdd(&s_count, local);
+        __syncthreads();
+        if (tid == 0 && !skip && s_count < (unsigned int)a.k) atomicOr(&a.cs.flags[qi], 2u);
+    }
+
+    bitonic_sort_u64(skey, P, tid, SEL_THREADS);
+
+    for (int r = tid; r < a.k; r += SEL_THREADS) {
+        float d = FLT_MAX;
+        int64_t lab = -1;
+        if ((uint32_t)r < nc) {
+            const uint64_t e = skey[r];
+            d = entry_key(e);
+            const uint32_t row = entry_row(e);
+            lab = a.ids ? a.ids[row] : (int64_t)row;
+        }
+        a.out_dist[(int64_t)qi * a.k + r] = d;
+        a.out_labels[(int64_t)qi * a.k + r] = lab;
+    }
+}
+
 // One workgroup per query.  LDS: q[D] | sort keys u64[P] | cmp values f32[P]
 template <int METRIC, int ORDER>
 __global__ __launch_bounds__(SEL_THREADS) void rerank_kernel(RerankArgs a)
@@ -307,6 +368,8 @@ __global__ __launch_bounds__(SEL_THREADS) void rerank_kernel(RerankArgs a)
         AccR<ORDER> acc, nb;
         acc.zero();
         nb.zero();
+        // each lane walks its own row: keep 16 independent 16-B loads (two 128-B lines) in flight
+#pragma unroll 16
         for (int i = 0; i < dmain; i += 4) {
             float x0, x1, x2, x3;
             if (a.aligned) {
@@ -365,58 +428,128 @@ __global__ __launch_bounds__(SEL_THREADS) void rerank_kernel(RerankArgs a)
     }
     __syncthreads();
 
-    // ---- containment check (only meaningful when the list is full: rows were left out) ----
-    // Any row y outside the list has approx_key(y) >= approx_key(c_last); with rounding-error
-    // bound E on both evaluations, exact_cmp(y) >= w - E.  If at least k candidates satisfy
-    // cmp < w - E (strictly), the true top-k lies inside the list.
-    if (nc >= (uint32_t)a.kc && nc > (uint32_t)a.k) {
-        // ga: error bound of the candidate inner product per unit of |q||x| (host-provided, depends
-        // on the contraction: f32 fma chain or split-bf16); go: the same for the exact f32 re-rank sums
-        const float ga = a.gamma;
-        const float go = 1.05f * (float)(D + 8) * 5.9604645e-8f; // (D+8) * 2^-24
-        const float xmax2 = __builtin_bit_cast(float, *a.maxnorm2);
-        const float xmax = sqrtf(xmax2) * 1.000001f;
-        const float w = s_w;
-        float T;
-        bool skip = false;
-        if (METRIC == METRIC_L2) {
-            float nq2 = 0.f;
-            for (int i = 0; i < D; i++) nq2 += sq[i] * sq[i];
-            const float nqn = sqrtf(nq2) * 1.000001f;
-            // d^2 space: key error go*|x|^2 + 2*ga*|q||x| for each of c_last and the outsider;
-            // exact side relative go on each of the two d^2 values
-            T = w * (1.0f - 3.0f * go) - 2.2f * (go * xmax2 + 2.0f * ga * nqn * xmax);
-        } else if (METRIC == METRIC_COS) {
-            T = w - 2.2f * (ga + 2.8f * go);
-            skip = (na == 0.0f); // all distances are exactly 1.0; selection by row is exact
-        } else {
-            float nq2 = 0.f;
-            for (int i = 0; i < D; i++) nq2 += sq[i] * sq[i];
-            const float nqn = sqrtf(nq2) * 1.000001f;
-            T = w - 2.2f * (ga + go) * nqn * xmax;
-        }
-        T = T - fabsf(T) * 1e-6f;
-        unsigned int local = 0;
-        for (uint32_t c = tid; c < nc; c += SEL_THREADS) local += (scmp[c] < T) ? 1u : 0u;
-        if (local) atomicAdd(&s_count, local);
+    rerank_finish<METRIC>(a, qi, tid, nc, P, sq, skey, scmp, s_count, s_w, na);
+}
+
+// ---------------------------------------------------------------------------
+// rerank_tiled_kernel: same arithmetic as rerank_kernel, but the candidate rows are gathered through
+// LDS in coalesced 256-B pieces (lane = candidate walks its own row out of LDS), instead of every lane
+// striding through HBM on its own: 16 independent 16-B loads per lane in flight, full lines per row.
+// One workgroup (256 lanes) per query, candidates processed in groups of 256.
+// LDS: q[Dpad] | row ids u32[256] | tile f32[256][68] | keys u64[P] | cmp f32[P] | scalars
+constexpr int RR_DK = 64, RR_LD = RR_DK + 4;
+
+template <int METRIC, int ORDER>
+__global__ __launch_bounds__(SEL_THREADS) void rerank_tiled_kernel(RerankArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int qi = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int D = a.D; // D % 4 == 0 and 16-B aligned rows (checked by the launcher)
+    const uint32_t nc = a.cs.cnt[qi];
+    const uint32_t P = next_pow2(nc > 0 ? nc : 1);
+    const uint32_t Pmax = next_pow2((uint32_t)a.kc);
+    const int Dpad = (D + 63) & ~63;
+    float *sq = reinterpret_cast<float *>(smem);
+    uint32_t *srow = reinterpret_cast<uint32_t *>(sq + Dpad);
+    float *tile = reinterpret_cast<float *>(srow + SEL_THREADS);
+    uint64_t *skey = reinterpret_cast<uint64_t *>(tile + SEL_THREADS * RR_LD);
+    float *scmp = reinterpret_cast<float *>(skey + Pmax);
+    unsigned int &s_count = *reinterpret_cast<unsigned int *>(scmp + Pmax);
+    float &s_w = *reinterpret_cast<float *>(scmp + Pmax + 1);
+
+    const float *q = a.Q + (int64_t)qi * D;
+    for (int i = tid; i < Dpad; i += SEL_THREADS) sq[i] = i < D ? q[i] : 0.f;
+    if (tid == 0) { s_count = 0; s_w = 0.f; }
+    const uint64_t *list = a.cs.lists + (size_t)qi * a.cs.cap;
+    const float na = (METRIC == METRIC_COS) ? a.qna[qi] : 0.f;
+    const int nchunks = (D + RR_DK - 1) / RR_DK;
+
+    for (uint32_t g0 = 0; g0 < P; g0 += SEL_THREADS) {
+        const uint32_t c = g0 + tid;
+        const uint32_t myrow = c < nc ? entry_row(list[c]) : (nc ? entry_row(list[0]) : 0u);
+        __syncthreads(); // previous group's tile reads are done; sq / s_* initialised
+        srow[tid] = myrow;
         __syncthreads();
-        if (tid == 0 && !skip && s_count < (unsigned int)a.k) atomicOr(&a.cs.flags[qi], 2u);
-    }
-
-    bitonic_sort_u64(skey, P, tid, SEL_THREADS);
-
-    for (int r = tid; r < a.k; r += SEL_THREADS) {
-        float d = FLT_MAX;
-        int64_t lab = -1;
-        if ((uint32_t)r < nc) {
-            const uint64_t e = skey[r];
-            d = entry_key(e);
-            const uint32_t row = entry_row(e);
-            lab = a.ids ? a.ids[row] : (int64_t)row;
+        AccR<ORDER> acc, nb;
+        acc.zero();
+        nb.zero();
+        f32x4 stg[16];
+        auto load_stage = [&](int ch) {
+            const int d0 = ch * RR_DK;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int idx = tid + SEL_THREADS * i;
+                const int r = idx >> 4, p = idx & 15;
+                int k = d0 + p * 4;
+                if (k > D - 4) k = D - 4; // pieces past D are never consumed
+                stg[i] = *reinterpret_cast<const f32x4 *>(a.X + (int64_t)srow[r] * D + k);
+            }
+        };
+        load_stage(0);
+        for (int ch = 0; ch < nchunks; ch++) {
+            __syncthreads(); // tile free
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int idx = tid + SEL_THREADS * i;
+                *reinterpret_cast<f32x4 *>(&tile[(idx >> 4) * RR_LD + (idx & 15) * 4]) = stg[i];
+            }
+            __syncthreads();
+            if (ch + 1 < nchunks) load_stage(ch + 1); // in flight under the compute below
+            const int d0 = ch * RR_DK;
+            const int n4 = (min(D, d0 + RR_DK) - d0) >> 2;
+            const float *xr = &tile[tid * RR_LD];
+#pragma unroll 4
+            for (int g = 0; g < n4; g++) {
+                const f32x4 xv = *reinterpret_cast<const f32x4 *>(&xr[g * 4]);
+                const f32x4 qv = *reinterpret_cast<const f32x4 *>(&sq[d0 + g * 4]);
+                if (METRIC == METRIC_COS) {
+                    nb.template add<0>(xv.x * xv.x);
+                    nb.template add<1>(xv.y * xv.y);
+                    nb.template add<2>(xv.z * xv.z);
+                    nb.template add<3>(xv.w * xv.w);
+                }
+                if (METRIC == METRIC_L2) {
+                    const float e0 = qv.x - xv.x, e1 = qv.y - xv.y, e2 = qv.z - xv.z, e3 = qv.w - xv.w;
+                    acc.template add<0>(e0 * e0);
+                    acc.template add<1>(e1 * e1);
+                    acc.template add<2>(e2 * e2);
+                    acc.template add<3>(e3 * e3);
+                } else {
+                    acc.template add<0>(qv.x * xv.x);
+                    acc.template add<1>(qv.y * xv.y);
+                    acc.template add<2>(qv.z * xv.z);
+                    acc.template add<3>(qv.w * xv.w);
+                }
+            }
         }
-        a.out_dist[(int64_t)qi * a.k + r] = d;
-        a.out_labels[(int64_t)qi * a.k + r] = lab;
+        if (c < P) {
+            if (c >= nc) {
+                skey[c] = kEntryMax;
+                scmp[c] = FLT_MAX;
+            } else {
+                const float t = acc.total();
+                float dist, cmp;
+                if (METRIC == METRIC_L2) {
+                    dist = (float)sqrt((double)t);
+                    cmp = t;
+                } else if (METRIC == METRIC_COS) {
+                    const float nbt = nb.total();
+                    if (D == 0 || na == 0.0f || nbt == 0.0f) dist = 1.0f;
+                    else dist = 1.0f - __fdiv_rn(t, (float)sqrt((double)na * (double)nbt));
+                    cmp = dist;
+                } else {
+                    dist = -t;
+                    cmp = dist;
+                }
+                skey[c] = pack_entry(dist, myrow);
+                scmp[c] = cmp;
+                if (c == (uint32_t)a.kc - 1) s_w = cmp;
+            }
+        }
     }
+    __syncthreads();
+    rerank_finish<METRIC>(a, qi, tid, nc, P, sq, skey, scmp, s_count, s_w, na);
 }
 
 void launch_rerank(int metric, int order, const float *X, int D, const float *Q, int nq,
@@ -432,6 +565,20 @@ void launch_rerank(int metric, int order, const float *X, int D, const float *Q,
     const size_t P = next_pow2_host((uint32_t)kc);
     const size_t shmem = (size_t)Dpad * 4 + P * 8 + P * 4 + 16;
     dim3 grid(nq), block(SEL_THREADS);
+    if (a.aligned && D >= 4) {
+        const int Dq = (D + 63) & ~63;
+        const size_t sh2 = (size_t)Dq * 4 + SEL_THREADS * 4 + (size_t)SEL_THREADS * RR_LD * 4 + P * 8 + P * 4 + 16;
+#define LB_RRT(M, O)                                                                \
+    do {                                                                            \
+        allow_big_lds(rerank_tiled_kernel<M, O>, sh2);                              \
+        hipLaunchKernelGGL((rerank_tiled_kernel<M, O>), grid, block, sh2, s, a);    \
+    } while (0)
+        if (metric == METRIC_L2) { if (order == ORDER_UNROLL4) LB_RRT(METRIC_L2, ORDER_UNROLL4); else LB_RRT(METRIC_L2, ORDER_SEQ); }
+        else if (metric == METRIC_COS) { if (order == ORDER_UNROLL4) LB_RRT(METRIC_COS, ORDER_UNROLL4); else LB_RRT(METRIC_COS, ORDER_SEQ); }
+        else { if (order == ORDER_UNROLL4) LB_RRT(METRIC_DOT, ORDER_UNROLL4); else LB_RRT(METRIC_DOT, ORDER_SEQ); }
+#undef LB_RRT
+        return;
+    }
     allow_big_lds(rerank_kernel<METRIC_L2, ORDER_SEQ>, shmem);
     allow_big_lds(rerank_kernel<METRIC_L2, ORDER_UNROLL4>, shmem);
     allow_big_lds(rerank_kernel<METRIC_COS, ORDER_SEQ>, shmem);
