@@ -90,7 +90,8 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
     return v;
 }
 
-__global__ __launch_bounds__(SEL_THREADS) void select_kernel(CandState cs, const int *qsel, int kc,
+template <int NT> // threads per workgroup: 256 (throughput, many queries) or 1024 (latency, few queries)
+__global__ __launch_bounds__(NT) void select_kernel(CandState cs, const int *qsel, int kc,
                                                              uint32_t boot_rows)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t sh[];
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(CandState cs, const
 
     if (tid == 0) { scal[2] = 0; scal[3] = 0; }
     uint32_t myvalid = 0;
-    for (uint32_t i = tid; i < P; i += SEL_THREADS) {
+    for (uint32_t i = tid; i < P; i += NT) {
         const uint64_t e = i < n ? list[i] : kEntryMax;
         sh[i] = e;
         myvalid += (e != kEntryMax) ? 1u : 0u;
@@ -132,8 +133,8 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(CandState cs, const
     const uint32_t keep = n < (uint32_t)kc ? n : (uint32_t)kc;
 
     if (P <= 2u * next_pow2((uint32_t)kc) || n <= (uint32_t)kc) {
-        bitonic_sort_u64(sh, P, tid, SEL_THREADS); // kEntryMax padding sorts last
-        for (uint32_t i = tid; i < keep; i += SEL_THREADS) list[i] = sh[i];
+        bitonic_sort_u64(sh, P, tid, NT); // kEntryMax padding sorts last
+        for (uint32_t i = tid; i < keep; i += NT) list[i] = sh[i];
         if (tid == 0) {
             cs.cnt[q] = keep;
             cs.tau[q] = n >= (uint32_t)kc ? sh[kc - 1] : kEntryMax;
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(CandState cs, const
     __syncthreads();
     {
         uint64_t o = 0, an = ~0ull;
-        for (uint32_t i = tid; i < P; i += SEL_THREADS) {
+        for (uint32_t i = tid; i < P; i += NT) {
             const uint64_t e = sh[i];
             if (e != kEntryMax) { o |= e; an &= e; }
         }
@@ -171,23 +172,25 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(CandState cs, const
     }
     uint32_t need = (uint32_t)kc;
     for (int shift = first_shift; shift >= 0; shift -= 8) {
-        hist[tid] = 0; // SEL_THREADS == 256 bins
+        if (tid < 256) hist[tid] = 0; // 256 bins
         __syncthreads();
-        for (uint32_t i = tid; i < P; i += SEL_THREADS) {
+        for (uint32_t i = tid; i < P; i += NT) {
             const uint64_t e = sh[i];
             if ((e & mask) == prefix) atomicAdd(&hist[(uint32_t)(e >> shift) & 0xffu], 1u);
         }
         __syncthreads();
-        const uint32_t h = hist[tid];
+        const uint32_t h = tid < 256 ? hist[tid] : 0u;
         uint32_t incl = wave_incl_scan(h, lane);
-        if (lane == 63) wsum[wave] = incl;
+        if (tid < 256 && lane == 63) wsum[wave] = incl;
         __syncthreads();
-        uint32_t base = 0;
+        if (tid < 256) {
+            uint32_t base = 0;
 #pragma unroll
-        for (int w = 0; w < 4; w++) base += (w < wave) ? wsum[w] : 0u;
-        incl += base;
-        const uint32_t excl = incl - h;
-        if (excl < need && need <= incl) { scal[0] = (uint32_t)tid; scal[1] = need - excl; }
+            for (int w = 0; w < 4; w++) base += (w < wave) ? wsum[w] : 0u;
+            incl += base;
+            const uint32_t excl = incl - h;
+            if (excl < need && need <= incl) { scal[0] = (uint32_t)tid; scal[1] = need - excl; }
+        }
         __syncthreads();
         prefix |= (uint64_t)scal[0] << shift;
         mask |= 0xffull << shift;
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(CandState cs, const
     const uint64_t pivot = prefix; // the kc-th smallest entry
     // compact the kc entries <= pivot into the front of the global list (unordered), then sort them
     __syncthreads();
-    for (uint32_t i = tid; i < P; i += SEL_THREADS) {
+    for (uint32_t i = tid; i < P; i += NT) {
         const uint64_t e = sh[i];
         if (e <= pivot) {
             const uint32_t pos = atomicAdd(&scal[2], 1u);
@@ -206,10 +209,10 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(CandState cs, const
     }
     __syncthreads();
     const uint32_t Pk = next_pow2((uint32_t)kc);
-    for (uint32_t i = tid; i < Pk; i += SEL_THREADS) sh[i] = i < (uint32_t)kc ? list[i] : kEntryMax;
+    for (uint32_t i = tid; i < Pk; i += NT) sh[i] = i < (uint32_t)kc ? list[i] : kEntryMax;
     __syncthreads();
-    bitonic_sort_u64(sh, Pk, tid, SEL_THREADS);
-    for (uint32_t i = tid; i < (uint32_t)kc; i += SEL_THREADS) list[i] = sh[i];
+    bitonic_sort_u64(sh, Pk, tid, NT);
+    for (uint32_t i = tid; i < (uint32_t)kc; i += NT) list[i] = sh[i];
     if (tid == 0) {
         cs.cnt[q] = (uint32_t)kc;
         cs.tau[q] = pivot;
@@ -220,8 +223,13 @@ void launch_select(CandState cs, const int *qsel, int nsel, int kc, uint32_t boo
 {
     if (nsel <= 0) return;
     const size_t shmem = (size_t)next_pow2_host(cs.cap) * sizeof(uint64_t) + (256 + 4 + 4) * sizeof(uint32_t);
-    allow_big_lds(select_kernel, shmem);
-    hipLaunchKernelGGL(select_kernel, dim3(nsel), dim3(SEL_THREADS), shmem, s, cs, qsel, kc, boot_rows);
+    if (nsel <= 32) { // few queries: one big workgroup each, latency matters
+        allow_big_lds(select_kernel<1024>, shmem);
+        hipLaunchKernelGGL(select_kernel<1024>, dim3(nsel), dim3(1024), shmem, s, cs, qsel, kc, boot_rows);
+    } else {
+        allow_big_lds(select_kernel<256>, shmem);
+        hipLaunchKernelGGL(select_kernel<256>, dim3(nsel), dim3(256), shmem, s, cs, qsel, kc, boot_rows);
+    }
 }
 
 // ---------------------------------------------------------------------------
