@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "liblongbow_gpu.so")
-SOURCES = ["index.hip", "pq.hip", "kernels_gemm.hip", "kernels_scan.hip", "kernels_select.hip",
+SOURCES = ["index.hip", "pq.hip", "kernels_gemm.hip", "kernels_gemm_narrow.hip", "kernels_scan.hip", "kernels_select.hip",
            "kernels_pq.hip", "kernels_filter.hip"]
 HEADERS = ["lb_device.h", os.path.join("..", "..", "include", "longbow_gpu.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

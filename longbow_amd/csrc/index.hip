@@ -15,6 +15,7 @@
 #include <cfloat>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -302,7 +303,13 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     const uint8_t *mask = h->has_mask ? h->d_mask : nullptr;
     ProfScope whole(w, s, prof, 4);
 
-    if (nq < kGemmMinQ) {
+    // Path selection (measured at 1M x 768 on MI355X, tools/bench_sweep.py): <= 4 queries exact scan
+    // (0.65-0.77 ms); 5..384 queries narrow MFMA tile (0.78 ms at 5-8, 0.87 ms at 32, 3.7 ms at 256);
+    // beyond that the 128-query tile.
+    const bool narrow_ok = h->dim % 32 == 0 && ((reinterpret_cast<uintptr_t>(d_q) & 15) == 0);
+    static const int narrow_min = [] { const char *e = getenv("LB_NARROW_MINQ"); return e ? atoi(e) : 5; }();
+    static const int narrow_max = [] { const char *e = getenv("LB_NARROW_MAXQ"); return e ? atoi(e) : 384; }();
+    if (nq < (narrow_ok ? narrow_min : kGemmMinQ)) {
         std::vector<int> all(nq);
         for (int i = 0; i < nq; i++) all[i] = i;
         scan_with_retry(h, w, s, d_q, nq, all, k, d_dist, d_lab, prof);
@@ -339,8 +346,12 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         const bool boot = step == 0;
         {
             ProfScope p(w, s, prof, 0);
-            launch_gemm_filter(metric, gx, h->d_norm2, h->d_rnorm, pos, end, h->dim, gq, nq, mask,
-                               w->cs, boot, split, s);
+            if (!split && narrow_ok && nq <= narrow_max)
+                launch_gemm_filter_narrow(metric, gx, h->d_norm2, h->d_rnorm, pos, end, h->dim, gq, nq, mask,
+                                          w->cs, boot, s);
+            else
+                launch_gemm_filter(metric, gx, h->d_norm2, h->d_rnorm, pos, end, h->dim, gq, nq, mask,
+                                   w->cs, boot, split, s);
         }
         {
             ProfScope p(w, s, prof, 1);

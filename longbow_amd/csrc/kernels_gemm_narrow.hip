@@ -1,0 +1,232 @@
+// kernels_gemm_narrow.hip -- candidate generation for SMALL and MID-SIZE query batches (5..384 queries).
+//
+// Same contract as gemm_filter_kernel (kernels_gemm.hip) with a tile shaped for the HBM-bound
+// regime: 256 corpus rows x 32 queries per workgroup.  At B <= 32 the f32 contraction needs
+// 2*32*N*D flop = 0.31 ms of MFMA time at 1M x 768 while the corpus read needs ~0.5 ms of HBM time,
+// so one pass over the corpus serves the whole batch at the HBM rate; the 128-query tile of the wide
+// kernel would spend 4x the MFMA time on padding.  4 waves, each 64 rows x 32 queries (2 MFMA
+// 32x32 tiles, 32 accumulator VGPRs); each wave stages exactly the 64 corpus rows it consumes
+// (8 direct-to-LDS DMA instructions of 1 KiB per K-step, nt policy) plus a quarter of the 4 KiB query
+// tile; LDS 2 x (32 + 4) KiB, two workgroups per CU = 64 KiB of corpus bytes in flight per CU.
+// LDS image, swizzle, k permutation and the epilogue (key, branch-free admission, one atomic per
+// lane) are those of the wide kernel.
+#include "lb_device.h"
+
+namespace lb {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int NBM = 256; // corpus rows per tile
+constexpr int NBN = 32;  // queries per tile
+constexpr int NBK = 32;
+constexpr int NTHREADS = 256;
+
+struct NarrowArgs {
+    const float *X;
+    const float *norm2;
+    const float *rnorm;
+    int64_t row_begin, row_end;
+    int D;
+    const float *Q;
+    int nq;
+    const uint8_t *mask;
+    CandState cs;
+    int n_row_tiles, n_q_tiles;
+    int boot;
+};
+
+__device__ __forceinline__ int nswz(int row, int chunk) { return row * NBK + ((chunk ^ ((row >> 1) & 7)) << 2); }
+
+template <int METRIC>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowArgs a)
+{
+    const int b = blockIdx.x;
+    const int xcd = b & 7;
+    const int in_xcd = b >> 3;
+    const int qt = in_xcd % a.n_q_tiles;
+    const int rt = (in_xcd / a.n_q_tiles) * 8 + xcd;
+    if (rt >= a.n_row_tiles) return;
+
+    constexpr int STAGE_F = (NBM + NBN) * NBK;
+    __shared__ __attribute__((aligned(16))) float lds_all[2 * STAGE_F + NBM + NBM / 4];
+    float *s_aux = lds_all + 2 * STAGE_F;
+    uint8_t *s_vis = reinterpret_cast<uint8_t *>(s_aux + NBM);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int64_t row0 = a.row_begin + (int64_t)rt * NBM;
+    const int q0 = qt * NBN;
+    const int64_t last_row = a.row_end - 1;
+    const int last_q = a.nq - 1;
+
+    {
+        int64_t ri = row0 + tid;
+        const bool in_range = ri <= last_row;
+        if (!in_range) ri = last_row;
+        s_aux[tid] = METRIC == METRIC_L2 ? a.norm2[ri] : (METRIC == METRIC_COS ? a.rnorm[ri] : 0.f);
+        s_vis[tid] = (in_range && (!a.mask || a.mask[ri])) ? (uint8_t)1 : (uint8_t)0;
+    }
+    const int qj = q0 + l31;
+    const bool qok = qj < a.nq;
+    const uint64_t tau = (qok && !a.boot) ? a.cs.tau[qj] : 0ull;
+    const float tk = entry_key(tau);
+    const uint32_t tr = entry_row(tau);
+
+    // DMA sources: A instruction i of this wave fills rows 64*wave + 8i .. +7; the wave's single
+    // B instruction fills query rows 8*wave .. +7.  Lane l lands at (row l/8, chunk position l%8).
+    const float *srcA[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int row = wave * 64 + i * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        int64_t xr = row0 + row;
+        if (xr > last_row) xr = last_row;
+        srcA[i] = a.X + xr * (int64_t)a.D + 4 * c;
+    }
+    const float *srcB;
+    {
+        const int row = wave * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        int qr = q0 + row;
+        if (qr > last_q) qr = last_q;
+        srcB = a.Q + (int64_t)qr * a.D + 4 * c;
+    }
+    auto stage_in = [&](int stage, int k0) {
+        float *A = lds_all + stage * STAGE_F;
+        float *B = A + NBM * NBK;
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcA[i] + k0),
+                                             (__attribute__((address_space(3))) void *)(A + (wave * 64 + i * 8) * NBK),
+                                             16, 0, 2 /* nt: the corpus streams through once */);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcB + k0),
+                                         (__attribute__((address_space(3))) void *)(B + wave * 8 * NBK), 16, 0, 0);
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+
+    const int nk = a.D / NBK; // D % 32 == 0 (launcher)
+    stage_in(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt++) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage_in(cur ^ 1, (kt + 1) * NBK);
+        const float *As = lds_all + cur * STAGE_F;
+        const float *Bs = As + NBM * NBK;
+        f32x4 fa[2][2], fb[2];
+#pragma unroll
+        for (int t = 0; t < 2; t++) fa[0][t] = *reinterpret_cast<const f32x4 *>(&As[nswz(wave * 64 + t * 32 + l31, h)]);
+        fb[0] = *reinterpret_cast<const f32x4 *>(&Bs[nswz(l31, h)]);
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const int cb = s & 1, nb = cb ^ 1;
+            if (s < 3) {
+                const int ch = 2 * (s + 1) + h;
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+                    fa[nb][t] = *reinterpret_cast<const f32x4 *>(&As[nswz(wave * 64 + t * 32 + l31, ch)]);
+                fb[nb] = *reinterpret_cast<const f32x4 *>(&Bs[nswz(l31, ch)]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+#pragma unroll
+                for (int tm = 0; tm < 2; tm++)
+                    acc[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb][tm][e], fb[cb][e], acc[tm], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue (as in gemm_filter_kernel) -------------------------------------------------
+    float aux[2][4][4];
+    uint32_t vbits = 0;
+#pragma unroll
+    for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int lr = wave * 64 + tm * 32 + 8 * g + 4 * h;
+            const f32x4 av = *reinterpret_cast<const f32x4 *>(&s_aux[lr]);
+            const uint32_t vv = *reinterpret_cast<const uint32_t *>(&s_vis[lr]);
+            aux[tm][g][0] = av.x; aux[tm][g][1] = av.y; aux[tm][g][2] = av.z; aux[tm][g][3] = av.w;
+            const uint32_t nib = (vv & 1u) | ((vv >> 7) & 2u) | ((vv >> 14) & 4u) | ((vv >> 21) & 8u);
+            vbits |= nib << (tm * 16 + g * 4);
+        }
+    auto key_of = [&](float dot, float ax) -> float {
+        if (METRIC == METRIC_L2) return fmaf(-2.0f, dot, ax);
+        if (METRIC == METRIC_COS) return -dot * ax;
+        return -dot;
+    };
+    uint64_t *list = a.cs.lists + (size_t)(qok ? qj : 0) * a.cs.cap;
+    if (a.boot) {
+        if (qok) {
+#pragma unroll
+            for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int64_t rbase = row0 + wave * 64 + tm * 32 + 8 * g + 4 * h;
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        if (rbase + e < a.row_end)
+                            list[rbase + e - a.row_begin] =
+                                ((vbits >> (tm * 16 + g * 4 + e)) & 1u)
+                                    ? pack_entry(key_of(acc[tm][4 * g + e], aux[tm][g][e]), (uint32_t)(rbase + e))
+                                    : kEntryMax;
+                }
+        }
+        return;
+    }
+    const uint32_t rloc0 = (uint32_t)(row0 + wave * 64 + 4 * h);
+    uint32_t bits = 0;
+#pragma unroll
+    for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float key = key_of(acc[tm][4 * g + e], aux[tm][g][e]);
+                const uint32_t ri = rloc0 + (uint32_t)(tm * 32 + 8 * g + e);
+                const uint32_t lt = (uint32_t)(key < tk) | ((uint32_t)(key == tk) & (uint32_t)(ri < tr));
+                bits |= lt << (tm * 16 + g * 4 + e);
+            }
+    bits &= vbits; // out-of-range rows and queries never pass (tau of a padded query decodes to NaN)
+    if (bits) {
+        uint32_t pos = atomicAdd(&a.cs.cnt[qj], (uint32_t)__builtin_popcount(bits));
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if (bits & (1u << (tm * 16 + g * 4 + e))) {
+                        const uint32_t ri = rloc0 + (uint32_t)(tm * 32 + 8 * g + e);
+                        if (pos < a.cs.cap) list[pos] = pack_entry(key_of(acc[tm][4 * g + e], aux[tm][g][e]), ri);
+                        pos++;
+                    }
+    }
+}
+
+// Requires D % 32 == 0 and 16-B aligned X / Q (the caller checks; otherwise the wide kernel runs).
+void launch_gemm_filter_narrow(int metric, const float *X, const float *norm2, const float *rnorm,
+                               int64_t row_begin, int64_t row_end, int D, const float *Q, int nq,
+                               const uint8_t *mask, CandState cs, bool boot, hipStream_t s)
+{
+    if (row_end <= row_begin || nq <= 0) return;
+    NarrowArgs a;
+    a.X = X; a.norm2 = norm2; a.rnorm = rnorm; a.row_begin = row_begin; a.row_end = row_end; a.D = D;
+    a.Q = Q; a.nq = nq; a.mask = mask; a.cs = cs; a.boot = boot ? 1 : 0;
+    a.n_row_tiles = (int)((row_end - row_begin + NBM - 1) / NBM);
+    a.n_q_tiles = (nq + NBN - 1) / NBN;
+    const int groups = (a.n_row_tiles + 7) / 8;
+    dim3 grid((unsigned)(groups * 8 * a.n_q_tiles));
+    if (metric == METRIC_L2) hipLaunchKernelGGL(gemm_filter_narrow_kernel<METRIC_L2>, grid, dim3(NTHREADS), 0, s, a);
+    else if (metric == METRIC_COS) hipLaunchKernelGGL(gemm_filter_narrow_kernel<METRIC_COS>, grid, dim3(NTHREADS), 0, s, a);
+    else hipLaunchKernelGGL(gemm_filter_narrow_kernel<METRIC_DOT>, grid, dim3(NTHREADS), 0, s, a);
+}
+
+} // namespace lb

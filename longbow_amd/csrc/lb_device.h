@@ -87,6 +87,10 @@ void launch_row_norms(const float *X, int64_t n, int D, float *norm2, float *rno
 void launch_gemm_filter(int metric, const float *X, const float *norm2, const float *rnorm,
                         int64_t row_begin, int64_t row_end, int D, const float *Q, int nq,
                         const uint8_t *mask, CandState cs, bool boot, bool split, hipStream_t s);
+// small/mid-size batches (5..384 queries): 256-row x 32-query tiles, HBM-bound; needs D % 32 == 0, 16-B aligned X/Q
+void launch_gemm_filter_narrow(int metric, const float *X, const float *norm2, const float *rnorm,
+                               int64_t row_begin, int64_t row_end, int D, const float *Q, int nq,
+                               const uint8_t *mask, CandState cs, bool boot, hipStream_t s);
 // f32 [rows][D] -> split-bf16 image (same byte shape; D % 32 == 0) consumed by the split GEMM
 void launch_split_bf16(const float *src, float *dst, int64_t rows, int D, hipStream_t s);
 
