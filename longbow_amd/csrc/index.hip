@@ -94,6 +94,22 @@ struct Workspace {
     }
 };
 
+// Device + pinned-host staging for the host-pointer search entry point, pooled per index so a
+// serving loop does not pay hipMalloc/hipFree per call.
+struct HostStage {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    void *d_buf = nullptr, *h_buf = nullptr; // [queries | dist | labels]
+    size_t bytes = 0;
+    ~HostStage()
+    {
+        (void)hipSetDevice(device);
+        if (d_buf) (void)hipFree(d_buf);
+        if (h_buf) (void)hipHostFree(h_buf);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
 } // namespace
 
 struct lb_gpu_index {
@@ -121,6 +137,7 @@ struct lb_gpu_index {
 
     std::mutex ws_mu;
     std::vector<std::unique_ptr<Workspace>> ws_free;
+    std::vector<std::unique_ptr<HostStage>> hs_free;
 
     mutable std::mutex err_mu;
     std::string last_error;
@@ -621,6 +638,7 @@ void lb_gpu_index_free(lb_gpu_index *h)
         {
             std::lock_guard<std::mutex> g2(h->ws_mu);
             h->ws_free.clear();
+            h->hs_free.clear();
         }
         if (h->d_X) (void)hipFree(h->d_X);
         if (h->d_norm2) (void)hipFree(h->d_norm2);
@@ -857,27 +875,49 @@ int lb_gpu_index_search(lb_gpu_index *h, int64_t nq, const float *queries, int k
         std::shared_lock<std::shared_mutex> g(h->mu);
         if (h->closed) { h->set_error("index is closed"); return LB_ERR_CLOSED; }
     }
-    // stage queries/results through device buffers owned by this call
-    float *d_q = nullptr, *d_d = nullptr;
-    int64_t *d_l = nullptr;
+    // borrowed host buffers -> pooled pinned slab -> HBM (async DMA on the call's own stream), and back
+    const size_t qb = (size_t)nq * h->dim * sizeof(float);
+    const size_t db = (((size_t)nq * k * sizeof(float)) + 15) & ~(size_t)15;
+    const size_t lb_ = (size_t)nq * k * sizeof(int64_t);
+    const size_t qoff = 0, doff = (qb + 15) & ~(size_t)15, loff = doff + db, total = loff + lb_;
+    std::unique_ptr<HostStage> st;
     int rc = LB_OK;
     try {
         LB_HIP(hipSetDevice(h->device));
-        LB_HIP(hipMalloc(&d_q, (size_t)nq * h->dim * sizeof(float)));
-        LB_HIP(hipMalloc(&d_d, (size_t)nq * k * sizeof(float)));
-        LB_HIP(hipMalloc(&d_l, (size_t)nq * k * sizeof(int64_t)));
-        LB_HIP(hipMemcpy(d_q, queries, (size_t)nq * h->dim * sizeof(float), hipMemcpyHostToDevice));
-        rc = lb_gpu_index_search_device(h, nq, d_q, k, d_d, d_l, nullptr);
-        if (rc == LB_OK) {
-            LB_HIP(hipMemcpy(dist, d_d, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost));
-            LB_HIP(hipMemcpy(labels, d_l, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost));
+        {
+            std::lock_guard<std::mutex> g(h->ws_mu);
+            for (size_t i = 0; i < h->hs_free.size(); i++)
+                if (h->hs_free[i]->bytes >= total) {
+                    st = std::move(h->hs_free[i]);
+                    h->hs_free.erase(h->hs_free.begin() + (long)i);
+                    break;
+                }
         }
+        if (!st) {
+            st = std::make_unique<HostStage>();
+            st->device = h->device;
+            st->bytes = std::max<size_t>(total, 1u << 20);
+            LB_HIP(hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking));
+            LB_HIP(hipMalloc(&st->d_buf, st->bytes));
+            LB_HIP(hipHostMalloc(&st->h_buf, st->bytes, hipHostMallocDefault));
+        }
+        char *hb = static_cast<char *>(st->h_buf), *dbuf = static_cast<char *>(st->d_buf);
+        std::memcpy(hb + qoff, queries, qb);
+        LB_HIP(hipMemcpyAsync(dbuf + qoff, hb + qoff, qb, hipMemcpyHostToDevice, st->stream));
+        rc = lb_gpu_index_search_device(h, nq, reinterpret_cast<const float *>(dbuf + qoff), k,
+                                        reinterpret_cast<float *>(dbuf + doff), reinterpret_cast<int64_t *>(dbuf + loff),
+                                        st->stream);
+        if (rc == LB_OK) {
+            LB_HIP(hipMemcpyAsync(hb + doff, dbuf + doff, db + lb_, hipMemcpyDeviceToHost, st->stream));
+            LB_HIP(hipStreamSynchronize(st->stream));
+            std::memcpy(dist, hb + doff, (size_t)nq * k * sizeof(float));
+            std::memcpy(labels, hb + loff, lb_);
+        }
+        std::lock_guard<std::mutex> g(h->ws_mu);
+        if (h->hs_free.size() < 8) h->hs_free.push_back(std::move(st));
     } catch (const HipErr &e) {
         rc = fail_hip(h, e);
     }
-    if (d_q) (void)hipFree(d_q);
-    if (d_d) (void)hipFree(d_d);
-    if (d_l) (void)hipFree(d_l);
     return rc;
 }
 
