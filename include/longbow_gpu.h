@@ -195,6 +195,17 @@ int lb_gpu_merge_topk_device(int device, int nshards, int64_t nq, int k, const f
 int lb_gpu_merge_topk_packed_device(int device, int nshards, int64_t nq, int k, const void *d_packed,
                                     float *d_dist_out, int64_t *d_labels_out, void *stream);
 
+/* ---- hybrid fusion ---------------------------------------------------------------------
+ * store.ReciprocalRankFusion (internal/store/rrf.go:10-51) for nq queries at once: per query a dense
+ * ranking ids[kd] and a sparse ranking ids[ks] (best first, -1 = padding, ids unique within a list);
+ * score(id) = sum 1/float64(k + rank + 1) (k <= 0 -> 60), narrowed to f32; output limit ids/scores per
+ * query, score descending (ties: lower id first), padded with -1 / 0.  kd + ks <= 8192. */
+int lb_gpu_rrf_fuse_device(int device, int64_t nq, int kd, const int64_t *d_dense_ids, int ks,
+                           const int64_t *d_sparse_ids, int k, int limit, int64_t *d_out_ids,
+                           float *d_out_scores, void *stream);
+int lb_gpu_rrf_fuse(int device, int64_t nq, int kd, const int64_t *dense_ids, int ks, const int64_t *sparse_ids,
+                    int k, int limit, int64_t *out_ids, float *out_scores);
+
 /* ---- synthetic data (bench / tests) ------------------------------------------------
  * Counter-based uniform [0,1) f32 / uniform u8, bit-identical to the oracle's
  * lbo_fill_uniform / lbo_fill_codes. */

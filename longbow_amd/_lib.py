@@ -70,6 +70,8 @@ SIGNATURES = [
     ("lb_gpu_pq_search_device", _i, [_vp, _i64, _vp, _i, _vp, _vp, _vp]),
     ("lb_gpu_merge_topk_device", _i, [_i, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp]),
     ("lb_gpu_merge_topk_packed_device", _i, [_i, _i, _i64, _i, _vp, _vp, _vp, _vp]),
+    ("lb_gpu_rrf_fuse_device", _i, [_i, _i64, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
+    ("lb_gpu_rrf_fuse", _i, [_i, _i64, _i, _vp, _i, _vp, _i, _i, _vp, _vp]),
     ("lb_gpu_fill_uniform_device", _i, [_i, _vp, _i64, _u64, _i64, _vp]),
     ("lb_gpu_fill_codes_device", _i, [_i, _vp, _i64, _u64, _i64, _vp]),
     ("lb_gpu_index_set_profiling", _i, [_vp, _i]),

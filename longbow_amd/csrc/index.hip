@@ -1025,6 +1025,49 @@ int lb_gpu_merge_topk_packed_device(int device, int nshards, int64_t nq, int k, 
     return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? LB_OK : LB_ERR_HIP;
 }
 
+int lb_gpu_rrf_fuse_device(int device, int64_t nq, int kd, const int64_t *d_dense_ids, int ks,
+                           const int64_t *d_sparse_ids, int k, int limit, int64_t *d_out_ids,
+                           float *d_out_scores, void *stream)
+{
+    if (nq < 0 || kd < 0 || ks < 0 || limit <= 0 || kd + ks > 8192) return LB_ERR_INVALID_ARG;
+    if (nq == 0) return LB_OK;
+    if ((kd > 0 && !d_dense_ids) || (ks > 0 && !d_sparse_ids) || !d_out_ids || !d_out_scores) return LB_ERR_INVALID_ARG;
+    if (!device_ok(device)) return LB_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return LB_ERR_HIP;
+    launch_rrf(nq, kd, d_dense_ids, ks, d_sparse_ids, k <= 0 ? 60 : k, limit, d_out_ids, d_out_scores, (hipStream_t)stream);
+    return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? LB_OK : LB_ERR_HIP;
+}
+
+int lb_gpu_rrf_fuse(int device, int64_t nq, int kd, const int64_t *dense_ids, int ks, const int64_t *sparse_ids,
+                    int k, int limit, int64_t *out_ids, float *out_scores)
+{
+    if (nq < 0 || kd < 0 || ks < 0 || limit <= 0 || kd + ks > 8192) return LB_ERR_INVALID_ARG;
+    if (nq == 0) return LB_OK;
+    if ((kd > 0 && !dense_ids) || (ks > 0 && !sparse_ids) || !out_ids || !out_scores) return LB_ERR_INVALID_ARG;
+    if (!device_ok(device)) return LB_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return LB_ERR_HIP;
+    int64_t *d_d = nullptr, *d_s = nullptr, *d_o = nullptr;
+    float *d_sc = nullptr;
+    int rc = LB_OK;
+    const size_t bd = (size_t)nq * std::max(kd, 1) * 8, bs = (size_t)nq * std::max(ks, 1) * 8;
+    if (hipMalloc(&d_d, bd) != hipSuccess || hipMalloc(&d_s, bs) != hipSuccess ||
+        hipMalloc(&d_o, (size_t)nq * limit * 8) != hipSuccess || hipMalloc(&d_sc, (size_t)nq * limit * 4) != hipSuccess) {
+        rc = LB_ERR_OOM;
+    } else {
+        if (kd > 0 && hipMemcpy(d_d, dense_ids, (size_t)nq * kd * 8, hipMemcpyHostToDevice) != hipSuccess) rc = LB_ERR_HIP;
+        if (ks > 0 && hipMemcpy(d_s, sparse_ids, (size_t)nq * ks * 8, hipMemcpyHostToDevice) != hipSuccess) rc = LB_ERR_HIP;
+        if (rc == LB_OK) rc = lb_gpu_rrf_fuse_device(device, nq, kd, d_d, ks, d_s, k, limit, d_o, d_sc, nullptr);
+        if (rc == LB_OK && (hipMemcpy(out_ids, d_o, (size_t)nq * limit * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+                            hipMemcpy(out_scores, d_sc, (size_t)nq * limit * 4, hipMemcpyDeviceToHost) != hipSuccess))
+            rc = LB_ERR_HIP;
+    }
+    if (d_d) (void)hipFree(d_d);
+    if (d_s) (void)hipFree(d_s);
+    if (d_o) (void)hipFree(d_o);
+    if (d_sc) (void)hipFree(d_sc);
+    return rc;
+}
+
 int lb_gpu_fill_uniform_device(int device, float *d_dst, int64_t n, uint64_t seed, int64_t offset, void *stream)
 {
     if (n < 0 || (n > 0 && !d_dst)) return LB_ERR_INVALID_ARG;

@@ -104,4 +104,77 @@ void launch_and_bytes(uint8_t *dst, const uint8_t *src, int64_t n, hipStream_t s
     hipLaunchKernelGGL(and_bytes_kernel, dim3(grid_for(n, 1)), dim3(256), 0, s, dst, src, n);
 }
 
+// ---------------------------------------------------------------------------
+// Reciprocal-rank fusion (SURVEY f-4): store.ReciprocalRankFusion (internal/store/rrf.go:10-51).
+// score(id) = sum over the lists containing id of 1 / float64(k + rank + 1), rank 0-based, accumulated
+// dense first then sparse in f64, narrowed to f32; output sorted by score descending (ties: lower id
+// first -- the reference's sort is unstable over a map, so any order of ties is "the reference's").
+// One workgroup per query; ids are unique within a list (search results); -1 entries are padding.
+__global__ __launch_bounds__(256) void rrf_kernel(int64_t nq, int kd, const int64_t *dense, int ks,
+                                                  const int64_t *sparse, int k, int limit, int64_t *out_ids,
+                                                  float *out_scores)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
+    const int64_t q = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int n = kd + ks;
+    uint32_t P = 2;
+    while ((int)P < n) P <<= 1;
+    int64_t *sid = reinterpret_cast<int64_t *>(rsm);         // [P] ids (dense then sparse)
+    uint32_t *skey = reinterpret_cast<uint32_t *>(sid + P);  // [P] sortable(-score): ascending == score desc
+    for (uint32_t i = tid; i < P; i += 256) {
+        int64_t id = -1;
+        if ((int)i < kd) id = dense[q * kd + i];
+        else if ((int)i < n) id = sparse[q * ks + (i - kd)];
+        sid[i] = id;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < P; i += 256) {
+        const int64_t id = sid[i];
+        uint32_t key = 0xffffffffu; // padding / consumed entries sort last
+        if (id >= 0) {
+            if ((int)i < kd) {
+                double sc = 1.0 / (double)(k + (int)i + 1);
+                for (int j = 0; j < ks; j++)
+                    if (sid[kd + j] == id) { sc += 1.0 / (double)(k + j + 1); break; }
+                key = f32_sortable(-(float)sc);
+            } else {
+                bool in_dense = false;
+                for (int j = 0; j < kd; j++)
+                    if (sid[j] == id) { in_dense = true; break; }
+                if (!in_dense) key = f32_sortable(-(float)(1.0 / (double)(k + ((int)i - kd) + 1)));
+            }
+        }
+        skey[i] = key;
+    }
+    __syncthreads();
+    // bitonic sort by (key asc, id asc as unsigned: -1 last)
+    for (uint32_t kk = 2; kk <= P; kk <<= 1)
+        for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < (P >> 1); t += 256) {
+                const uint32_t i = 2 * t - (t & (j - 1)), l = i + j;
+                const uint32_t ka = skey[i], kb = skey[l];
+                const uint64_t ia = (uint64_t)sid[i], ib = (uint64_t)sid[l];
+                const bool gt = ka > kb || (ka == kb && ia > ib);
+                if (gt == ((i & kk) == 0)) { skey[i] = kb; skey[l] = ka; sid[i] = (int64_t)ib; sid[l] = (int64_t)ia; }
+            }
+            __syncthreads();
+        }
+    for (int r = tid; r < limit; r += 256) {
+        const bool ok = (uint32_t)r < P && skey[r] != 0xffffffffu;
+        out_ids[q * limit + r] = ok ? sid[r] : -1;
+        out_scores[q * limit + r] = ok ? -sortable_f32(skey[r]) : 0.f;
+    }
+}
+
+void launch_rrf(int64_t nq, int kd, const int64_t *dense, int ks, const int64_t *sparse, int k, int limit,
+                int64_t *out_ids, float *out_scores, hipStream_t s)
+{
+    if (nq <= 0 || limit <= 0) return;
+    uint32_t P = 2;
+    while ((int)P < kd + ks) P <<= 1;
+    hipLaunchKernelGGL(rrf_kernel, dim3((unsigned)nq), dim3(256), (size_t)P * 12, s, nq, kd, dense, ks, sparse, k, limit,
+                       out_ids, out_scores);
+}
+
 } // namespace lb

@@ -145,5 +145,8 @@ void launch_match_int64(const int64_t *src, int64_t n, int64_t val, int op, cons
 void launch_match_float32(const float *src, int64_t n, float val, int op, const uint8_t *validity,
                           int64_t valid_offset, uint8_t *dst, int combine, hipStream_t s);
 void launch_and_bytes(uint8_t *dst, const uint8_t *src, int64_t n, hipStream_t s);
+// reciprocal-rank fusion of two ranked id lists per query (kernels_filter.hip)
+void launch_rrf(int64_t nq, int kd, const int64_t *dense, int ks, const int64_t *sparse, int k, int limit,
+                int64_t *out_ids, float *out_scores, hipStream_t s);
 
 } // namespace lb

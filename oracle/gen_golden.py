@@ -159,6 +159,24 @@ def main():
                   "op": "fnv", "inputs": ["", "a", "foobar"],
                   "expected": [0x811C9DC5, 0xE40C292C, 0xBF9CF968]})
 
+    # RRF literals (internal/store/hybrid_search_test.go:75-150): A=0 must rank first; expected
+    # scores by the formula in the test's own comment, evaluated in f64 and narrowed
+    d, sp = [0, 1, 2, 3], [2, 0, 4, 1]
+    sc = {}
+    for lst in (d, sp):
+        for r, i in enumerate(lst):
+            sc[i] = sc.get(i, 0.0) + 1.0 / float(60 + r + 1)
+    order = sorted(sc, key=lambda i: (-np.float32(sc[i]), i))
+    cases.append({"name": "rrf_basic_fusion", "src": "internal/store/hybrid_search_test.go:75-108",
+                  "op": "rrf", "dense": d, "sparse": sp, "k": 60, "limit": 10, "expected_ids": order,
+                  "expected_scores": [float(np.float32(sc[i])) for i in order], "expect_top": 0})
+    cases.append({"name": "rrf_one_empty", "src": "internal/store/hybrid_search_test.go:111-124",
+                  "op": "rrf", "dense": [0], "sparse": [], "k": 60, "limit": 10, "expected_ids": [0],
+                  "expected_scores": [float(np.float32(1.0 / 61.0))], "expect_top": 0})
+    cases.append({"name": "rrf_k1", "src": "internal/store/hybrid_search_test.go:126-150",
+                  "op": "rrf", "dense": [0, 1], "sparse": [1, 0], "k": 1, "limit": 10, "expected_ids": [0, 1],
+                  "expected_scores": [float(np.float32(0.5 + 1.0 / 3.0))] * 2, "expect_top": None})
+
     # pack/unpack 8 bytes <-> 2 floats (internal/store/hnsw_pq_test.go:37-70): layout only
     cases.append({"name": "pq_pack_8bytes", "src": "internal/store/hnsw_pq_test.go:61-69",
                   "op": "pack", "bytes": [1, 2, 3, 4, 250, 251, 252, 253], "n_floats": 2})

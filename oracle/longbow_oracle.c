@@ -556,6 +556,44 @@ void lbo_and_bytes(uint8_t *dst, const uint8_t *src, int64_t n)
 }
 
 /* ======================================================================
+ * Reciprocal-rank fusion (internal/store/rrf.go:10-51)
+ * ====================================================================== */
+typedef struct { int64_t id; double s; float f; } rrf_item;
+static int rrf_cmp(const void *pa, const void *pb)
+{
+    const rrf_item *a = (const rrf_item *)pa, *b = (const rrf_item *)pb;
+    if (a->f > b->f) return -1;
+    if (a->f < b->f) return 1;
+    return (a->id > b->id) - (a->id < b->id);
+}
+
+int lbo_rrf(const int64_t *dense, int nd, const int64_t *sparse, int ns, int k, int limit,
+            int64_t *out_ids, float *out_scores)
+{
+    if (k <= 0) k = 60;
+    rrf_item *it = (rrf_item *)malloc(sizeof(rrf_item) * (size_t)(nd + ns + 1));
+    int n = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        const int64_t *l = pass == 0 ? dense : sparse;
+        const int len = pass == 0 ? nd : ns;
+        for (int rank = 0; rank < len; rank++) {
+            if (l[rank] < 0) continue;
+            int j = 0;
+            for (; j < n; j++)
+                if (it[j].id == l[rank]) break;
+            if (j == n) { it[n].id = l[rank]; it[n].s = 0.0; n++; }
+            it[j].s += 1.0 / (double)(k + rank + 1);
+        }
+    }
+    for (int j = 0; j < n; j++) it[j].f = (float)it[j].s;
+    qsort(it, (size_t)n, sizeof(rrf_item), rrf_cmp);
+    int cnt = (limit > 0 && n > limit) ? limit : n;
+    for (int j = 0; j < cnt; j++) { out_ids[j] = it[j].id; out_scores[j] = it[j].f; }
+    free(it);
+    return cnt;
+}
+
+/* ======================================================================
  * Synthetic data (shared definition with lb_gpu_fill_uniform)
  * ====================================================================== */
 static inline uint64_t splitmix64_at(uint64_t seed, uint64_t idx)

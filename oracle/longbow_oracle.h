@@ -130,6 +130,13 @@ void lbo_match_int64(const int64_t *src, int64_t n, int64_t val, int op, uint8_t
 void lbo_match_float32(const float *src, int64_t n, float val, int op, uint8_t *dst);
 void lbo_and_bytes(uint8_t *dst, const uint8_t *src, int64_t n);
 
+/* ---- hybrid fusion ------------------------------------------------------------- */
+/* store.ReciprocalRankFusion (internal/store/rrf.go:10-51): f64 accumulation dense then sparse,
+ * Score = float32(sum); sorted by score descending (canonical tie order: lower id first).
+ * ids < 0 are padding.  Returns the number of fused results written (<= limit if limit > 0). */
+int lbo_rrf(const int64_t *dense, int nd, const int64_t *sparse, int ns, int k, int limit,
+            int64_t *out_ids, float *out_scores);
+
 /* ---- synthetic data ------------------------------------------------------ */
 /* Counter-based uniform [0,1) f32 generator shared bit-for-bit with the HIP
  * library (lb_gpu_fill_uniform): value(idx) = (splitmix64(seed ^ mix(idx)) >> 40) * 2^-24.

@@ -84,6 +84,8 @@ def lib():
         L.lbo_match_float32.argtypes = [_f32p, C.c_int64, C.c_float, C.c_int, _u8p]
         L.lbo_and_bytes.restype = None
         L.lbo_and_bytes.argtypes = [_u8p, _u8p, C.c_int64]
+        L.lbo_rrf.restype = C.c_int
+        L.lbo_rrf.argtypes = [_i64p, C.c_int, _i64p, C.c_int, C.c_int, C.c_int, _i64p, _f32p]
         L.lbo_fill_uniform.restype = None
         L.lbo_fill_uniform.argtypes = [_f32p, C.c_int64, C.c_uint64, C.c_int64]
         L.lbo_fill_codes.restype = None
@@ -255,6 +257,17 @@ def and_bytes(dst, src):
     src = np.ascontiguousarray(src, np.uint8)
     lib().lbo_and_bytes(dst, src, dst.size)
     return dst
+
+
+def rrf(dense_ids, sparse_ids, k=60, limit=0):
+    d = np.ascontiguousarray(dense_ids, np.int64)
+    s_ = np.ascontiguousarray(sparse_ids, np.int64)
+    cap = max(d.size + s_.size, 1)
+    oi = np.empty(cap, np.int64)
+    os_ = np.empty(cap, np.float32)
+    cnt = lib().lbo_rrf(d if d.size else np.zeros(1, np.int64), d.size, s_ if s_.size else np.zeros(1, np.int64), s_.size,
+                        k, limit, oi, os_)
+    return oi[:cnt].copy(), os_[:cnt].copy()
 
 
 def fill_uniform(n, seed, offset=0):

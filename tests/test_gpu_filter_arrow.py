@@ -174,3 +174,42 @@ def test_arrow_upcast_and_missing_id_column(oracle):
     with pytest.raises(arrow_io.ExchangeError):
         ds.add_record_batch(pa.record_batch([pa.array([1, 2, 3])], names=["embedding"]))  # no "vector" column
     ds.close()
+
+
+def test_rrf_fusion_on_gpu(oracle, golden):
+    """store.ReciprocalRankFusion (hybrid_search_test.go:75-150) + batched fusion vs the oracle"""
+    gpu_or_skip()
+    from longbow_amd import hybrid
+    for c in golden:
+        if c["op"] != "rrf":
+            continue
+        ids, sc = hybrid.ReciprocalRankFusion(c["dense"], c["sparse"], c["k"], c["limit"])
+        assert list(ids) == c["expected_ids"], c["name"]
+        assert np.array_equal(sc, np.array(c["expected_scores"], F)), c["name"]
+    assert len(hybrid.ReciprocalRankFusion(None, None, 60, 10)[0]) == 0
+    rng = np.random.default_rng(9)
+    nq, kd, ks, lim = 50, 200, 150, 100          # dense side asks for k*2 (hybrid_search.go:62)
+    dense = np.stack([rng.permutation(1000)[:kd] for _ in range(nq)]).astype(np.int64)
+    sparse = np.stack([rng.permutation(1000)[:ks] for _ in range(nq)]).astype(np.int64)
+    sparse[3, 100:] = -1                          # ragged sparse list (padding)
+    oi, os_ = hybrid.fuse_batch(dense, sparse, 60, lim)
+    for q in range(nq):
+        ei, es = oracle.rrf(dense[q], sparse[q], 60, lim)
+        assert np.array_equal(oi[q, :len(ei)], ei) and np.array_equal(os_[q, :len(es)], es), q
+
+
+def test_hybrid_candidate_handoff(oracle):
+    """ArrowHNSW.SearchHybrid's GPU hand-off: min(10k, Len) candidates, first k live (hnsw_gpu.go:84-123)"""
+    gpu_or_skip()
+    from longbow_amd import hybrid
+    rng = np.random.default_rng(10)
+    X = rng.random((500, 32), dtype=F)
+    idx = new_index(32, 0)
+    idx.Add(None, X)
+    q = rng.random(32, dtype=F)
+    dead = set(range(0, 500, 3))                 # tombstones
+    ids, dist = hybrid.search_hybrid_candidates(idx, q, 10, is_live=lambda i: i not in dead)
+    oi, od = oracle.search_batch(0, q[None], X, 100)
+    exp = [i for i in oi[0] if i not in dead][:10]
+    assert list(ids) == exp
+    idx.Close()

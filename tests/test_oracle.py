@@ -293,3 +293,20 @@ def test_match_and_and_bytes(oracle):
     assert list(oracle.match_float32(f, 0.5, 1)) == [0, 1, 1]   # NaN != x is true (Go / IEEE)
     assert list(oracle.match_float32(f, 0.5, 3)) == [1, 0, 1]
     assert list(oracle.and_bytes(np.array([1, 1, 0], np.uint8), np.array([1, 0, 1], np.uint8))) == [1, 0, 0]
+
+
+def test_golden_rrf(oracle, golden):
+    n = 0
+    for c in golden:
+        if c["op"] != "rrf":
+            continue
+        ids, sc = oracle.rrf(c["dense"], c["sparse"], c["k"], c["limit"])
+        assert list(ids) == c["expected_ids"], c["name"]
+        assert np.array_equal(sc, np.array(c["expected_scores"], F)), c["name"]
+        if c["expect_top"] is not None:
+            assert ids[0] == c["expect_top"]
+        n += 1
+    assert n == 3
+    assert len(oracle.rrf([], [], 60, 10)[0]) == 0            # both empty -> nil
+    ids, sc = oracle.rrf([5, 6, 7], [7, 8], 0, 2)             # k <= 0 -> 60; limit
+    assert len(ids) == 2 and ids[0] == 7
