@@ -126,6 +126,12 @@ struct lb_gpu_index {
     bool has_ids = false;
     uint8_t *d_mask = nullptr;
     bool has_mask = false;
+    // ascending list of the rows the mask leaves visible (rebuilt whenever the mask or the corpus
+    // changes); searches walk it instead of the corpus when the filter is selective enough
+    uint32_t *d_rowmap = nullptr, *d_cscratch = nullptr;
+    int64_t rowmap_cap = 0, cscratch_words = 0;
+    int64_t n_visible = 0;
+    bool rowmap_on = false;
     // optional split-bf16 image of the corpus for the 3x-bf16 candidate contraction (same byte shape as d_X)
     std::atomic<int> cand_mode{0};
     float *d_Xs = nullptr;
@@ -237,14 +243,29 @@ struct ProfScope {
     }
 };
 
+// What a search walks: all corpus rows (optionally testing the mask per row), or the compacted
+// list of visible rows (rebuild_rowmap decides).
+struct RowView {
+    const uint8_t *mask;
+    const uint32_t *rowmap;
+    int64_t n;
+};
+static RowView row_view(const lb_gpu_index *h)
+{
+    if (!h->has_mask) return {nullptr, nullptr, h->n};
+    if (h->rowmap_on) return {nullptr, h->d_rowmap, h->n_visible};
+    return {h->d_mask, nullptr, h->n};
+}
+
 // Exact scan of all rows for the query slots sel[0..nsel) (indices into d_q rows).
 // safe=false: 3 chunks (bootstrap / 64k / rest); safe=true: chunks that cannot overflow.
 void run_scan_path(lb_gpu_index *h, Workspace *w, hipStream_t s, const float *d_q, const int *d_sel,
                    int nsel, int k, bool safe, float *d_dist, int64_t *d_lab, bool prof)
 {
     const int metric = h->metric, order = h->order.load();
-    const int64_t n = h->n;
-    const uint8_t *mask = h->has_mask ? h->d_mask : nullptr;
+    const RowView rv = row_view(h);
+    const int64_t n = rv.n;
+    const uint8_t *mask = rv.mask;
     const int kkeep = std::max(k, 1);
     launch_init_cand(w->cs, d_sel, nsel, s);
     for (int g0 = 0; g0 < nsel; g0 += kScanMaxQ) {
@@ -262,7 +283,7 @@ void run_scan_path(lb_gpu_index *h, Workspace *w, hipStream_t s, const float *d_
             {
                 ProfScope p(w, s, prof, 3);
                 launch_scan(metric, order, false, h->d_X, pos, end, h->dim, d_q, use_sel, gn, w->d_qna,
-                            mask, w->cs, boot, nullptr, 0, s);
+                            mask, rv.rowmap, w->cs, boot, nullptr, 0, s);
             }
             {
                 ProfScope p(w, s, prof, 1);
@@ -316,8 +337,9 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
                         float *d_dist, int64_t *d_lab, int kc, bool prof, int64_t &fallbacks)
 {
     const int metric = h->metric, order = h->order.load();
-    const int64_t n = h->n;
-    const uint8_t *mask = h->has_mask ? h->d_mask : nullptr;
+    const RowView rv = row_view(h);
+    const int64_t n = rv.n; // positions to walk: corpus rows, or the visible-row list under a selective filter
+    const uint8_t *mask = rv.mask;
     ProfScope whole(w, s, prof, 4);
 
     // Path selection (measured at 1M x 768 on MI355X, tools/bench_sweep.py): <= 4 queries exact scan
@@ -337,7 +359,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     launch_init_cand(w->cs, nullptr, nq, s);
     if (metric == LB_METRIC_COSINE) launch_query_norms(order, d_q, nullptr, nq, h->dim, w->d_qna, s);
     // candidate contraction: exact f32 MFMA, or 3 x bf16 MFMA on the split images
-    const bool split = h->cand_mode.load() == 1 && h->d_Xs != nullptr && h->xs_rows == n && h->dim % 32 == 0;
+    const bool split = h->cand_mode.load() == 1 && h->d_Xs != nullptr && h->xs_rows == h->n && h->dim % 32 == 0;
     const float *gx = h->d_X, *gq = d_q;
     const float u24 = 5.9604645e-8f;
     float gamma = 1.05f * (float)(h->dim + 8) * u24; // k-ordered f32 fma chain of length D
@@ -365,10 +387,10 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
             ProfScope p(w, s, prof, 0);
             if (!split && narrow_ok && nq <= narrow_max)
                 launch_gemm_filter_narrow(metric, gx, h->d_norm2, h->d_rnorm, pos, end, h->dim, gq, nq, mask,
-                                          w->cs, boot, s);
+                                          rv.rowmap, w->cs, boot, s);
             else
                 launch_gemm_filter(metric, gx, h->d_norm2, h->d_rnorm, pos, end, h->dim, gq, nq, mask,
-                                   w->cs, boot, split, s);
+                                   rv.rowmap, w->cs, boot, split, s);
         }
         {
             ProfScope p(w, s, prof, 1);
@@ -457,6 +479,42 @@ int grow(lb_gpu_index *h, int64_t need)
 
 void sync_split_image(lb_gpu_index *h);
 
+// Recompute the visible-row list from d_mask (caller holds the exclusive lock).  The list is used
+// by searches when at most LB_ROWMAP_MAX_PCT % of the corpus is visible (default 95; measured on
+// 1.25M x 1536: time scales with the visible fraction all the way up -- 8.6 ms unfiltered, 7.8 ms at
+// 90 %, 4.5 ms at 50 %, 1.16 ms at 10 % for 256 queries -- so only near-total masks keep the per-row test).
+void rebuild_rowmap(lb_gpu_index *h)
+{
+    h->rowmap_on = false;
+    h->n_visible = h->n;
+    if (!h->has_mask || h->n == 0) return;
+    static const int max_pct = [] { const char *e = getenv("LB_ROWMAP_MAX_PCT"); return e ? atoi(e) : 95; }();
+    if (max_pct <= 0) return;
+    hipStream_t s = h->add_stream;
+    if (h->rowmap_cap < h->n) {
+        if (h->d_rowmap) (void)hipFree(h->d_rowmap);
+        h->d_rowmap = nullptr;
+        h->rowmap_cap = 0;
+        LB_HIP(hipMalloc(&h->d_rowmap, (size_t)h->capacity * sizeof(uint32_t)));
+        h->rowmap_cap = h->capacity;
+    }
+    const int64_t words = compact_scratch_words(h->n);
+    if (h->cscratch_words < words) {
+        if (h->d_cscratch) (void)hipFree(h->d_cscratch);
+        h->d_cscratch = nullptr;
+        h->cscratch_words = 0;
+        const int64_t cap_words = compact_scratch_words(h->capacity);
+        LB_HIP(hipMalloc(&h->d_cscratch, (size_t)cap_words * sizeof(uint32_t)));
+        h->cscratch_words = cap_words;
+    }
+    launch_compact_mask(h->d_mask, h->n, h->d_rowmap, h->d_cscratch, s);
+    uint32_t total = 0;
+    LB_HIP(hipMemcpyAsync(&total, h->d_cscratch + (words - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    LB_HIP(hipStreamSynchronize(s));
+    h->n_visible = (int64_t)total;
+    h->rowmap_on = h->n_visible * 100 <= h->n * (int64_t)max_pct;
+}
+
 __global__ void iota_ids_kernel(int64_t *ids, int64_t start, int64_t n)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -484,6 +542,7 @@ void finish_add(lb_gpu_index *h, int64_t n, const int64_t *ids_src, bool ids_on_
     LB_HIP(hipStreamSynchronize(s));
     h->n += n;
     sync_split_image(h);
+    rebuild_rowmap(h); // appended rows are visible; keep the list in step with the corpus
 }
 
 // bring the split-bf16 mirror up to date with d_X (no-op unless the mode is enabled)
@@ -524,7 +583,7 @@ static int filter_column(lb_gpu_index *h, const T *column, int64_t n, T value, i
         h->set_error("filter column has %lld values, index has %lld rows", (long long)n, (long long)h->n);
         return LB_ERR_INVALID_ARG;
     }
-    if (n == 0) { h->has_mask = true; return LB_OK; }
+    if (n == 0) { h->has_mask = true; h->rowmap_on = false; return LB_OK; }
     T *d_col = nullptr;
     uint8_t *d_val = nullptr;
     int rc = LB_OK;
@@ -544,6 +603,7 @@ static int filter_column(lb_gpu_index *h, const T *column, int64_t n, T value, i
             launch_match_float32(reinterpret_cast<const float *>(d_col), n, (float)value, op, d_val, voff, h->d_mask, comb, h->add_stream);
         LB_HIP(hipStreamSynchronize(h->add_stream));
         h->has_mask = true;
+        rebuild_rowmap(h);
     } catch (const HipErr &e) {
         rc = fail_hip(h, e);
     }
@@ -645,6 +705,8 @@ void lb_gpu_index_free(lb_gpu_index *h)
         if (h->d_rnorm) (void)hipFree(h->d_rnorm);
         if (h->d_ids) (void)hipFree(h->d_ids);
         if (h->d_mask) (void)hipFree(h->d_mask);
+        if (h->d_rowmap) (void)hipFree(h->d_rowmap);
+        if (h->d_cscratch) (void)hipFree(h->d_cscratch);
         if (h->d_maxnorm2) (void)hipFree(h->d_maxnorm2);
         if (h->d_Xs) (void)hipFree(h->d_Xs);
         for (int i = 0; i < 2; i++) {
@@ -769,12 +831,13 @@ int lb_gpu_index_set_filter(lb_gpu_index *h, const uint8_t *mask, int64_t n)
     if (!h) return LB_ERR_INVALID_ARG;
     std::unique_lock<std::shared_mutex> g(h->mu);
     if (h->closed) return LB_ERR_CLOSED;
-    if (!mask) { h->has_mask = false; return LB_OK; }
+    if (!mask) { h->has_mask = false; h->rowmap_on = false; return LB_OK; }
     if (n != h->n) { h->set_error("filter mask has %lld bytes, index has %lld rows", (long long)n, (long long)h->n); return LB_ERR_INVALID_ARG; }
     try {
         LB_HIP(hipSetDevice(h->device));
         if (n > 0) LB_HIP(hipMemcpy(h->d_mask, mask, (size_t)n, hipMemcpyHostToDevice));
         h->has_mask = true;
+        rebuild_rowmap(h);
     } catch (const HipErr &e) {
         return fail_hip(h, e);
     }
@@ -960,7 +1023,7 @@ int lb_simd_distance_batch_flat_device(int device, int metric, int order, const 
         launch_query_norms(order, d_query, nullptr, 1, dims, d_qna, s);
     }
     CandState cs{};
-    launch_scan(metric, order, /*raw_dot=*/true, d_flat, 0, n, dims, d_query, nullptr, 1, d_qna, nullptr, cs,
+    launch_scan(metric, order, /*raw_dot=*/true, d_flat, 0, n, dims, d_query, nullptr, 1, d_qna, nullptr, nullptr, cs,
                 false, d_results, n, s);
     hipError_t e = hipStreamSynchronize(s);
     if (d_qna) (void)hipFree(d_qna);

@@ -74,6 +74,112 @@ __global__ __launch_bounds__(256) void and_bytes_kernel(uint8_t *dst, const uint
         dst[i] &= src[i];
 }
 
+// ---- ordered stream compaction of the predicate mask --------------------------------------------
+// A selective filter (BASELINE config 5: 10 % of the rows pass) should not pay distance work for
+// the rows it hides.  These three kernels turn the byte mask into the ascending list of visible
+// corpus rows; the search kernels then walk *positions* of that list and fetch rows through it,
+// so hidden rows cost neither HBM reads nor MFMA/VALU work.  Ascending order keeps the canonical
+// (distance, row) tie-break unchanged.  Replaces the per-row `if bitmap.Contains(id)` test of
+// internal/store/adaptive_index.go:180-186 / the mask walk of filter_evaluator.go:79-115.
+constexpr int CP_THREADS = 256;
+constexpr int CP_PER = 8; // mask bytes per thread
+constexpr int CP_ROWS = CP_THREADS * CP_PER;
+
+__device__ __forceinline__ uint32_t cp_load8(const uint8_t *mask, int64_t n, int64_t base)
+{
+    // bit i set <=> mask[base + i] != 0 (bytes past n read as 0)
+    uint32_t bits = 0;
+    if (base + CP_PER <= n) {
+        const uint64_t v = *reinterpret_cast<const uint64_t *>(mask + base); // base % 8 == 0, mask is 256-B aligned
+#pragma unroll
+        for (int i = 0; i < CP_PER; i++) bits |= ((v >> (8 * i)) & 0xffull) ? (1u << i) : 0u;
+    } else {
+        for (int i = 0; i < CP_PER; i++)
+            if (base + i < n && mask[base + i]) bits |= 1u << i;
+    }
+    return bits;
+}
+
+// inclusive scan of one value per thread over the 256-thread block; returns this thread's inclusive sum
+__device__ __forceinline__ uint32_t cp_block_scan(uint32_t v, uint32_t *s_wave /*[4]*/, uint32_t &block_total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) s_wave[wave] = x;
+    __syncthreads();
+    uint32_t before = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < CP_THREADS / 64; w++) {
+        const uint32_t t = s_wave[w];
+        if (w < wave) before += t;
+        tot += t;
+    }
+    block_total = tot;
+    return x + before;
+}
+
+__global__ __launch_bounds__(CP_THREADS) void compact_count_kernel(const uint8_t *mask, int64_t n, uint32_t *block_counts)
+{
+    __shared__ uint32_t s_wave[CP_THREADS / 64];
+    const int64_t base = ((int64_t)blockIdx.x * CP_THREADS + threadIdx.x) * CP_PER;
+    const uint32_t c = base < n ? (uint32_t)__popc(cp_load8(mask, n, base)) : 0u;
+    uint32_t tot;
+    (void)cp_block_scan(c, s_wave, tot);
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = tot;
+}
+
+// exclusive scan of the per-block counts in place (one workgroup; nb is a few hundred to a few
+// hundred thousand), total to block_counts[nb]
+__global__ __launch_bounds__(CP_THREADS) void compact_offsets_kernel(uint32_t *block_counts, int64_t nb)
+{
+    __shared__ uint32_t s_wave[CP_THREADS / 64];
+    uint32_t running = 0;
+    for (int64_t b0 = 0; b0 < nb; b0 += CP_THREADS) {
+        const int64_t i = b0 + threadIdx.x;
+        const uint32_t v = i < nb ? block_counts[i] : 0u;
+        uint32_t tot;
+        const uint32_t inc = cp_block_scan(v, s_wave, tot);
+        if (i < nb) block_counts[i] = running + inc - v;
+        running += tot;
+        __syncthreads(); // s_wave is rewritten by the next round
+    }
+    if (threadIdx.x == 0) block_counts[nb] = running;
+}
+
+__global__ __launch_bounds__(CP_THREADS) void compact_scatter_kernel(const uint8_t *mask, int64_t n,
+                                                                    const uint32_t *block_offsets, uint32_t *rowmap)
+{
+    __shared__ uint32_t s_wave[CP_THREADS / 64];
+    const int64_t base = ((int64_t)blockIdx.x * CP_THREADS + threadIdx.x) * CP_PER;
+    const uint32_t bits = base < n ? cp_load8(mask, n, base) : 0u;
+    const uint32_t c = (uint32_t)__popc(bits);
+    uint32_t tot;
+    const uint32_t inc = cp_block_scan(c, s_wave, tot);
+    uint32_t at = block_offsets[blockIdx.x] + inc - c;
+#pragma unroll
+    for (int i = 0; i < CP_PER; i++)
+        if (bits & (1u << i)) rowmap[at++] = (uint32_t)(base + i);
+}
+
+int64_t compact_scratch_words(int64_t n) { return (n + CP_ROWS - 1) / CP_ROWS + 1; }
+
+void launch_compact_mask(const uint8_t *mask, int64_t n, uint32_t *rowmap, uint32_t *scratch, hipStream_t s)
+{
+    const int64_t nb = (n + CP_ROWS - 1) / CP_ROWS;
+    if (nb <= 0) {
+        (void)hipMemsetAsync(scratch, 0, sizeof(uint32_t), s);
+        return;
+    }
+    hipLaunchKernelGGL(compact_count_kernel, dim3((unsigned)nb), dim3(CP_THREADS), 0, s, mask, n, scratch);
+    hipLaunchKernelGGL(compact_offsets_kernel, dim3(1), dim3(CP_THREADS), 0, s, scratch, nb);
+    hipLaunchKernelGGL(compact_scatter_kernel, dim3((unsigned)nb), dim3(CP_THREADS), 0, s, mask, n, scratch, rowmap);
+}
+
 static unsigned grid_for(int64_t n, int per_thread)
 {
     int64_t blocks = (n + 256 * per_thread - 1) / (256 * per_thread);

@@ -38,6 +38,7 @@ struct GemmArgs {
     const float *Q;
     int nq;
     const uint8_t *mask;
+    const uint32_t *rowmap; // filtered search over a compacted row list: position -> corpus row (or null)
     CandState cs;
     int n_row_tiles, n_q_tiles;
     int boot; // bootstrap chunk: store every row at list[row - row_begin], no test, no atomics
@@ -98,10 +99,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_filter_kernel(GemmArgs a
 
     // one LDS object: [stage][A|B][BM*BK] f32 tiles, then the tile's per-row side inputs
     // (norm / 1/norm and the predicate byte), fetched once at kernel entry
-    __shared__ __attribute__((aligned(16))) float lds_all[2 * 2 * BM * BK + BM + BM / 4];
+    __shared__ __attribute__((aligned(16))) float lds_all[2 * 2 * BM * BK + BM + BM + BM / 4];
     float(*lds)[2][BM * BK] = reinterpret_cast<float(*)[2][BM * BK]>(lds_all);
     float *s_aux = lds_all + 2 * 2 * BM * BK;
-    uint8_t *s_vis = reinterpret_cast<uint8_t *>(s_aux + BM);
+    uint32_t *s_rowid = reinterpret_cast<uint32_t *>(s_aux + BM); // corpus row of each tile row
+    uint8_t *s_vis = reinterpret_cast<uint8_t *>(s_rowid + BM);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -114,12 +116,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_filter_kernel(GemmArgs a
     const int64_t last_row = a.row_end - 1;
     const int last_q = a.nq - 1;
 
+    auto corpus_row = [&](int64_t pos) -> int64_t { // positions index the (possibly compacted) row list
+        if (pos > last_row) pos = last_row;
+        return a.rowmap ? (int64_t)a.rowmap[pos] : pos;
+    };
     if (tid < BM) {
-        int64_t ri = row0 + tid;
-        if (ri > last_row) ri = last_row;
+        const int64_t ri = corpus_row(row0 + tid);
         s_aux[tid] = METRIC == METRIC_L2 ? a.norm2[ri] : (METRIC == METRIC_COS ? a.rnorm[ri] : 0.f);
         const bool in_range = row0 + tid <= last_row;
         s_vis[tid] = (in_range && (!a.mask || a.mask[ri])) ? (uint8_t)1 : (uint8_t)0;
+        s_rowid[tid] = (uint32_t)ri;
     }
     // admission thresholds of this lane's two queries, split into (key, row)
     float tau_key[2];
@@ -141,8 +147,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_filter_kernel(GemmArgs a
         int c = tid + GEMM_THREADS * i;
         st_row[i] = c >> 3;
         st_ch[i] = c & 7;
-        int64_t xr = row0 + st_row[i];
-        st_xrow[i] = xr < last_row ? xr : last_row;
+        st_xrow[i] = corpus_row(row0 + st_row[i]);
         int qr = q0 + st_row[i];
         st_qrow[i] = qr < last_q ? qr : last_q;
     }
@@ -168,8 +173,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_filter_kernel(GemmArgs a
             const int j = wave * 4 + i;
             const int row = j * 8 + (lane >> 3);
             const int c = (lane & 7) ^ ((row >> 1) & 7);
-            int64_t xr = row0 + row;
-            if (xr > last_row) xr = last_row;
+            const int64_t xr = corpus_row(row0 + row);
             int qr = q0 + row;
             if (qr > last_q) qr = last_q;
             gsrcA[i] = a.X + xr * (int64_t)a.D + 4 * c;
@@ -329,6 +333,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_filter_kernel(GemmArgs a
         return;
     }
     float aux[2][4][4];
+    uint32_t rid[2][4][4]; // corpus row ids of this lane's 32 rows
     uint32_t vbits = 0; // bit (tm*16 + g*4 + e): row visible (in range and not masked out)
 #pragma unroll
     for (int tm = 0; tm < 2; tm++)
@@ -336,6 +341,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_filter_kernel(GemmArgs a
         for (int g = 0; g < 4; g++) {
             const int lr = wr * 64 + tm * 32 + 8 * g + 4 * h; // 4 consecutive local rows
             const f32x4 av = *reinterpret_cast<const f32x4 *>(&s_aux[lr]);
+            const uint4 rv = *reinterpret_cast<const uint4 *>(&s_rowid[lr]);
+            rid[tm][g][0] = rv.x; rid[tm][g][1] = rv.y; rid[tm][g][2] = rv.z; rid[tm][g][3] = rv.w;
             const uint32_t vv = *reinterpret_cast<const uint32_t *>(&s_vis[lr]); // 4 bytes of 0/1
             aux[tm][g][0] = av.x; aux[tm][g][1] = av.y; aux[tm][g][2] = av.z; aux[tm][g][3] = av.w;
             // gather the four 0/1 bytes into 4 adjacent bits
@@ -347,7 +354,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_filter_kernel(GemmArgs a
         if (METRIC == METRIC_COS) return -dot * ax;
         return -dot;
     };
-    const uint32_t rloc0 = (uint32_t)(row0 + wr * 64 + 4 * h); // lane's first row (fits u32: N < 2^32)
 #pragma unroll
     for (int tn = 0; tn < 2; tn++) {
         const int qj = q0 + wc * 64 + tn * 32 + l31;
@@ -366,7 +372,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_filter_kernel(GemmArgs a
 #pragma unroll
                         for (int e = 0; e < 4; e++)
                             ent[e] = ((vbits >> (tm * 16 + g * 4 + e)) & 1u)
-                                         ? pack_entry(key_of(acc[tm][tn][4 * g + e], aux[tm][g][e]), (uint32_t)(rbase + e))
+                                         ? pack_entry(key_of(acc[tm][tn][4 * g + e], aux[tm][g][e]), rid[tm][g][e])
                                          : kEntryMax;
                         uint64_t *dst = list + (rbase - a.row_begin);
                         if (rbase + 3 < a.row_end) {
@@ -397,7 +403,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_filter_kernel(GemmArgs a
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const float key = key_of(acc[tm][tn][4 * g + e], aux[tm][g][e]);
-                    const uint32_t ri = rloc0 + (uint32_t)(tm * 32 + 8 * g + e);
+                    const uint32_t ri = rid[tm][g][e];
                     const uint32_t lt = (uint32_t)(key < tk) | ((uint32_t)(key == tk) & (uint32_t)(ri < tr));
                     bits |= lt << (tm * 16 + g * 4 + e);
                 }
@@ -413,7 +419,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_filter_kernel(GemmArgs a
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
                         if (bits & (1u << (tm * 16 + g * 4 + e))) {
-                            const uint32_t ri = rloc0 + (uint32_t)(tm * 32 + 8 * g + e);
+                            const uint32_t ri = rid[tm][g][e];
                             if (pos < a.cs.cap)
                                 list[pos] = pack_entry(key_of(acc[tm][tn][4 * g + e], aux[tm][g][e]), ri);
                             pos++;
@@ -481,10 +487,12 @@ int g_gemm_ablation = 0; // profiling aid (tools/ablate_gemm.py); never set by t
 
 void launch_gemm_filter(int metric, const float *X, const float *norm2, const float *rnorm,
                         int64_t row_begin, int64_t row_end, int D, const float *Q, int nq,
-                        const uint8_t *mask, CandState cs, bool boot, bool split, hipStream_t s)
+                        const uint8_t *mask, const uint32_t *rowmap, CandState cs, bool boot, bool split,
+                        hipStream_t s)
 {
     if (row_end <= row_begin || nq <= 0) return;
     GemmArgs a;
+    a.rowmap = rowmap;
     a.boot = boot ? 1 : 0;
     a.X = X; a.norm2 = norm2; a.rnorm = rnorm;
     a.row_begin = row_begin; a.row_end = row_end; a.D = D;

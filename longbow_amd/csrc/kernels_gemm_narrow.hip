@@ -31,6 +31,7 @@ struct NarrowArgs {
     const float *Q;
     int nq;
     const uint8_t *mask;
+    const uint32_t *rowmap; // position -> corpus row for filtered search over a compacted list (or null)
     CandState cs;
     int n_row_tiles, n_q_tiles;
     int boot;
@@ -49,9 +50,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
     if (rt >= a.n_row_tiles) return;
 
     constexpr int STAGE_F = (NBM + NBN) * NBK;
-    __shared__ __attribute__((aligned(16))) float lds_all[2 * STAGE_F + NBM + NBM / 4];
+    __shared__ __attribute__((aligned(16))) float lds_all[2 * STAGE_F + NBM + NBM + NBM / 4];
     float *s_aux = lds_all + 2 * STAGE_F;
-    uint8_t *s_vis = reinterpret_cast<uint8_t *>(s_aux + NBM);
+    uint32_t *s_rowid = reinterpret_cast<uint32_t *>(s_aux + NBM);
+    uint8_t *s_vis = reinterpret_cast<uint8_t *>(s_rowid + NBM);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -62,12 +64,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
     const int64_t last_row = a.row_end - 1;
     const int last_q = a.nq - 1;
 
+    auto corpus_row = [&](int64_t pos) -> int64_t {
+        if (pos > last_row) pos = last_row;
+        return a.rowmap ? (int64_t)a.rowmap[pos] : pos;
+    };
     {
-        int64_t ri = row0 + tid;
-        const bool in_range = ri <= last_row;
-        if (!in_range) ri = last_row;
+        const bool in_range = row0 + tid <= last_row;
+        const int64_t ri = corpus_row(row0 + tid);
         s_aux[tid] = METRIC == METRIC_L2 ? a.norm2[ri] : (METRIC == METRIC_COS ? a.rnorm[ri] : 0.f);
         s_vis[tid] = (in_range && (!a.mask || a.mask[ri])) ? (uint8_t)1 : (uint8_t)0;
+        s_rowid[tid] = (uint32_t)ri;
     }
     const int qj = q0 + l31;
     const bool qok = qj < a.nq;
@@ -82,9 +88,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
     for (int i = 0; i < 8; i++) {
         const int row = wave * 64 + i * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((row >> 1) & 7);
-        int64_t xr = row0 + row;
-        if (xr > last_row) xr = last_row;
-        srcA[i] = a.X + xr * (int64_t)a.D + 4 * c;
+        srcA[i] = a.X + corpus_row(row0 + row) * (int64_t)a.D + 4 * c;
     }
     const float *srcB;
     {
@@ -145,6 +149,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
 
     // ---- epilogue (as in gemm_filter_kernel) -------------------------------------------------
     float aux[2][4][4];
+    uint32_t rid[2][4][4];
     uint32_t vbits = 0;
 #pragma unroll
     for (int tm = 0; tm < 2; tm++)
@@ -152,6 +157,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
         for (int g = 0; g < 4; g++) {
             const int lr = wave * 64 + tm * 32 + 8 * g + 4 * h;
             const f32x4 av = *reinterpret_cast<const f32x4 *>(&s_aux[lr]);
+            const uint4 rv = *reinterpret_cast<const uint4 *>(&s_rowid[lr]);
+            rid[tm][g][0] = rv.x; rid[tm][g][1] = rv.y; rid[tm][g][2] = rv.z; rid[tm][g][3] = rv.w;
             const uint32_t vv = *reinterpret_cast<const uint32_t *>(&s_vis[lr]);
             aux[tm][g][0] = av.x; aux[tm][g][1] = av.y; aux[tm][g][2] = av.z; aux[tm][g][3] = av.w;
             const uint32_t nib = (vv & 1u) | ((vv >> 7) & 2u) | ((vv >> 14) & 4u) | ((vv >> 21) & 8u);
@@ -175,13 +182,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
                         if (rbase + e < a.row_end)
                             list[rbase + e - a.row_begin] =
                                 ((vbits >> (tm * 16 + g * 4 + e)) & 1u)
-                                    ? pack_entry(key_of(acc[tm][4 * g + e], aux[tm][g][e]), (uint32_t)(rbase + e))
+                                    ? pack_entry(key_of(acc[tm][4 * g + e], aux[tm][g][e]), rid[tm][g][e])
                                     : kEntryMax;
                 }
         }
         return;
     }
-    const uint32_t rloc0 = (uint32_t)(row0 + wave * 64 + 4 * h);
     uint32_t bits = 0;
 #pragma unroll
     for (int tm = 0; tm < 2; tm++)
@@ -190,7 +196,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const float key = key_of(acc[tm][4 * g + e], aux[tm][g][e]);
-                const uint32_t ri = rloc0 + (uint32_t)(tm * 32 + 8 * g + e);
+                const uint32_t ri = rid[tm][g][e];
                 const uint32_t lt = (uint32_t)(key < tk) | ((uint32_t)(key == tk) & (uint32_t)(ri < tr));
                 bits |= lt << (tm * 16 + g * 4 + e);
             }
@@ -204,7 +210,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
 #pragma unroll
                 for (int e = 0; e < 4; e++)
                     if (bits & (1u << (tm * 16 + g * 4 + e))) {
-                        const uint32_t ri = rloc0 + (uint32_t)(tm * 32 + 8 * g + e);
+                        const uint32_t ri = rid[tm][g][e];
                         if (pos < a.cs.cap) list[pos] = pack_entry(key_of(acc[tm][4 * g + e], aux[tm][g][e]), ri);
                         pos++;
                     }
@@ -214,10 +220,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
 // Requires D % 32 == 0 and 16-B aligned X / Q (the caller checks; otherwise the wide kernel runs).
 void launch_gemm_filter_narrow(int metric, const float *X, const float *norm2, const float *rnorm,
                                int64_t row_begin, int64_t row_end, int D, const float *Q, int nq,
-                               const uint8_t *mask, CandState cs, bool boot, hipStream_t s)
+                               const uint8_t *mask, const uint32_t *rowmap, CandState cs, bool boot,
+                               hipStream_t s)
 {
     if (row_end <= row_begin || nq <= 0) return;
     NarrowArgs a;
+    a.rowmap = rowmap;
     a.X = X; a.norm2 = norm2; a.rnorm = rnorm; a.row_begin = row_begin; a.row_end = row_end; a.D = D;
     a.Q = Q; a.nq = nq; a.mask = mask; a.cs = cs; a.boot = boot ? 1 : 0;
     a.n_row_tiles = (int)((row_end - row_begin + NBM - 1) / NBM);

@@ -32,6 +32,7 @@ struct ScanArgs {
     int nsel;
     const float *qna; // per selected slot: ||q||^2 in the requested order (cosine)
     const uint8_t *mask;
+    const uint32_t *rowmap; // filtered search over a compacted row list: position -> corpus row (or null)
     CandState cs;
     float *all_out;
     int64_t ld;
@@ -68,12 +69,14 @@ struct Acc {
     }
 };
 
-template <int METRIC, int ORDER, int NQ>
+// MAPPED: positions [row_begin,row_end) index a.rowmap (the visible rows under a filter) instead of the corpus
+template <int METRIC, int ORDER, int NQ, bool MAPPED>
 __global__ __launch_bounds__(SC_ROWS) void scan_kernel(ScanArgs a)
 {
     // one __shared__ object: [stage][rows | query chunk]
     constexpr int STAGE_F = SC_ROWS * SC_LD + NQ * SC_DK;
     __shared__ __attribute__((aligned(16))) float lds[2][STAGE_F];
+    __shared__ uint32_t s_rowid[MAPPED ? SC_ROWS : 1]; // corpus row of each tile position
     const int tid = threadIdx.x;
     const int D = a.D;
     const int nchunks = (D + SC_DK - 1) / SC_DK;
@@ -105,6 +108,12 @@ __global__ __launch_bounds__(SC_ROWS) void scan_kernel(ScanArgs a)
         const int64_t trow0 = a.row_begin + tile * SC_ROWS;
         const int64_t myrow = trow0 + tid;
         const bool valid = myrow < a.row_end;
+        int64_t arow = myrow; // corpus row behind position myrow
+        if (MAPPED) {         // (the chunk loop's closing barrier fences the previous tile's readers)
+            arow = a.rowmap[valid ? myrow : a.row_end - 1];
+            s_rowid[tid] = (uint32_t)arow;
+            __syncthreads();
+        }
 
         Acc<ORDER> acc[NQ]; // L2: sum (q-x)^2 ; cos/dot: sum q*x
         Acc<ORDER> nb;      // cos: sum x*x
@@ -127,6 +136,7 @@ __global__ __launch_bounds__(SC_ROWS) void scan_kernel(ScanArgs a)
                 const int r = ch >> 4, p = ch & 15;
                 int64_t row = trow0 + r;
                 if (row >= a.row_end) row = a.row_end - 1;
+                if (MAPPED) row = s_rowid[r];
                 int k = d0 + p * 4;
                 if (k > D - 4) k = D - 4; // D % 4 == 0 here; chunks past D are never consumed
                 stg[i] = *reinterpret_cast<const f32x4 *>(a.X + row * (int64_t)D + k);
@@ -185,7 +195,7 @@ __global__ __launch_bounds__(SC_ROWS) void scan_kernel(ScanArgs a)
             __syncthreads();
         }
 
-        const bool masked_out = valid && a.all_out == nullptr && a.mask != nullptr && !a.mask[myrow];
+        const bool masked_out = valid && a.all_out == nullptr && a.mask != nullptr && !a.mask[arow];
         if (valid && a.boot && masked_out) {
 #pragma unroll
             for (int j = 0; j < NQ; j++)
@@ -213,7 +223,7 @@ __global__ __launch_bounds__(SC_ROWS) void scan_kernel(ScanArgs a)
                 if (a.all_out) {
                     a.all_out[(int64_t)j * a.ld + myrow] = dist;
                 } else {
-                    const uint64_t ent = pack_entry(dist, (uint32_t)myrow);
+                    const uint64_t ent = pack_entry(dist, (uint32_t)arow);
                     const int qj = qidx[j];
                     if (a.boot) {
                         a.cs.lists[(size_t)qj * a.cs.cap + (myrow - a.row_begin)] = ent;
@@ -235,12 +245,13 @@ __global__ __launch_bounds__(256) void scan_generic_kernel(ScanArgs a)
 {
     const int D = a.D;
     const int dmain = D & ~3;
-    for (int64_t row = a.row_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < a.row_end;
-         row += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t pos = a.row_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pos < a.row_end;
+         pos += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = a.rowmap ? (int64_t)a.rowmap[pos] : pos;
         if (a.all_out == nullptr && a.mask != nullptr && !a.mask[row]) {
             if (a.boot)
                 for (int j = 0; j < a.nsel; j++)
-                    a.cs.lists[(size_t)(a.qsel ? a.qsel[j] : j) * a.cs.cap + (row - a.row_begin)] = kEntryMax;
+                    a.cs.lists[(size_t)(a.qsel ? a.qsel[j] : j) * a.cs.cap + (pos - a.row_begin)] = kEntryMax;
             continue;
         }
         const float *x = a.X + row * (int64_t)D;
@@ -297,7 +308,7 @@ __global__ __launch_bounds__(256) void scan_generic_kernel(ScanArgs a)
             } else {
                 const uint64_t ent = pack_entry(dist, (uint32_t)row);
                 if (a.boot) {
-                    a.cs.lists[(size_t)qj * a.cs.cap + (row - a.row_begin)] = ent;
+                    a.cs.lists[(size_t)qj * a.cs.cap + (pos - a.row_begin)] = ent;
                 } else if (ent < a.cs.tau[qj]) {
                     uint32_t pos = atomicAdd(&a.cs.cnt[qj], 1u);
                     if (pos < a.cs.cap) a.cs.lists[(size_t)qj * a.cs.cap + pos] = ent;
@@ -352,20 +363,33 @@ template <int METRIC, int ORDER>
 static void launch_scan_nq(int nq_t, dim3 grid, hipStream_t s, const ScanArgs &a)
 {
     switch (nq_t) {
-    case 1: hipLaunchKernelGGL((scan_kernel<METRIC, ORDER, 1>), grid, dim3(SC_ROWS), 0, s, a); break;
-    case 2: hipLaunchKernelGGL((scan_kernel<METRIC, ORDER, 2>), grid, dim3(SC_ROWS), 0, s, a); break;
-    case 4: hipLaunchKernelGGL((scan_kernel<METRIC, ORDER, 4>), grid, dim3(SC_ROWS), 0, s, a); break;
-    default: hipLaunchKernelGGL((scan_kernel<METRIC, ORDER, 8>), grid, dim3(SC_ROWS), 0, s, a); break;
+    case 1:
+        if (a.rowmap) hipLaunchKernelGGL((scan_kernel<METRIC, ORDER, 1, true>), grid, dim3(SC_ROWS), 0, s, a);
+        else hipLaunchKernelGGL((scan_kernel<METRIC, ORDER, 1, false>), grid, dim3(SC_ROWS), 0, s, a);
+        break;
+    case 2:
+        if (a.rowmap) hipLaunchKernelGGL((scan_kernel<METRIC, ORDER, 2, true>), grid, dim3(SC_ROWS), 0, s, a);
+        else hipLaunchKernelGGL((scan_kernel<METRIC, ORDER, 2, false>), grid, dim3(SC_ROWS), 0, s, a);
+        break;
+    case 4:
+        if (a.rowmap) hipLaunchKernelGGL((scan_kernel<METRIC, ORDER, 4, true>), grid, dim3(SC_ROWS), 0, s, a);
+        else hipLaunchKernelGGL((scan_kernel<METRIC, ORDER, 4, false>), grid, dim3(SC_ROWS), 0, s, a);
+        break;
+    default:
+        if (a.rowmap) hipLaunchKernelGGL((scan_kernel<METRIC, ORDER, 8, true>), grid, dim3(SC_ROWS), 0, s, a);
+        else hipLaunchKernelGGL((scan_kernel<METRIC, ORDER, 8, false>), grid, dim3(SC_ROWS), 0, s, a);
+        break;
     }
 }
 
 void launch_scan(int metric, int order, bool raw_dot, const float *X, int64_t row_begin,
                       int64_t row_end, int D, const float *Q, const int *qsel, int nsel,
-                      const float *qna, const uint8_t *mask, CandState cs, bool boot, float *all_out,
-                      int64_t ld, hipStream_t s)
+                      const float *qna, const uint8_t *mask, const uint32_t *rowmap, CandState cs, bool boot,
+                      float *all_out, int64_t ld, hipStream_t s)
 {
     if (row_end <= row_begin || nsel <= 0) return;
     ScanArgs a;
+    a.rowmap = rowmap;
     a.boot = boot ? 1 : 0;
     a.X = X; a.row_begin = row_begin; a.row_end = row_end; a.D = D;
     a.Q = Q; a.qsel = qsel; a.nsel = nsel; a.qna = qna; a.mask = mask; a.cs = cs;

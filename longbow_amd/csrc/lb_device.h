@@ -86,11 +86,13 @@ void launch_row_norms(const float *X, int64_t n, int D, float *norm2, float *rno
 // boot: every row is stored at list[row - row_begin] (no admission test, no atomics).
 void launch_gemm_filter(int metric, const float *X, const float *norm2, const float *rnorm,
                         int64_t row_begin, int64_t row_end, int D, const float *Q, int nq,
-                        const uint8_t *mask, CandState cs, bool boot, bool split, hipStream_t s);
+                        const uint8_t *mask, const uint32_t *rowmap, CandState cs, bool boot, bool split,
+                        hipStream_t s);
 // small/mid-size batches (5..384 queries): 256-row x 32-query tiles, HBM-bound; needs D % 32 == 0, 16-B aligned X/Q
 void launch_gemm_filter_narrow(int metric, const float *X, const float *norm2, const float *rnorm,
                                int64_t row_begin, int64_t row_end, int D, const float *Q, int nq,
-                               const uint8_t *mask, CandState cs, bool boot, hipStream_t s);
+                               const uint8_t *mask, const uint32_t *rowmap, CandState cs, bool boot,
+                               hipStream_t s);
 // f32 [rows][D] -> split-bf16 image (same byte shape; D % 32 == 0) consumed by the split GEMM
 void launch_split_bf16(const float *src, float *dst, int64_t rows, int D, hipStream_t s);
 
@@ -114,8 +116,8 @@ void launch_query_norms(int order, const float *Q, const int *qsel, int nsel, in
 // If all_out != nullptr writes every distance to all_out[slot*ld + row] instead (simd batch API).
 void launch_scan(int metric, int order, bool raw_dot, const float *X, int64_t row_begin,
                  int64_t row_end, int D, const float *Q, const int *qsel, int nsel,
-                 const float *qna, const uint8_t *mask, CandState cs, bool boot, float *all_out,
-                 int64_t ld, hipStream_t s);
+                 const float *qna, const uint8_t *mask, const uint32_t *rowmap, CandState cs, bool boot,
+                 float *all_out, int64_t ld, hipStream_t s);
 
 // after the last select of the scan path: lists already hold exact distances.
 void launch_emit_lists(CandState cs, const int *qsel, int nsel, int k, const int64_t *ids,
@@ -145,6 +147,10 @@ void launch_match_int64(const int64_t *src, int64_t n, int64_t val, int op, cons
 void launch_match_float32(const float *src, int64_t n, float val, int op, const uint8_t *validity,
                           int64_t valid_offset, uint8_t *dst, int combine, hipStream_t s);
 void launch_and_bytes(uint8_t *dst, const uint8_t *src, int64_t n, hipStream_t s);
+// ordered compaction of a byte mask into the ascending list of visible rows; scratch holds
+// compact_scratch_words(n) u32 and ends with the visible-row count at [words-1]
+int64_t compact_scratch_words(int64_t n);
+void launch_compact_mask(const uint8_t *mask, int64_t n, uint32_t *rowmap, uint32_t *scratch, hipStream_t s);
 // reciprocal-rank fusion of two ranked id lists per query (kernels_filter.hip)
 void launch_rrf(int64_t nq, int kd, const int64_t *dense, int ks, const int64_t *sparse, int k, int limit,
                 int64_t *out_ids, float *out_scores, hipStream_t s);

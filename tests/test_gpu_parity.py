@@ -155,6 +155,63 @@ def test_filter_mask(oracle):
         idx.Close()
 
 
+def test_selective_filter_walks_compacted_row_list(oracle):
+    """a filter hiding >= 5 % of the corpus switches every search path (exact scan, narrow and wide
+    MFMA tiles, split-bf16 candidates) to the compacted visible-row list; results stay bit-exact,
+    including ids, ragged tile tails, fewer-than-k and zero visible rows, and appends after the filter"""
+    gpu_or_skip()
+    rng = np.random.default_rng(77)
+    n, d = 70001, 64
+    X = rng.random((n, d), dtype=F)
+    X[5000:5040] = X[100]                        # duplicate rows: ties must still break by row position
+    Q = rng.random((400, d), dtype=F)
+    Q[7] = X[100]
+    ids = (np.arange(n, dtype=np.int64) * 3 + 11)
+    meta = rng.integers(0, 1000, n)
+    meta[[100, 5003, 5017]] = 0
+    for metric in (0, 1, 2):
+        idx = new_index(d, metric)
+        idx.Add(ids, X)
+        for sel in (980, 500, 100, 7, 1):        # 98 % (per-row mask test), 50 %, 10 %, 0.7 %, ~0.1 % visible
+            mask = (meta < sel).astype(np.uint8)
+            idx.set_filter(mask)
+            for qs in (Q[:1], Q[:3], Q[:8], Q[:40], Q):
+                lab, dist = idx.SearchBatch(qs, 100)
+                oi, od = oracle.search_batch(metric, qs, X, 100, mask=mask, ids=ids, nthreads=8)
+                assert_same(lab, dist, oi, od, f"metric {metric} sel {sel} nq {len(qs)}")
+        # split-bf16 candidate generation walks the same list
+        mask = (meta < 100).astype(np.uint8)
+        idx.set_filter(mask)
+        idx.set_candidate_mode(1)
+        lab, dist = idx.SearchBatch(Q, 100)
+        oi, od = oracle.search_batch(metric, Q, X, 100, mask=mask, ids=ids, nthreads=8)
+        assert_same(lab, dist, oi, od, f"split metric {metric}")
+        idx.set_candidate_mode(0)
+        # rows appended after the filter are visible (and join the list)
+        X2 = rng.random((300, d), dtype=F)
+        ids2 = np.arange(300, dtype=np.int64) + 10_000_000
+        idx.Add(ids2, X2)
+        Xa, ida = np.concatenate([X, X2]), np.concatenate([ids, ids2])
+        ma = np.concatenate([mask, np.ones(300, np.uint8)])
+        for qs in (Q[:2], Q[:40]):
+            lab, dist = idx.SearchBatch(qs, 100)
+            oi, od = oracle.search_batch(metric, qs, Xa, 100, mask=ma, ids=ida, nthreads=8)
+            assert_same(lab, dist, oi, od, f"after append metric {metric}")
+        # nothing visible -> every slot padded
+        idx.set_filter(np.zeros(n + 300, np.uint8))
+        for qs in (Q[:2], Q[:40]):
+            lab, dist = idx.SearchBatch(qs, 10)
+            assert np.all(lab == -1) and np.all(dist == np.finfo(F).max)
+        # a column predicate evaluated on the device lands on the same path
+        col = np.concatenate([meta, np.full(300, 999)]).astype(np.int64)
+        idx.filter_column(col, "<", 50)
+        mc = (col < 50).astype(np.uint8)
+        lab, dist = idx.SearchBatch(Q[:40], 100)
+        oi, od = oracle.search_batch(metric, Q[:40], Xa, 100, mask=mc, ids=ida, nthreads=8)
+        assert_same(lab, dist, oi, od, f"column predicate metric {metric}")
+        idx.Close()
+
+
 def test_adversarial_order_forces_list_overflow(oracle):
     """rows sorted from worst to best: every row is admitted, the candidate lists overflow, and the
     library must fall back to overflow-proof chunking and still be exact"""
