@@ -16,6 +16,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -60,6 +61,7 @@ struct Workspace {
     float *d_qs = nullptr; // split-bf16 image of the query batch
     size_t d_qs_bytes = 0;
     int *d_qsel = nullptr;
+    uint32_t *d_smap = nullptr;  // [cap] sampled rows of the first pass
     uint32_t *h_flags = nullptr; // pinned
     int *h_qsel = nullptr;       // pinned
     // host-API staging (device side)
@@ -81,6 +83,7 @@ struct Workspace {
         if (d_qna) (void)hipFree(d_qna);
         if (d_qs) (void)hipFree(d_qs);
         if (d_qsel) (void)hipFree(d_qsel);
+        if (d_smap) (void)hipFree(d_smap);
         if (h_flags) (void)hipHostFree(h_flags);
         if (h_qsel) (void)hipHostFree(h_qsel);
         if (d_q) (void)hipFree(d_q);
@@ -206,6 +209,7 @@ std::unique_ptr<Workspace> acquire_ws(lb_gpu_index *h, int nq, uint32_t cap)
     LB_HIP(hipMalloc(&w->cs.flags, (size_t)w->nq_cap * sizeof(uint32_t)));
     LB_HIP(hipMalloc(&w->d_qna, (size_t)w->nq_cap * sizeof(float)));
     LB_HIP(hipMalloc(&w->d_qsel, (size_t)w->nq_cap * sizeof(int)));
+    LB_HIP(hipMalloc(&w->d_smap, (size_t)cap * sizeof(uint32_t)));
     LB_HIP(hipHostMalloc(&w->h_flags, (size_t)w->nq_cap * sizeof(uint32_t), hipHostMallocDefault));
     LB_HIP(hipHostMalloc(&w->h_qsel, (size_t)w->nq_cap * sizeof(int), hipHostMallocDefault));
     return w;
@@ -257,26 +261,90 @@ static RowView row_view(const lb_gpu_index *h)
     return {h->d_mask, nullptr, h->n};
 }
 
+// First pass with a sampled threshold.  Instead of bootstrapping on the first few thousand rows and
+// growing the chunks geometrically (3-4 launches + selects per search), `count` evenly spaced rows of
+// the first `span` positions are scored, their m-th best entry becomes the admission threshold and
+// the whole span is then walked ONCE.  The threshold is only a filter: every row below it is collected,
+// so a list that ends with >= keep entries holds exactly the span's best `keep`.
+//   too tight:  fewer than `keep` rows pass iff >= m sampled rows are among the span's best keep-1;
+//               that count is ~Poisson(lambda = keep*count/span), and m = lambda + 5 sqrt(lambda) + 4
+//               puts the tail below 1e-7 (m = 10 for k = 100, 14 for the 256 MFMA candidates at 1M rows);
+//   too loose:  about m*span/count rows pass (1.2k-1.8k at 1M rows), relative spread 1/sqrt(m); the span
+//               is capped so that mean + 5 sigma stays below the list capacity.
+// Either miss is detected (flag bit 2 / bit 0) and the query is redone by the classic bootstrap
+// schedule, so results never depend on the sample.  The stride makes the estimate independent of the
+// row order (sorted or clustered corpora included).  Fewer admitted rows also matter for speed: each
+// admission is a returning atomic on one hot counter, ~12 ns apiece in the 1-query scan.
+struct SamplePlan {
+    bool on = false;
+    int64_t span = 0;   // positions covered by the first pass
+    uint32_t count = 0; // sampled rows
+    int m = 0;
+};
+std::atomic<int> g_sample_tau{[] { const char *e = getenv("LB_SAMPLE_TAU"); return e ? atoi(e) : 1; }()};
+static SamplePlan sample_plan(int64_t n, int keep, uint32_t cap)
+{
+    SamplePlan p;
+    if (!g_sample_tau.load() || n < 65536) return p;
+    const uint32_t count = std::min<uint32_t>(cap, 8192u);
+    int m = 8;
+    int64_t span = 0;
+    for (int it = 0; it < 8; it++) {
+        const double loose = (double)m * (1.0 + 5.0 / std::sqrt((double)m)); // mean + 5 sigma, in units of span/count
+        const double span_max = (double)(cap - (uint32_t)keep) * (double)count / loose;
+        span = span_max >= (double)n ? n : (int64_t)span_max;
+        const double lambda = (double)keep * (double)count / (double)span;
+        const int need = (int)std::ceil(lambda + 5.0 * std::sqrt(lambda) + 4.0);
+        if (need <= m) break;
+        m = need;
+        if (m > 32) return p;
+    }
+    if (span < 8 * (int64_t)count || !sample_tau_supported(count, m)) return p;
+    p.on = true;
+    p.span = span;
+    p.count = count;
+    p.m = m;
+    return p;
+}
+
 // Exact scan of all rows for the query slots sel[0..nsel) (indices into d_q rows).
-// safe=false: 3 chunks (bootstrap / 64k / rest); safe=true: chunks that cannot overflow.
-void run_scan_path(lb_gpu_index *h, Workspace *w, hipStream_t s, const float *d_q, const int *d_sel,
-                   int nsel, int k, bool safe, float *d_dist, int64_t *d_lab, bool prof)
+// mode 0: sampled first pass, 1: classic (bootstrap / growing chunks), 2: chunks that cannot overflow.
+bool run_scan_path(lb_gpu_index *h, Workspace *w, hipStream_t s, const float *d_q, const int *d_sel,
+                   int nsel, int k, int mode, float *d_dist, int64_t *d_lab, bool prof)
 {
     const int metric = h->metric, order = h->order.load();
     const RowView rv = row_view(h);
     const int64_t n = rv.n;
     const uint8_t *mask = rv.mask;
     const int kkeep = std::max(k, 1);
-    launch_init_cand(w->cs, d_sel, nsel, s);
+    const bool safe = mode == 2;
+    const SamplePlan sp = mode == 0 ? sample_plan(n, kkeep, w->cap) : SamplePlan{};
+    if (!sp.on) launch_init_cand(w->cs, d_sel, nsel, s);
     for (int g0 = 0; g0 < nsel; g0 += kScanMaxQ) {
         const int gn = std::min(kScanMaxQ, nsel - g0);
         const int *use_sel = d_sel + g0; // d_sel is always an explicit slot list here
-        if (metric == LB_METRIC_COSINE) {
+        int64_t pos = 0;
+        int step = 0;
+        if (sp.on) {
+            {   // sample scores (clears the flags), then threshold + exact query norms in one launch
+                ProfScope p(w, s, prof, 3);
+                launch_sample_scores(metric, h->d_X, h->dim, sp.span, sp.count, rv.rowmap, mask, d_q, use_sel, gn,
+                                     w->cs, s);
+                launch_sample_tau(order, w->cs, use_sel, gn, sp.count, sp.m, d_q, h->dim,
+                                  metric == LB_METRIC_COSINE ? w->d_qna : nullptr, s);
+                launch_scan(metric, order, false, h->d_X, 0, sp.span, h->dim, d_q, use_sel, gn, w->d_qna, mask,
+                            rv.rowmap, w->cs, /*boot=*/false, nullptr, 0, s);
+            }
+            {
+                ProfScope p(w, s, prof, 1);
+                launch_select(w->cs, use_sel, gn, kkeep, 0u, s, false, (uint32_t)kkeep);
+            }
+            pos = sp.span;
+            step = 1;
+        } else if (metric == LB_METRIC_COSINE) {
             ProfScope p(w, s, prof, 3);
             launch_query_norms(order, d_q, use_sel, gn, h->dim, w->d_qna, s);
         }
-        int64_t pos = 0;
-        int step = 0;
         while (pos < n) {
             const int64_t end = chunk_end_host(step, pos, n, kkeep, w->cap, safe, /*big_boot=*/true);
             const bool boot = step == 0;
@@ -294,6 +362,7 @@ void run_scan_path(lb_gpu_index *h, Workspace *w, hipStream_t s, const float *d_
         }
         launch_emit_lists(w->cs, use_sel, gn, k, h->has_ids ? h->d_ids : nullptr, d_dist, d_lab, s);
     }
+    return sp.on;
 }
 
 // download flags for slots [0,nq) and return those with any of `bits` set
@@ -324,12 +393,20 @@ void scan_with_retry(lb_gpu_index *h, Workspace *w, hipStream_t s, const float *
 {
     if (sel.empty()) return;
     upload_sel(w, s, sel);
-    run_scan_path(h, w, s, d_q, w->d_qsel, (int)sel.size(), k, false, d_dist, d_lab, prof);
-    std::vector<int> over;
-    if (collect_flagged(w, s, nq_total, 1u, sel.data(), (int)sel.size(), over) > 0) {
-        upload_sel(w, s, over);
-        run_scan_path(h, w, s, d_q, w->d_qsel, (int)over.size(), k, true, d_dist, d_lab, prof);
-        LB_HIP(hipStreamSynchronize(s));
+    const bool sampled = run_scan_path(h, w, s, d_q, w->d_qsel, (int)sel.size(), k, 0, d_dist, d_lab, prof);
+    std::vector<int> redo, over;
+    if (collect_flagged(w, s, nq_total, 1u | 4u, sel.data(), (int)sel.size(), redo) > 0) {
+        // the sampled threshold missed (or a list overflowed): classic schedule, then overflow-proof chunks
+        if (sampled) {
+            upload_sel(w, s, redo);
+            run_scan_path(h, w, s, d_q, w->d_qsel, (int)redo.size(), k, 1, d_dist, d_lab, prof);
+        }
+        if (!sampled || collect_flagged(w, s, nq_total, 1u, redo.data(), (int)redo.size(), over) > 0) {
+            if (!sampled) over = redo;
+            upload_sel(w, s, over);
+            run_scan_path(h, w, s, d_q, w->d_qsel, (int)over.size(), k, 2, d_dist, d_lab, prof);
+            LB_HIP(hipStreamSynchronize(s));
+        }
     }
 }
 
@@ -378,20 +455,37 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         // 3D/16 MFMA accumulations + <=16-term block sums, plus the dropped lo*lo / residual terms
         gamma = 1.05f * ((float)(3 * h->dim / 16 + 24) * u24 + 3.0f * 3.8146973e-6f);
     }
+    auto candidates = [&](int64_t b, int64_t e, const uint32_t *rowmap, bool boot) {
+        ProfScope p(w, s, prof, 0);
+        if (!split && narrow_ok && nq <= narrow_max)
+            launch_gemm_filter_narrow(metric, gx, h->d_norm2, h->d_rnorm, b, e, h->dim, gq, nq, mask, rowmap,
+                                      w->cs, boot, s);
+        else
+            launch_gemm_filter(metric, gx, h->d_norm2, h->d_rnorm, b, e, h->dim, gq, nq, mask, rowmap, w->cs,
+                               boot, split, s);
+    };
     int64_t pos = 0;
     int step = 0;
+    const SamplePlan sp = sample_plan(n, kc, w->cap);
+    if (sp.on) { // sampled threshold, then one pass over the span (see sample_plan)
+        launch_sample_map(rv.rowmap, sp.span, sp.count, w->d_smap, s);
+        candidates(0, sp.count, w->d_smap, /*boot=*/true);
+        {
+            ProfScope p(w, s, prof, 1);
+            launch_sample_tau(order, w->cs, nullptr, nq, sp.count, sp.m, d_q, h->dim, nullptr, s);
+        }
+        candidates(0, sp.span, rv.rowmap, /*boot=*/false);
+        {
+            ProfScope p(w, s, prof, 1);
+            launch_select(w->cs, nullptr, nq, kc, 0u, s, false, (uint32_t)kc);
+        }
+        pos = sp.span;
+        step = 1;
+    }
     while (pos < n) {
         const int64_t end = chunk_end_host(step, pos, n, kc, w->cap, false);
         const bool boot = step == 0;
-        {
-            ProfScope p(w, s, prof, 0);
-            if (!split && narrow_ok && nq <= narrow_max)
-                launch_gemm_filter_narrow(metric, gx, h->d_norm2, h->d_rnorm, pos, end, h->dim, gq, nq, mask,
-                                          rv.rowmap, w->cs, boot, s);
-            else
-                launch_gemm_filter(metric, gx, h->d_norm2, h->d_rnorm, pos, end, h->dim, gq, nq, mask,
-                                   rv.rowmap, w->cs, boot, split, s);
-        }
+        candidates(pos, end, rv.rowmap, boot);
         {
             ProfScope p(w, s, prof, 1);
             launch_select(w->cs, nullptr, nq, kc, boot ? (uint32_t)(end - pos) : 0u, s);
@@ -405,7 +499,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
                       h->has_ids ? h->d_ids : nullptr, d_dist, d_lab, s);
     }
     std::vector<int> bad;
-    if (collect_flagged(w, s, nq, 3u, nullptr, 0, bad) > 0) {
+    if (collect_flagged(w, s, nq, 3u | 4u, nullptr, 0, bad) > 0) {
         fallbacks += (int64_t)bad.size();
         scan_with_retry(h, w, s, d_q, nq, bad, k, d_dist, d_lab, prof);
     }
@@ -1002,6 +1096,7 @@ int lb_gpu_index_last_timing(const lb_gpu_index *hc, float ms[5], int n_launch[5
 
 // profiling aid, not part of the public header: selects a timing-only ablation of the GEMM kernel
 void lb_debug_set_gemm_ablation(int v) { lb::g_gemm_ablation = v; }
+void lb_debug_set_sample_tau(int v) { g_sample_tau.store(v); } // 0: classic bootstrap schedule only
 void lb_debug_set_gemm_glds(int v) { lb::g_gemm_glds = v; }
 void lb_debug_set_adc_ablation(int v) { lb::g_adc_ablation = v; }
 int lb_debug_gemm_occupancy(void) { return lb::debug_gemm_occupancy(); }

@@ -69,20 +69,24 @@ struct Acc {
     }
 };
 
-// MAPPED: positions [row_begin,row_end) index a.rowmap (the visible rows under a filter) instead of the corpus
-template <int METRIC, int ORDER, int NQ, bool MAPPED>
+// MAPPED: positions [row_begin,row_end) index a.rowmap (the visible rows under a filter) instead of the corpus.
+// NBUF: LDS stages.  2 = write the next stage while the current one is read (69.6 KB, 2 workgroups/CU);
+// 1 = one stage + an extra barrier (34.8 KB, 4 workgroups/CU: twice the bytes in flight per CU).
+// The (tile, chunk) sequence of a workgroup is one flat pipeline: the first chunk of the next tile
+// is already in flight while the last chunk of the current tile is consumed.
+template <int METRIC, int ORDER, int NQ, bool MAPPED, int NBUF>
 __global__ __launch_bounds__(SC_ROWS) void scan_kernel(ScanArgs a)
 {
     // one __shared__ object: [stage][rows | query chunk]
     constexpr int STAGE_F = SC_ROWS * SC_LD + NQ * SC_DK;
-    __shared__ __attribute__((aligned(16))) float lds[2][STAGE_F];
-    __shared__ uint32_t s_rowid[MAPPED ? SC_ROWS : 1]; // corpus row of each tile position
+    __shared__ __attribute__((aligned(16))) float lds[NBUF][STAGE_F];
     const int tid = threadIdx.x;
     const int D = a.D;
     const int nchunks = (D + SC_DK - 1) / SC_DK;
     const int dmain = D & ~3; // elements covered by the 4-wide main loop of UNROLL4
     const int64_t nrows = a.row_end - a.row_begin;
     const int64_t ntiles = (nrows + SC_ROWS - 1) / SC_ROWS;
+    if ((int64_t)blockIdx.x >= ntiles) return;
 
     // query slots (wave-uniform)
     int qidx[NQ];
@@ -104,63 +108,74 @@ __global__ __launch_bounds__(SC_ROWS) void scan_kernel(ScanArgs a)
         q_src = a.Q + (int64_t)(a.qsel ? a.qsel[j] : j) * D;
     }
 
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    f32x4 stg[16];
+    f32x4 stq = {0.f, 0.f, 0.f, 0.f};
+    uint32_t rid[MAPPED ? 16 : 1]; // MAPPED: corpus rows behind this thread's 16 staging slots of the tile being loaded
+    auto load_stage = [&](int64_t tile, int c) {
         const int64_t trow0 = a.row_begin + tile * SC_ROWS;
-        const int64_t myrow = trow0 + tid;
-        const bool valid = myrow < a.row_end;
-        int64_t arow = myrow; // corpus row behind position myrow
-        if (MAPPED) {         // (the chunk loop's closing barrier fences the previous tile's readers)
-            arow = a.rowmap[valid ? myrow : a.row_end - 1];
-            s_rowid[tid] = (uint32_t)arow;
-            __syncthreads();
+        const int d0 = c * SC_DK;
+        if (q_loader) {
+            int k = d0 + (tid & 15) * 4;
+            if (k > D - 4) k = D - 4;
+            stq = *reinterpret_cast<const f32x4 *>(q_src + k);
         }
-
-        Acc<ORDER> acc[NQ]; // L2: sum (q-x)^2 ; cos/dot: sum q*x
-        Acc<ORDER> nb;      // cos: sum x*x
-#pragma unroll
-        for (int j = 0; j < NQ; j++) acc[j].zero();
-        nb.zero();
-
-        f32x4 stg[16];
-        f32x4 stq = {0.f, 0.f, 0.f, 0.f};
-        auto load_stage = [&](int c) {
-            const int d0 = c * SC_DK;
-            if (q_loader) {
-                int k = d0 + (tid & 15) * 4;
-                if (k > D - 4) k = D - 4;
-                stq = *reinterpret_cast<const f32x4 *>(q_src + k);
-            }
+        if (MAPPED && c == 0) {
 #pragma unroll
             for (int i = 0; i < 16; i++) {
-                const int ch = tid + SC_ROWS * i;
-                const int r = ch >> 4, p = ch & 15;
-                int64_t row = trow0 + r;
-                if (row >= a.row_end) row = a.row_end - 1;
-                if (MAPPED) row = s_rowid[r];
-                int k = d0 + p * 4;
-                if (k > D - 4) k = D - 4; // D % 4 == 0 here; chunks past D are never consumed
-                stg[i] = *reinterpret_cast<const f32x4 *>(a.X + row * (int64_t)D + k);
+                int64_t pos = trow0 + ((tid + SC_ROWS * i) >> 4);
+                if (pos >= a.row_end) pos = a.row_end - 1;
+                rid[MAPPED ? i : 0] = a.rowmap[pos];
             }
-        };
-        auto write_stage = [&](int st) {
+        }
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const int ch = tid + SC_ROWS * i;
-                const int r = ch >> 4, p = ch & 15;
-                *reinterpret_cast<f32x4 *>(&lds[st][r * SC_LD + p * 4]) = stg[i];
-            }
-            if (q_loader)
-                *reinterpret_cast<f32x4 *>(&lds[st][SC_ROWS * SC_LD + (tid >> 4) * SC_DK + (tid & 15) * 4]) = stq;
-        };
+        for (int i = 0; i < 16; i++) {
+            const int ch = tid + SC_ROWS * i;
+            const int r = ch >> 4, p = ch & 15;
+            int64_t row = trow0 + r;
+            if (row >= a.row_end) row = a.row_end - 1;
+            if (MAPPED) row = rid[MAPPED ? i : 0];
+            int k = d0 + p * 4;
+            if (k > D - 4) k = D - 4; // D % 4 == 0 here; chunks past D are never consumed
+            stg[i] = *reinterpret_cast<const f32x4 *>(a.X + row * (int64_t)D + k);
+        }
+    };
+    auto write_stage = [&](int st) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int ch = tid + SC_ROWS * i;
+            const int r = ch >> 4, p = ch & 15;
+            *reinterpret_cast<f32x4 *>(&lds[st][r * SC_LD + p * 4]) = stg[i];
+        }
+        if (q_loader)
+            *reinterpret_cast<f32x4 *>(&lds[st][SC_ROWS * SC_LD + (tid >> 4) * SC_DK + (tid & 15) * 4]) = stq;
+    };
 
-        load_stage(0);
-        write_stage(0);
-        __syncthreads();
+    Acc<ORDER> acc[NQ]; // L2: sum (q-x)^2 ; cos/dot: sum q*x
+    Acc<ORDER> nb;      // cos: sum x*x
 
-        for (int c = 0; c < nchunks; c++) {
-            if (c + 1 < nchunks) load_stage(c + 1);
-            const float *xr = &lds[c & 1][tid * SC_LD];
-            const float *lq = &lds[c & 1][SC_ROWS * SC_LD];
+    int64_t tile = blockIdx.x;
+    int c = 0, cur = 0;
+    load_stage(tile, 0);
+    write_stage(0);
+    __syncthreads();
+
+    while (true) {
+        int64_t ntile = tile;
+        int nc = c + 1;
+        if (nc == nchunks) {
+            nc = 0;
+            ntile = tile + gridDim.x;
+        }
+        const bool has_next = ntile < ntiles;
+        if (has_next) load_stage(ntile, nc);
+        if (c == 0) {
+#pragma unroll
+            for (int j = 0; j < NQ; j++) acc[j].zero();
+            nb.zero();
+        }
+        {
+            const float *xr = &lds[cur][tid * SC_LD];
+            const float *lq = &lds[cur][SC_ROWS * SC_LD];
             const int d0 = c * SC_DK;
             const int nfull4 = (min(dmain, d0 + SC_DK) - d0) >> 2; // groups of 4 in the main loop
             // main loop: groups of 4 elements, positions 0..3 -> accumulators 0..3 (UNROLL4)
@@ -191,49 +206,64 @@ __global__ __launch_bounds__(SC_ROWS) void scan_kernel(ScanArgs a)
                     }
                 }
             }
-            if (c + 1 < nchunks) write_stage((c + 1) & 1);
-            __syncthreads();
+        }
+        if (NBUF == 1) {
+            __syncthreads(); // every wave is done reading the single stage
+            if (has_next) write_stage(0);
+        } else if (has_next) {
+            write_stage(cur ^ 1);
         }
 
-        const bool masked_out = valid && a.all_out == nullptr && a.mask != nullptr && !a.mask[arow];
-        if (valid && a.boot && masked_out) {
+        if (c == nchunks - 1) { // the tile's distances are complete
+            const int64_t myrow = a.row_begin + tile * SC_ROWS + tid;
+            const bool valid = myrow < a.row_end;
+            int64_t arow = myrow; // corpus row behind position myrow
+            if (MAPPED) arow = a.rowmap[valid ? myrow : a.row_end - 1];
+            const bool masked_out = valid && a.all_out == nullptr && a.mask != nullptr && !a.mask[arow];
+            if (valid && a.boot && masked_out) {
 #pragma unroll
-            for (int j = 0; j < NQ; j++)
-                if (j < a.nsel) a.cs.lists[(size_t)qidx[j] * a.cs.cap + (myrow - a.row_begin)] = kEntryMax;
-        }
-        if (valid && !masked_out) {
-            const float nbt = nb.total();
+                for (int j = 0; j < NQ; j++)
+                    if (j < a.nsel) a.cs.lists[(size_t)qidx[j] * a.cs.cap + (myrow - a.row_begin)] = kEntryMax;
+            }
+            if (valid && !masked_out) {
+                const float nbt = nb.total();
 #pragma unroll
-            for (int j = 0; j < NQ; j++) {
-                if (j >= a.nsel) break;
-                const float t = acc[j].total();
-                float dist;
-                if (METRIC == METRIC_L2) {
-                    dist = (float)sqrt((double)t);
-                } else if (METRIC == METRIC_COS) {
-                    const float na = a.qna[j];
-                    if (D == 0 || na == 0.0f || nbt == 0.0f) dist = 1.0f;
-                    else {
-                        const float den = (float)sqrt((double)na * (double)nbt);
-                        dist = 1.0f - __fdiv_rn(t, den);
+                for (int j = 0; j < NQ; j++) {
+                    if (j >= a.nsel) break;
+                    const float t = acc[j].total();
+                    float dist;
+                    if (METRIC == METRIC_L2) {
+                        dist = (float)sqrt((double)t);
+                    } else if (METRIC == METRIC_COS) {
+                        const float na = a.qna[j];
+                        if (D == 0 || na == 0.0f || nbt == 0.0f) dist = 1.0f;
+                        else {
+                            const float den = (float)sqrt((double)na * (double)nbt);
+                            dist = 1.0f - __fdiv_rn(t, den);
+                        }
+                    } else {
+                        dist = a.raw_dot ? t : -t;
                     }
-                } else {
-                    dist = a.raw_dot ? t : -t;
-                }
-                if (a.all_out) {
-                    a.all_out[(int64_t)j * a.ld + myrow] = dist;
-                } else {
-                    const uint64_t ent = pack_entry(dist, (uint32_t)arow);
-                    const int qj = qidx[j];
-                    if (a.boot) {
-                        a.cs.lists[(size_t)qj * a.cs.cap + (myrow - a.row_begin)] = ent;
-                    } else if (ent < tau[j]) {
-                        uint32_t pos = atomicAdd(&a.cs.cnt[qj], 1u);
-                        if (pos < a.cs.cap) a.cs.lists[(size_t)qj * a.cs.cap + pos] = ent;
+                    if (a.all_out) {
+                        a.all_out[(int64_t)j * a.ld + myrow] = dist;
+                    } else {
+                        const uint64_t ent = pack_entry(dist, (uint32_t)arow);
+                        const int qj = qidx[j];
+                        if (a.boot) {
+                            a.cs.lists[(size_t)qj * a.cs.cap + (myrow - a.row_begin)] = ent;
+                        } else if (ent < tau[j]) {
+                            uint32_t pos = atomicAdd(&a.cs.cnt[qj], 1u);
+                            if (pos < a.cs.cap) a.cs.lists[(size_t)qj * a.cs.cap + pos] = ent;
+                        }
                     }
                 }
             }
         }
+        __syncthreads();
+        if (!has_next) break;
+        tile = ntile;
+        c = nc;
+        if (NBUF == 2) cur ^= 1;
     }
 }
 
@@ -359,26 +389,235 @@ void launch_query_norms(int order, const float *Q, const int *qsel, int nsel, in
         hipLaunchKernelGGL(query_norms_kernel<ORDER_SEQ>, grid, block, shmem, s, Q, qsel, nsel, D, qna);
 }
 
+// ---------------------------------------------------------------------------
+// Sampled admission threshold (index.hip: sample_plan).  `count` evenly spaced positions of
+// [0, span) are scored approximately -- one wave per sampled row, every load of the row in flight
+// at once, wave-shuffle reduction: the whole sample costs one HBM round trip instead of the exact
+// kernel's D/64 dependent stages -- and the m-th best of them becomes tau.  tau is only a filter
+// (every row below it is collected and scored exactly afterwards), so the summation order here
+// does not matter; a threshold that admits too few or too many rows is detected and the query is
+// redone by the classic schedule.
+// ---------------------------------------------------------------------------
+constexpr int SS_MAXQ = 8;
+
+struct SampleArgs {
+    const float *X;
+    int D;
+    int64_t span;
+    uint32_t count;
+    const uint32_t *rowmap;
+    const uint8_t *mask;
+    const float *Q;
+    const int *qsel;
+    int nsel;
+    CandState cs;
+    int aligned;
+};
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+template <int METRIC>
+__global__ __launch_bounds__(256) void sample_scores_kernel(SampleArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (blockIdx.x == 0 && (int)threadIdx.x < a.nsel) a.cs.flags[a.qsel ? a.qsel[threadIdx.x] : threadIdx.x] = 0;
+    const uint32_t i = blockIdx.x * 4u + (uint32_t)wave;
+    if (i >= a.count) return;
+    const int64_t pos = (int64_t)(((uint64_t)i * (uint64_t)a.span) / a.count); // i, span < 2^32
+    const int64_t row = a.rowmap ? (int64_t)a.rowmap[pos] : pos;
+    const int D = a.D;
+    const bool hidden = a.mask != nullptr && !a.mask[row];
+    float acc[SS_MAXQ], qq[SS_MAXQ], xx = 0.f;
+#pragma unroll
+    for (int j = 0; j < SS_MAXQ; j++) { acc[j] = 0.f; qq[j] = 0.f; }
+    if (!hidden) {
+        const float *x = a.X + row * (int64_t)D;
+        if (a.aligned) {
+            for (int k = lane * 4; k < D; k += 256) {
+                const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + k);
+                if (METRIC == METRIC_COS) xx += xv.x * xv.x + xv.y * xv.y + xv.z * xv.z + xv.w * xv.w;
+#pragma unroll
+                for (int j = 0; j < SS_MAXQ; j++) {
+                    if (j >= a.nsel) break;
+                    const f32x4 qv = *reinterpret_cast<const f32x4 *>(a.Q + (int64_t)(a.qsel ? a.qsel[j] : j) * D + k);
+                    if (METRIC == METRIC_L2) {
+                        const float e0 = qv.x - xv.x, e1 = qv.y - xv.y, e2 = qv.z - xv.z, e3 = qv.w - xv.w;
+                        acc[j] += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
+                    } else {
+                        acc[j] += qv.x * xv.x + qv.y * xv.y + qv.z * xv.z + qv.w * xv.w;
+                        if (METRIC == METRIC_COS) qq[j] += qv.x * qv.x + qv.y * qv.y + qv.z * qv.z + qv.w * qv.w;
+                    }
+                }
+            }
+        } else {
+            for (int k = lane; k < D; k += 64) {
+                const float xv = x[k];
+                if (METRIC == METRIC_COS) xx += xv * xv;
+#pragma unroll
+                for (int j = 0; j < SS_MAXQ; j++) {
+                    if (j >= a.nsel) break;
+                    const float qv = a.Q[(int64_t)(a.qsel ? a.qsel[j] : j) * D + k];
+                    if (METRIC == METRIC_L2) {
+                        const float e = qv - xv;
+                        acc[j] += e * e;
+                    } else {
+                        acc[j] += qv * xv;
+                        if (METRIC == METRIC_COS) qq[j] += qv * qv;
+                    }
+                }
+            }
+        }
+    }
+    if (METRIC == METRIC_COS) xx = wave_sum(xx);
+#pragma unroll
+    for (int j = 0; j < SS_MAXQ; j++) {
+        if (j >= a.nsel) break;
+        const float t = wave_sum(acc[j]);
+        float dist;
+        if (METRIC == METRIC_L2) {
+            dist = sqrtf(t);
+        } else if (METRIC == METRIC_COS) {
+            const float na = wave_sum(qq[j]);
+            dist = (na == 0.f || xx == 0.f) ? 1.0f : 1.0f - t * rsqrtf(na * xx);
+        } else {
+            dist = -t;
+        }
+        if (lane == 0) {
+            const int qj = a.qsel ? a.qsel[j] : j;
+            a.cs.lists[(size_t)qj * a.cs.cap + i] = hidden ? kEntryMax : pack_entry(dist, (uint32_t)row);
+        }
+    }
+}
+
+void launch_sample_scores(int metric, const float *X, int D, int64_t span, uint32_t count, const uint32_t *rowmap,
+                          const uint8_t *mask, const float *Q, const int *qsel, int nsel, CandState cs, hipStream_t s)
+{
+    if (count == 0 || nsel <= 0) return;
+    SampleArgs a;
+    a.X = X; a.D = D; a.span = span; a.count = count; a.rowmap = rowmap; a.mask = mask;
+    a.Q = Q; a.qsel = qsel; a.nsel = nsel < SS_MAXQ ? nsel : SS_MAXQ; a.cs = cs;
+    a.aligned = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && ((reinterpret_cast<uintptr_t>(Q) & 15) == 0);
+    dim3 grid((count + 3) / 4), block(256);
+    if (metric == METRIC_L2) hipLaunchKernelGGL(sample_scores_kernel<METRIC_L2>, grid, block, 0, s, a);
+    else if (metric == METRIC_COS) hipLaunchKernelGGL(sample_scores_kernel<METRIC_COS>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(sample_scores_kernel<METRIC_DOT>, grid, block, 0, s, a);
+}
+
+// tau[q] = m-th smallest of the first `count` entries of list q (row bits saturated), cnt[q] = 0.
+// m is small (8..32): m rounds of a workgroup-wide minimum over register-resident entries beat a
+// radix select by 3-4x here.  Workgroups [nsel, 2*nsel) compute the exact query norms of the same
+// slots (cosine; qna != null) so that launch rides along instead of preceding the scan.
+constexpr int ST_THREADS = 1024;
+constexpr int ST_PER = 8;
+
+template <int ORDER>
+__global__ __launch_bounds__(ST_THREADS) void sample_tau_kernel(CandState cs, const int *qsel, int nsel, uint32_t count,
+                                                                int m, const float *Q, int D, float *qna)
+{
+    extern __shared__ __attribute__((aligned(16))) float sq[];
+    __shared__ uint64_t wmin[2][ST_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if ((int)blockIdx.x >= nsel) { // exact ||q||^2 in the requested order (as query_norms_kernel)
+        const int j = (int)blockIdx.x - nsel;
+        const float *q = Q + (int64_t)(qsel ? qsel[j] : j) * D;
+        const int Dpad = (D + 3) & ~3;
+        for (int i = tid; i < Dpad; i += ST_THREADS) sq[i] = i < D ? q[i] : 0.f;
+        __syncthreads();
+        if (tid != 0) return;
+        Acc<ORDER> a;
+        a.zero();
+        const int dmain = D & ~3;
+#pragma unroll 8
+        for (int i = 0; i < dmain; i += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(&sq[i]);
+            a.template add<0>(v.x * v.x);
+            a.template add<1>(v.y * v.y);
+            a.template add<2>(v.z * v.z);
+            a.template add<3>(v.w * v.w);
+        }
+        for (int i = dmain; i < D; i++) a.add_tail(sq[i] * sq[i]);
+        qna[j] = a.total();
+        return;
+    }
+    const int q = qsel ? qsel[blockIdx.x] : blockIdx.x;
+    const uint64_t *list = cs.lists + (size_t)q * cs.cap;
+    uint64_t e[ST_PER];
+#pragma unroll
+    for (int i = 0; i < ST_PER; i++) {
+        const uint32_t idx = (uint32_t)tid + (uint32_t)ST_THREADS * i;
+        e[i] = idx < count ? list[idx] : kEntryMax;
+    }
+    uint64_t lo = 0; // entries are unique: round r takes the smallest entry >= lo
+    uint64_t kth = kEntryMax;
+    for (int r = 0; r < m; r++) {
+        uint64_t v = kEntryMax;
+#pragma unroll
+        for (int i = 0; i < ST_PER; i++)
+            if (e[i] >= lo && e[i] < v) v = e[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint64_t o = __shfl_xor(v, off);
+            v = o < v ? o : v;
+        }
+        if (lane == 0) wmin[r & 1][wave] = v;
+        __syncthreads();
+        v = wmin[r & 1][lane & (ST_THREADS / 64 - 1)];
+#pragma unroll
+        for (int off = ST_THREADS / 128; off > 0; off >>= 1) {
+            const uint64_t o = __shfl_xor(v, off);
+            v = o < v ? o : v;
+        }
+        kth = v;
+        if (v == kEntryMax) break; // fewer than m visible sample rows: no threshold
+        lo = v + 1;
+    }
+    if (tid == 0) {
+        cs.tau[q] = kth == kEntryMax ? kEntryMax : (kth | 0xffffffffull);
+        cs.cnt[q] = 0;
+    }
+}
+
+bool sample_tau_supported(uint32_t count, int m) { return count <= (uint32_t)(ST_THREADS * ST_PER) && m >= 1 && m <= 64; }
+
+void launch_sample_tau(int order, CandState cs, const int *qsel, int nsel, uint32_t count, int m, const float *Q, int D,
+                       float *qna, hipStream_t s)
+{
+    if (nsel <= 0) return;
+    dim3 grid(qna ? 2 * nsel : nsel), block(ST_THREADS);
+    const size_t shmem = qna ? (size_t)((D + 3) & ~3) * sizeof(float) : 0;
+    if (order == ORDER_UNROLL4)
+        hipLaunchKernelGGL(sample_tau_kernel<ORDER_UNROLL4>, grid, block, shmem, s, cs, qsel, nsel, count, m, Q, D, qna);
+    else
+        hipLaunchKernelGGL(sample_tau_kernel<ORDER_SEQ>, grid, block, shmem, s, cs, qsel, nsel, count, m, Q, D, qna);
+}
+
+int g_scan_nbuf = [] { const char *e = getenv("LB_SCAN_NBUF"); return e ? atoi(e) : 1; }();
+
+template <int METRIC, int ORDER, int NQ>
+static void launch_scan_variant(dim3 grid, hipStream_t s, const ScanArgs &a)
+{
+    if (g_scan_nbuf == 1) {
+        if (a.rowmap) hipLaunchKernelGGL((scan_kernel<METRIC, ORDER, NQ, true, 1>), grid, dim3(SC_ROWS), 0, s, a);
+        else hipLaunchKernelGGL((scan_kernel<METRIC, ORDER, NQ, false, 1>), grid, dim3(SC_ROWS), 0, s, a);
+    } else {
+        if (a.rowmap) hipLaunchKernelGGL((scan_kernel<METRIC, ORDER, NQ, true, 2>), grid, dim3(SC_ROWS), 0, s, a);
+        else hipLaunchKernelGGL((scan_kernel<METRIC, ORDER, NQ, false, 2>), grid, dim3(SC_ROWS), 0, s, a);
+    }
+}
+
 template <int METRIC, int ORDER>
 static void launch_scan_nq(int nq_t, dim3 grid, hipStream_t s, const ScanArgs &a)
 {
     switch (nq_t) {
-    case 1:
-        if (a.rowmap) hipLaunchKernelGGL((scan_kernel<METRIC, ORDER, 1, true>), grid, dim3(SC_ROWS), 0, s, a);
-        else hipLaunchKernelGGL((scan_kernel<METRIC, ORDER, 1, false>), grid, dim3(SC_ROWS), 0, s, a);
-        break;
-    case 2:
-        if (a.rowmap) hipLaunchKernelGGL((scan_kernel<METRIC, ORDER, 2, true>), grid, dim3(SC_ROWS), 0, s, a);
-        else hipLaunchKernelGGL((scan_kernel<METRIC, ORDER, 2, false>), grid, dim3(SC_ROWS), 0, s, a);
-        break;
-    case 4:
-        if (a.rowmap) hipLaunchKernelGGL((scan_kernel<METRIC, ORDER, 4, true>), grid, dim3(SC_ROWS), 0, s, a);
-        else hipLaunchKernelGGL((scan_kernel<METRIC, ORDER, 4, false>), grid, dim3(SC_ROWS), 0, s, a);
-        break;
-    default:
-        if (a.rowmap) hipLaunchKernelGGL((scan_kernel<METRIC, ORDER, 8, true>), grid, dim3(SC_ROWS), 0, s, a);
-        else hipLaunchKernelGGL((scan_kernel<METRIC, ORDER, 8, false>), grid, dim3(SC_ROWS), 0, s, a);
-        break;
+    case 1: launch_scan_variant<METRIC, ORDER, 1>(grid, s, a); break;
+    case 2: launch_scan_variant<METRIC, ORDER, 2>(grid, s, a); break;
+    case 4: launch_scan_variant<METRIC, ORDER, 4>(grid, s, a); break;
+    default: launch_scan_variant<METRIC, ORDER, 8>(grid, s, a); break;
     }
 }
 
@@ -411,8 +650,9 @@ void launch_scan(int metric, int order, bool raw_dot, const float *X, int64_t ro
         return;
     }
     const int64_t ntiles = (row_end - row_begin + SC_ROWS - 1) / SC_ROWS;
-    // 69.6 KB LDS per workgroup -> 2 workgroups per CU; 256 CUs.
-    const int64_t maxgrid = 256 * 2 * 2;
+    // 69.6 KB (2 stages) / 34.8 KB (1 stage) LDS per workgroup -> 2 / 4 workgroups per CU; 256 CUs.
+    static const int waves_mult = [] { const char *e = getenv("LB_SCAN_GRIDMULT"); return e ? atoi(e) : 4; }();
+    const int64_t maxgrid = 256 * (g_scan_nbuf == 1 ? 4 : 2) * waves_mult;
     dim3 grid((unsigned)(ntiles < maxgrid ? ntiles : maxgrid));
     int nq_t = nsel <= 1 ? 1 : nsel <= 2 ? 2 : nsel <= 4 ? 4 : 8;
 #define LB_SCAN(M)                                                                       \

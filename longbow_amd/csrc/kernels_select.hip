@@ -92,8 +92,12 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
 
 template <int NT> // threads per workgroup: 256 (throughput, many queries) or 1024 (latency, few queries)
 __global__ __launch_bounds__(NT) void select_kernel(CandState cs, const int *qsel, int kc,
-                                                             uint32_t boot_rows)
+                                                             uint32_t boot_rows, uint32_t tau_only,
+                                                             uint32_t need_at_least)
 {
+    // tau_only: the list holds a *sample* of the rows; publish its kc-th entry (row bits saturated) as
+    // the admission threshold and leave the list empty.  need_at_least: a list shorter than this means a
+    // sampled threshold admitted too few rows -> flag bit 2, the query is redone without sampling.
     extern __shared__ __attribute__((aligned(16))) uint64_t sh[];
     const int q = qsel ? qsel[blockIdx.x] : blockIdx.x;
     const int tid = threadIdx.x;
@@ -104,13 +108,17 @@ __global__ __launch_bounds__(NT) void select_kernel(CandState cs, const int *qse
     uint64_t *list = cs.lists + (size_t)q * cs.cap;
     if (raw > cs.cap && tid == 0) atomicOr(&cs.flags[q], 1u);
     if (n == 0) {
-        if (tid == 0) { cs.tau[q] = kEntryMax; cs.cnt[q] = 0; }
+        if (tid == 0) {
+            cs.tau[q] = kEntryMax;
+            cs.cnt[q] = 0;
+            if (need_at_least) atomicOr(&cs.flags[q], 4u);
+        }
         return;
     }
     const uint32_t P = next_pow2(n);
     uint32_t *hist = reinterpret_cast<uint32_t *>(sh + next_pow2(cs.cap));
     uint32_t *wsum = hist + 256;
-    uint32_t *scal = wsum + 4; // [0]=bucket [1]=need [2]=out counter [3]=valid count
+    uint32_t *scal = wsum + 4; // [0]=bucket [1]=need [2]=out counter [3]=valid count [4]=take the whole bucket
 
     if (tid == 0) { scal[2] = 0; scal[3] = 0; }
     uint32_t myvalid = 0;
@@ -126,14 +134,26 @@ __global__ __launch_bounds__(NT) void select_kernel(CandState cs, const int *qse
         n = scal[3];
         __syncthreads();
         if (n == 0) {
-            if (tid == 0) { cs.tau[q] = kEntryMax; cs.cnt[q] = 0; }
+            if (tid == 0) {
+                cs.tau[q] = kEntryMax;
+                cs.cnt[q] = 0;
+                if (need_at_least) atomicOr(&cs.flags[q], 4u);
+            }
             return;
         }
     }
     const uint32_t keep = n < (uint32_t)kc ? n : (uint32_t)kc;
+    if (n < need_at_least && tid == 0) atomicOr(&cs.flags[q], 4u);
 
     if (P <= 2u * next_pow2((uint32_t)kc) || n <= (uint32_t)kc) {
         bitonic_sort_u64(sh, P, tid, NT); // kEntryMax padding sorts last
+        if (tau_only) {
+            if (tid == 0) {
+                cs.cnt[q] = 0;
+                cs.tau[q] = n >= (uint32_t)kc ? (sh[kc - 1] | 0xffffffffull) : kEntryMax;
+            }
+            return;
+        }
         for (uint32_t i = tid; i < keep; i += NT) list[i] = sh[i];
         if (tid == 0) {
             cs.cnt[q] = keep;
@@ -189,15 +209,31 @@ __global__ __launch_bounds__(NT) void select_kernel(CandState cs, const int *qse
             for (int w = 0; w < 4; w++) base += (w < wave) ? wsum[w] : 0u;
             incl += base;
             const uint32_t excl = incl - h;
-            if (excl < need && need <= incl) { scal[0] = (uint32_t)tid; scal[1] = need - excl; }
+            if (excl < need && need <= incl) {
+                scal[0] = (uint32_t)tid;
+                scal[1] = need - excl;
+                scal[4] = (need == incl) ? 1u : 0u; // the whole bucket is wanted: no need to split it further
+            }
         }
         __syncthreads();
         prefix |= (uint64_t)scal[0] << shift;
         mask |= 0xffull << shift;
         need = scal[1];
+        const bool whole_bucket = scal[4] != 0u;
         __syncthreads();
+        if (whole_bucket) { // (entries are unique, so the row bytes are rarely ever walked)
+            prefix |= ~mask; // every entry sharing the resolved bytes is kept; this bound is >= the kc-th entry
+            break;
+        }
     }
-    const uint64_t pivot = prefix; // the kc-th smallest entry
+    const uint64_t pivot = prefix; // >= the kc-th smallest entry and < the (kc+1)-th: exactly kc entries are <= pivot
+    if (tau_only) {
+        if (tid == 0) {
+            cs.cnt[q] = 0;
+            cs.tau[q] = pivot | 0xffffffffull;
+        }
+        return;
+    }
     // compact the kc entries <= pivot into the front of the global list (unordered), then sort them
     __syncthreads();
     for (uint32_t i = tid; i < P; i += NT) {
@@ -219,16 +255,35 @@ __global__ __launch_bounds__(NT) void select_kernel(CandState cs, const int *qse
     }
 }
 
-void launch_select(CandState cs, const int *qsel, int nsel, int kc, uint32_t boot_rows, hipStream_t s)
+// smap[i] = corpus row behind the i-th of `count` evenly spaced positions of [0, span)
+__global__ __launch_bounds__(256) void sample_map_kernel(const uint32_t *rowmap, int64_t span, uint32_t count,
+                                                         uint32_t *smap)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= count) return;
+    const int64_t pos = (int64_t)(((uint64_t)i * (uint64_t)span) / count); // i, span < 2^32
+    smap[i] = rowmap ? rowmap[pos] : (uint32_t)pos;
+}
+
+void launch_sample_map(const uint32_t *rowmap, int64_t span, uint32_t count, uint32_t *smap, hipStream_t s)
+{
+    if (count == 0) return;
+    hipLaunchKernelGGL(sample_map_kernel, dim3((count + 255) / 256), dim3(256), 0, s, rowmap, span, count, smap);
+}
+
+void launch_select(CandState cs, const int *qsel, int nsel, int kc, uint32_t boot_rows, hipStream_t s,
+                   bool tau_only, uint32_t need_at_least)
 {
     if (nsel <= 0) return;
-    const size_t shmem = (size_t)next_pow2_host(cs.cap) * sizeof(uint64_t) + (256 + 4 + 4) * sizeof(uint32_t);
+    const size_t shmem = (size_t)next_pow2_host(cs.cap) * sizeof(uint64_t) + (256 + 4 + 8) * sizeof(uint32_t);
     if (nsel <= 32) { // few queries: one big workgroup each, latency matters
         allow_big_lds(select_kernel<1024>, shmem);
-        hipLaunchKernelGGL(select_kernel<1024>, dim3(nsel), dim3(1024), shmem, s, cs, qsel, kc, boot_rows);
+        hipLaunchKernelGGL(select_kernel<1024>, dim3(nsel), dim3(1024), shmem, s, cs, qsel, kc, boot_rows,
+                           tau_only ? 1u : 0u, need_at_least);
     } else {
         allow_big_lds(select_kernel<256>, shmem);
-        hipLaunchKernelGGL(select_kernel<256>, dim3(nsel), dim3(256), shmem, s, cs, qsel, kc, boot_rows);
+        hipLaunchKernelGGL(select_kernel<256>, dim3(nsel), dim3(256), shmem, s, cs, qsel, kc, boot_rows,
+                           tau_only ? 1u : 0u, need_at_least);
     }
 }
 

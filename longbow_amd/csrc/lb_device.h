@@ -69,7 +69,7 @@ struct CandState {
     uint64_t *lists; // [nq][cap] entries; [0,cnt) valid
     uint32_t *cnt;   // [nq] appended so far (may exceed cap -> overflow)
     uint64_t *tau;   // [nq] admission threshold: entry admitted iff e < tau
-    uint32_t *flags; // [nq] bit0 = list overflowed, bit1 = containment bound failed
+    uint32_t *flags; // [nq] bit0 = list overflowed, bit1 = containment bound failed, bit2 = sampled threshold too tight
     uint32_t cap;
 };
 
@@ -99,7 +99,21 @@ void launch_split_bf16(const float *src, float *dst, int64_t rows, int D, hipStr
 // per query: sort the list, keep the best kc, tau = kc-th entry (or max), flag overflow.
 // qsel (nullable): only these query slots.  boot_rows > 0: the list was filled by a bootstrap
 // launch (one entry per row at index row - row_begin, no atomics; masked rows hold kEntryMax).
-void launch_select(CandState cs, const int *qsel, int nsel, int kc, uint32_t boot_rows, hipStream_t s);
+// tau_only: the list is a row *sample*; publish its kc-th entry as threshold and empty the list.
+// need_at_least: flag bit 2 when fewer entries than this were admitted (sampled threshold too tight).
+void launch_select(CandState cs, const int *qsel, int nsel, int kc, uint32_t boot_rows, hipStream_t s,
+                   bool tau_only = false, uint32_t need_at_least = 0);
+// approximate distances of `count` evenly spaced positions of [0, span) for up to 8 query slots, written
+// as entries to lists[q][0..count) (also clears the slots' flags)
+void launch_sample_scores(int metric, const float *X, int D, int64_t span, uint32_t count, const uint32_t *rowmap,
+                          const uint8_t *mask, const float *Q, const int *qsel, int nsel, CandState cs, hipStream_t s);
+// tau[q] = m-th smallest of lists[q][0..count) with the row bits saturated, cnt[q] = 0; with qna != null the
+// same launch also computes the exact query norms of the slots (cosine)
+bool sample_tau_supported(uint32_t count, int m);
+void launch_sample_tau(int order, CandState cs, const int *qsel, int nsel, uint32_t count, int m, const float *Q, int D,
+                       float *qna, hipStream_t s);
+// smap[i] = row behind the i-th of `count` evenly spaced positions of [0, span) (through rowmap if given)
+void launch_sample_map(const uint32_t *rowmap, int64_t span, uint32_t count, uint32_t *smap, hipStream_t s);
 
 // exact-order distances of the kept candidates, final ordering, containment check, output.
 // gamma: relative rounding-error bound of the candidate inner products (depends on the contraction)

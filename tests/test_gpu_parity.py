@@ -212,6 +212,44 @@ def test_selective_filter_walks_compacted_row_list(oracle):
         idx.Close()
 
 
+def test_sampled_threshold_first_pass(oracle):
+    """corpora >= 64k rows take a strided row sample's m-th best entry as admission threshold and walk
+    the rows once; the classic bootstrap schedule is the fallback.  Both must equal the oracle on random,
+    sorted (worst->best and best->worst), and heavily duplicated corpora, on every search path."""
+    lib = gpu_or_skip()
+    rng = np.random.default_rng(2024)
+    n, d = 150_000, 32
+    base = rng.random((n, d), dtype=F)
+    q = rng.random(d, dtype=F)
+    dist = oracle.batch_flat(0, q, base)
+    corpora = {
+        "random": base,
+        "worst_first": base[np.argsort(-dist)],
+        "best_first": base[np.argsort(dist)],
+        "duplicates": base[rng.integers(0, 40, n)],   # 40 distinct vectors: thresholds tie massively
+    }
+    Q = np.concatenate([np.stack([q + F(1e-3) * rng.random(d, dtype=F) for _ in range(8)]),
+                        rng.random((192, d), dtype=F)])
+    try:
+        for name, X in corpora.items():
+            for metric in (0, 1, 2):
+                idx = new_index(d, metric)
+                idx.Add(None, X)
+                want = {}
+                for nq in (1, 3, 8, 40, 200):
+                    want[nq] = oracle.search_batch(metric, Q[:nq], X, 20, nthreads=8)
+                for sampled in (1, 0):
+                    lib.lb_debug_set_sample_tau(sampled)
+                    for nq in (1, 3, 8, 40, 200):
+                        lab, dd = idx.SearchBatch(Q[:nq], 20)
+                        assert_same(lab, dd, *want[nq], f"{name} metric {metric} nq {nq} sampled {sampled}")
+                        if name == "random" and sampled:
+                            assert idx.last_fallbacks == 0
+                idx.Close()
+    finally:
+        lib.lb_debug_set_sample_tau(1)
+
+
 def test_adversarial_order_forces_list_overflow(oracle):
     """rows sorted from worst to best: every row is admitted, the candidate lists overflow, and the
     library must fall back to overflow-proof chunking and still be exact"""
