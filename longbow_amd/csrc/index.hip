@@ -61,6 +61,7 @@ struct Workspace {
     float *d_qs = nullptr; // split-bf16 image of the query batch
     size_t d_qs_bytes = 0;
     int *d_qsel = nullptr;
+    int *d_iota = nullptr;       // [nq_cap] 0,1,2,...: the slot list of "every query", filled once
     uint32_t *d_smap = nullptr;  // [cap] sampled rows of the first pass
     uint32_t *h_flags = nullptr; // pinned
     int *h_qsel = nullptr;       // pinned
@@ -83,6 +84,7 @@ struct Workspace {
         if (d_qna) (void)hipFree(d_qna);
         if (d_qs) (void)hipFree(d_qs);
         if (d_qsel) (void)hipFree(d_qsel);
+        if (d_iota) (void)hipFree(d_iota);
         if (d_smap) (void)hipFree(d_smap);
         if (h_flags) (void)hipHostFree(h_flags);
         if (h_qsel) (void)hipHostFree(h_qsel);
@@ -209,6 +211,12 @@ std::unique_ptr<Workspace> acquire_ws(lb_gpu_index *h, int nq, uint32_t cap)
     LB_HIP(hipMalloc(&w->cs.flags, (size_t)w->nq_cap * sizeof(uint32_t)));
     LB_HIP(hipMalloc(&w->d_qna, (size_t)w->nq_cap * sizeof(float)));
     LB_HIP(hipMalloc(&w->d_qsel, (size_t)w->nq_cap * sizeof(int)));
+    LB_HIP(hipMalloc(&w->d_iota, (size_t)w->nq_cap * sizeof(int)));
+    {
+        std::vector<int> iota((size_t)w->nq_cap);
+        for (int i = 0; i < w->nq_cap; i++) iota[(size_t)i] = i;
+        LB_HIP(hipMemcpy(w->d_iota, iota.data(), iota.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
     LB_HIP(hipMalloc(&w->d_smap, (size_t)cap * sizeof(uint32_t)));
     LB_HIP(hipHostMalloc(&w->h_flags, (size_t)w->nq_cap * sizeof(uint32_t), hipHostMallocDefault));
     LB_HIP(hipHostMalloc(&w->h_qsel, (size_t)w->nq_cap * sizeof(int), hipHostMallocDefault));
@@ -360,16 +368,18 @@ bool run_scan_path(lb_gpu_index *h, Workspace *w, hipStream_t s, const float *d_
             pos = end;
             step++;
         }
-        launch_emit_lists(w->cs, use_sel, gn, k, h->has_ids ? h->d_ids : nullptr, d_dist, d_lab, s);
+        launch_emit_lists(w->cs, use_sel, gn, k, h->has_ids ? h->d_ids : nullptr, d_dist, d_lab, w->h_flags, s);
     }
     return sp.on;
 }
 
 // download flags for slots [0,nq) and return those with any of `bits` set
+// (on_host: the last kernel already wrote the subset's flags into the pinned h_flags)
 int collect_flagged(Workspace *w, hipStream_t s, int nq, uint32_t bits, const int *h_subset,
-                    int nsubset, std::vector<int> &out)
+                    int nsubset, std::vector<int> &out, bool on_host = false)
 {
-    LB_HIP(hipMemcpyAsync(w->h_flags, w->cs.flags, (size_t)nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (!on_host)
+        LB_HIP(hipMemcpyAsync(w->h_flags, w->cs.flags, (size_t)nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     LB_HIP(hipStreamSynchronize(s));
     out.clear();
     if (h_subset) {
@@ -392,16 +402,19 @@ void scan_with_retry(lb_gpu_index *h, Workspace *w, hipStream_t s, const float *
                      const std::vector<int> &sel, int k, float *d_dist, int64_t *d_lab, bool prof)
 {
     if (sel.empty()) return;
-    upload_sel(w, s, sel);
-    const bool sampled = run_scan_path(h, w, s, d_q, w->d_qsel, (int)sel.size(), k, 0, d_dist, d_lab, prof);
+    bool identity = true; // "all queries": the prefilled list saves an upload on the latency path
+    for (size_t i = 0; i < sel.size() && identity; i++) identity = sel[i] == (int)i;
+    if (!identity) upload_sel(w, s, sel);
+    const bool sampled = run_scan_path(h, w, s, d_q, identity ? w->d_iota : w->d_qsel, (int)sel.size(), k, 0,
+                                       d_dist, d_lab, prof);
     std::vector<int> redo, over;
-    if (collect_flagged(w, s, nq_total, 1u | 4u, sel.data(), (int)sel.size(), redo) > 0) {
+    if (collect_flagged(w, s, nq_total, 1u | 4u, sel.data(), (int)sel.size(), redo, true) > 0) {
         // the sampled threshold missed (or a list overflowed): classic schedule, then overflow-proof chunks
         if (sampled) {
             upload_sel(w, s, redo);
             run_scan_path(h, w, s, d_q, w->d_qsel, (int)redo.size(), k, 1, d_dist, d_lab, prof);
         }
-        if (!sampled || collect_flagged(w, s, nq_total, 1u, redo.data(), (int)redo.size(), over) > 0) {
+        if (!sampled || collect_flagged(w, s, nq_total, 1u, redo.data(), (int)redo.size(), over, true) > 0) {
             if (!sampled) over = redo;
             upload_sel(w, s, over);
             run_scan_path(h, w, s, d_q, w->d_qsel, (int)over.size(), k, 2, d_dist, d_lab, prof);

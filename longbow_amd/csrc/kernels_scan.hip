@@ -153,6 +153,45 @@ __global__ __launch_bounds__(SC_ROWS) void scan_kernel(ScanArgs a)
     Acc<ORDER> acc[NQ]; // L2: sum (q-x)^2 ; cos/dot: sum q*x
     Acc<ORDER> nb;      // cos: sum x*x
 
+    // finished tile waiting for admission (done right after the next stage's loads are issued, so the
+    // returning atomic's latency overlaps the stream instead of draining it)
+    float pend_dist[NQ];
+    int64_t pend_tile = -1;
+    auto flush = [&]() {
+        const int64_t myrow = a.row_begin + pend_tile * SC_ROWS + tid;
+        const bool valid = myrow < a.row_end;
+        int64_t arow = myrow; // corpus row behind position myrow
+        if (MAPPED) arow = a.rowmap[valid ? myrow : a.row_end - 1];
+        const bool masked_out = valid && a.all_out == nullptr && a.mask != nullptr && !a.mask[arow];
+        if (valid && a.boot && masked_out) {
+#pragma unroll
+            for (int j = 0; j < NQ; j++)
+                if (j < a.nsel) a.cs.lists[(size_t)qidx[j] * a.cs.cap + (myrow - a.row_begin)] = kEntryMax;
+        }
+        if (valid && !masked_out) {
+#pragma unroll
+            for (int j = 0; j < NQ; j++) {
+                if (j >= a.nsel) break;
+                const float dist = pend_dist[j];
+                if (a.all_out) {
+                    a.all_out[(int64_t)j * a.ld + myrow] = dist;
+                } else {
+                    const uint64_t ent = pack_entry(dist, (uint32_t)arow);
+                    const int qj = qidx[j];
+                    if (a.boot) {
+                        a.cs.lists[(size_t)qj * a.cs.cap + (myrow - a.row_begin)] = ent;
+                    } else if (ent < tau[j]) {
+                        // (a returning atomic on one hot counter: measured 6-20 ns apiece in the 1-query
+                        // scan, which is why the sampled threshold aims at ~1.2k admissions, not cap/2)
+                        uint32_t pos = atomicAdd(&a.cs.cnt[qj], 1u);
+                        if (pos < a.cs.cap) a.cs.lists[(size_t)qj * a.cs.cap + pos] = ent;
+                    }
+                }
+            }
+        }
+        pend_tile = -1;
+    };
+
     int64_t tile = blockIdx.x;
     int c = 0, cur = 0;
     load_stage(tile, 0);
@@ -168,6 +207,7 @@ __global__ __launch_bounds__(SC_ROWS) void scan_kernel(ScanArgs a)
         }
         const bool has_next = ntile < ntiles;
         if (has_next) load_stage(ntile, nc);
+        if (pend_tile >= 0) flush();
         if (c == 0) {
 #pragma unroll
             for (int j = 0; j < NQ; j++) acc[j].zero();
@@ -214,50 +254,27 @@ __global__ __launch_bounds__(SC_ROWS) void scan_kernel(ScanArgs a)
             write_stage(cur ^ 1);
         }
 
-        if (c == nchunks - 1) { // the tile's distances are complete
-            const int64_t myrow = a.row_begin + tile * SC_ROWS + tid;
-            const bool valid = myrow < a.row_end;
-            int64_t arow = myrow; // corpus row behind position myrow
-            if (MAPPED) arow = a.rowmap[valid ? myrow : a.row_end - 1];
-            const bool masked_out = valid && a.all_out == nullptr && a.mask != nullptr && !a.mask[arow];
-            if (valid && a.boot && masked_out) {
+        if (c == nchunks - 1) { // the tile's distances are complete: park them, admission runs under the next loads
+            const float nbt = nb.total();
 #pragma unroll
-                for (int j = 0; j < NQ; j++)
-                    if (j < a.nsel) a.cs.lists[(size_t)qidx[j] * a.cs.cap + (myrow - a.row_begin)] = kEntryMax;
-            }
-            if (valid && !masked_out) {
-                const float nbt = nb.total();
-#pragma unroll
-                for (int j = 0; j < NQ; j++) {
-                    if (j >= a.nsel) break;
-                    const float t = acc[j].total();
-                    float dist;
-                    if (METRIC == METRIC_L2) {
-                        dist = (float)sqrt((double)t);
-                    } else if (METRIC == METRIC_COS) {
-                        const float na = a.qna[j];
-                        if (D == 0 || na == 0.0f || nbt == 0.0f) dist = 1.0f;
-                        else {
-                            const float den = (float)sqrt((double)na * (double)nbt);
-                            dist = 1.0f - __fdiv_rn(t, den);
-                        }
-                    } else {
-                        dist = a.raw_dot ? t : -t;
+            for (int j = 0; j < NQ; j++) {
+                const float t = acc[j].total();
+                float dist;
+                if (METRIC == METRIC_L2) {
+                    dist = (float)sqrt((double)t);
+                } else if (METRIC == METRIC_COS) {
+                    const float na = a.qna[j < a.nsel ? j : 0];
+                    if (D == 0 || na == 0.0f || nbt == 0.0f) dist = 1.0f;
+                    else {
+                        const float den = (float)sqrt((double)na * (double)nbt);
+                        dist = 1.0f - __fdiv_rn(t, den);
                     }
-                    if (a.all_out) {
-                        a.all_out[(int64_t)j * a.ld + myrow] = dist;
-                    } else {
-                        const uint64_t ent = pack_entry(dist, (uint32_t)arow);
-                        const int qj = qidx[j];
-                        if (a.boot) {
-                            a.cs.lists[(size_t)qj * a.cs.cap + (myrow - a.row_begin)] = ent;
-                        } else if (ent < tau[j]) {
-                            uint32_t pos = atomicAdd(&a.cs.cnt[qj], 1u);
-                            if (pos < a.cs.cap) a.cs.lists[(size_t)qj * a.cs.cap + pos] = ent;
-                        }
-                    }
+                } else {
+                    dist = a.raw_dot ? t : -t;
                 }
+                pend_dist[j] = dist;
             }
+            pend_tile = tile;
         }
         __syncthreads();
         if (!has_next) break;
@@ -265,6 +282,7 @@ __global__ __launch_bounds__(SC_ROWS) void scan_kernel(ScanArgs a)
         c = nc;
         if (NBUF == 2) cur ^= 1;
     }
+    if (pend_tile >= 0) flush();
 }
 
 

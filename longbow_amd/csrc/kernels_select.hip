@@ -662,11 +662,13 @@ void launch_rerank(int metric, int order, const float *X, int D, const float *Q,
 // ---------------------------------------------------------------------------
 // scan path: lists already hold exact distances, sorted by the last select.
 __global__ void emit_lists_kernel(CandState cs, const int *qsel, int nsel, int k, const int64_t *ids,
-                                  float *out_dist, int64_t *out_labels)
+                                  float *out_dist, int64_t *out_labels, uint32_t *flags_host)
 {
     const int j = blockIdx.x;
     if (j >= nsel) return;
     const int q = qsel ? qsel[j] : j;
+    // the slot's status word goes straight to pinned host memory: no separate D2H copy after the search
+    if (flags_host && threadIdx.x == 0) flags_host[q] = cs.flags[q];
     const uint32_t n = cs.cnt[q];
     const uint64_t *list = cs.lists + (size_t)q * cs.cap;
     for (int r = threadIdx.x; r < k; r += blockDim.x) {
@@ -684,11 +686,11 @@ __global__ void emit_lists_kernel(CandState cs, const int *qsel, int nsel, int k
 }
 
 void launch_emit_lists(CandState cs, const int *qsel, int nsel, int k, const int64_t *ids,
-                       float *out_dist, int64_t *out_labels, hipStream_t s)
+                       float *out_dist, int64_t *out_labels, uint32_t *flags_host, hipStream_t s)
 {
     if (nsel <= 0) return;
     hipLaunchKernelGGL(emit_lists_kernel, dim3(nsel), dim3(128), 0, s, cs, qsel, nsel, k, ids, out_dist,
-                       out_labels);
+                       out_labels, flags_host);
 }
 
 // ---------------------------------------------------------------------------

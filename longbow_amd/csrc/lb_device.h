@@ -135,7 +135,7 @@ void launch_scan(int metric, int order, bool raw_dot, const float *X, int64_t ro
 
 // after the last select of the scan path: lists already hold exact distances.
 void launch_emit_lists(CandState cs, const int *qsel, int nsel, int k, const int64_t *ids,
-                       float *out_dist, int64_t *out_labels, hipStream_t s);
+                       float *out_dist, int64_t *out_labels, uint32_t *flags_host, hipStream_t s);
 
 void launch_init_cand(CandState cs, const int *qsel, int nsel, hipStream_t s);
 

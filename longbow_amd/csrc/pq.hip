@@ -267,7 +267,7 @@ int lb_gpu_pq_search_device(lb_gpu_pq *p, int64_t nq, const float *d_queries, in
         LBP_HIP(hipStreamSynchronize(s));
         for (int q = 0; q < nqi; q++)
             if (flags[q] & 1u) scan_query(q, true); // chunks that cannot overflow the list
-        launch_emit_lists(sc.cs, nullptr, nqi, k, nullptr, d_dist, d_labels, s);
+        launch_emit_lists(sc.cs, nullptr, nqi, k, nullptr, d_dist, d_labels, nullptr, s);
         LBP_HIP(hipStreamSynchronize(s));
     } catch (const HipErrP &e) {
         return pq_fail(p, e);
