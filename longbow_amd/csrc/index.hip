@@ -81,6 +81,7 @@ struct Workspace {
         if (cs.cnt) (void)hipFree(cs.cnt);
         if (cs.tau) (void)hipFree(cs.tau);
         if (cs.flags) (void)hipFree(cs.flags);
+        if (cs.stripes) (void)hipFree(cs.stripes);
         if (d_qna) (void)hipFree(d_qna);
         if (d_qs) (void)hipFree(d_qs);
         if (d_qsel) (void)hipFree(d_qsel);
@@ -209,6 +210,7 @@ std::unique_ptr<Workspace> acquire_ws(lb_gpu_index *h, int nq, uint32_t cap)
     LB_HIP(hipMalloc(&w->cs.cnt, (size_t)w->nq_cap * sizeof(uint32_t)));
     LB_HIP(hipMalloc(&w->cs.tau, (size_t)w->nq_cap * sizeof(uint64_t)));
     LB_HIP(hipMalloc(&w->cs.flags, (size_t)w->nq_cap * sizeof(uint32_t)));
+    LB_HIP(hipMalloc(&w->cs.stripes, (size_t)kScanMaxQ * LB_STRIPES * LB_STRIPE_PAD * sizeof(uint32_t)));
     LB_HIP(hipMalloc(&w->d_qna, (size_t)w->nq_cap * sizeof(float)));
     LB_HIP(hipMalloc(&w->d_qsel, (size_t)w->nq_cap * sizeof(int)));
     LB_HIP(hipMalloc(&w->d_iota, (size_t)w->nq_cap * sizeof(int)));
@@ -333,22 +335,25 @@ bool run_scan_path(lb_gpu_index *h, Workspace *w, hipStream_t s, const float *d_
         const int *use_sel = d_sel + g0; // d_sel is always an explicit slot list here
         int64_t pos = 0;
         int step = 0;
+        bool emitted = false;
+        const EmitArgs em{k, h->has_ids ? h->d_ids : nullptr, d_dist, d_lab, w->h_flags};
         if (sp.on) {
-            {   // sample scores (clears the flags), then threshold + exact query norms in one launch
+            {   // sample scores (clear the flags; exact query norms ride along), threshold, one pass
                 ProfScope p(w, s, prof, 3);
-                launch_sample_scores(metric, h->d_X, h->dim, sp.span, sp.count, rv.rowmap, mask, d_q, use_sel, gn,
-                                     w->cs, s);
-                launch_sample_tau(order, w->cs, use_sel, gn, sp.count, sp.m, d_q, h->dim,
-                                  metric == LB_METRIC_COSINE ? w->d_qna : nullptr, s);
+                launch_sample_scores(metric, order, h->d_X, h->dim, sp.span, sp.count, rv.rowmap, mask, d_q, use_sel,
+                                     gn, w->cs, w->d_qna, s);
+                launch_sample_tau(w->cs, use_sel, gn, sp.count, sp.m, /*zero_stripes=*/true, s);
                 launch_scan(metric, order, false, h->d_X, 0, sp.span, h->dim, d_q, use_sel, gn, w->d_qna, mask,
-                            rv.rowmap, w->cs, /*boot=*/false, nullptr, 0, s);
+                            rv.rowmap, w->cs, /*boot=*/false, nullptr, 0, s, /*striped=*/true);
             }
             {
                 ProfScope p(w, s, prof, 1);
-                launch_select(w->cs, use_sel, gn, kkeep, 0u, s, false, (uint32_t)kkeep);
+                launch_select(w->cs, use_sel, gn, kkeep, 0u, s, false, (uint32_t)kkeep, sp.span >= n ? &em : nullptr,
+                              /*striped=*/true);
             }
             pos = sp.span;
             step = 1;
+            emitted = sp.span >= n;
         } else if (metric == LB_METRIC_COSINE) {
             ProfScope p(w, s, prof, 3);
             launch_query_norms(order, d_q, use_sel, gn, h->dim, w->d_qna, s);
@@ -363,12 +368,15 @@ bool run_scan_path(lb_gpu_index *h, Workspace *w, hipStream_t s, const float *d_
             }
             {
                 ProfScope p(w, s, prof, 1);
-                launch_select(w->cs, use_sel, gn, kkeep, boot ? (uint32_t)(end - pos) : 0u, s);
+                launch_select(w->cs, use_sel, gn, kkeep, boot ? (uint32_t)(end - pos) : 0u, s, false, 0u,
+                              end >= n ? &em : nullptr);
             }
+            emitted = end >= n;
             pos = end;
             step++;
         }
-        launch_emit_lists(w->cs, use_sel, gn, k, h->has_ids ? h->d_ids : nullptr, d_dist, d_lab, w->h_flags, s);
+        if (!emitted) // (only an empty corpus view gets here)
+            launch_emit_lists(w->cs, use_sel, gn, k, h->has_ids ? h->d_ids : nullptr, d_dist, d_lab, w->h_flags, s);
     }
     return sp.on;
 }
@@ -485,7 +493,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         candidates(0, sp.count, w->d_smap, /*boot=*/true);
         {
             ProfScope p(w, s, prof, 1);
-            launch_sample_tau(order, w->cs, nullptr, nq, sp.count, sp.m, d_q, h->dim, nullptr, s);
+            launch_sample_tau(w->cs, nullptr, nq, sp.count, sp.m, false, s);
         }
         candidates(0, sp.span, rv.rowmap, /*boot=*/false);
         {

@@ -39,6 +39,7 @@ struct ScanArgs {
     int raw_dot;
     int aligned;
     int boot;
+    int striped; // admissions go through cs.stripes (slot = position in the launch's slot list)
 };
 
 template <int ORDER>
@@ -183,7 +184,13 @@ __global__ __launch_bounds__(SC_ROWS) void scan_kernel(ScanArgs a)
                     } else if (ent < tau[j]) {
                         // (a returning atomic on one hot counter: measured 6-20 ns apiece in the 1-query
                         // scan, which is why the sampled threshold aims at ~1.2k admissions, not cap/2)
-                        uint32_t pos = atomicAdd(&a.cs.cnt[qj], 1u);
+                        uint32_t pos;
+                        if (a.striped) {
+                            const uint32_t st = blockIdx.x & (LB_STRIPES - 1);
+                            pos = st + LB_STRIPES * atomicAdd(&a.cs.stripes[(j * LB_STRIPES + st) * LB_STRIPE_PAD], 1u);
+                        } else {
+                            pos = atomicAdd(&a.cs.cnt[qj], 1u);
+                        }
                         if (pos < a.cs.cap) a.cs.lists[(size_t)qj * a.cs.cap + pos] = ent;
                     }
                 }
@@ -430,6 +437,9 @@ struct SampleArgs {
     int nsel;
     CandState cs;
     int aligned;
+    float *qna;       // cosine: exact ||q||^2 per slot, computed by `nsel` extra workgroups of this launch
+    int order;
+    uint32_t nblocks; // workgroups that score sample rows
 };
 
 __device__ __forceinline__ float wave_sum(float v)
@@ -439,12 +449,43 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+template <int ORDER>
+__device__ __forceinline__ float exact_sq_norm_lds(const float *sq, int D)
+{
+    Acc<ORDER> a;
+    a.zero();
+    const int dmain = D & ~3;
+#pragma unroll 8
+    for (int i = 0; i < dmain; i += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(&sq[i]);
+        a.template add<0>(v.x * v.x);
+        a.template add<1>(v.y * v.y);
+        a.template add<2>(v.z * v.z);
+        a.template add<3>(v.w * v.w);
+    }
+    for (int i = dmain; i < D; i++) a.add_tail(sq[i] * sq[i]);
+    return a.total();
+}
+
 template <int METRIC>
 __global__ __launch_bounds__(256) void sample_scores_kernel(SampleArgs a)
 {
+    extern __shared__ __attribute__((aligned(16))) float sq[];
+    const uint32_t nnorm = a.qna ? (uint32_t)a.nsel : 0u; // the serial norm chains are dispatched first
+    if (blockIdx.x < nnorm) { // exact ||q||^2 in the reference's order, off the critical path
+        const int j = (int)blockIdx.x;
+        const float *q = a.Q + (int64_t)(a.qsel ? a.qsel[j] : j) * a.D;
+        const int Dpad = (a.D + 3) & ~3;
+        for (int i = threadIdx.x; i < Dpad; i += 256) sq[i] = i < a.D ? q[i] : 0.f;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            a.qna[j] = a.order == ORDER_UNROLL4 ? exact_sq_norm_lds<ORDER_UNROLL4>(sq, a.D) : exact_sq_norm_lds<ORDER_SEQ>(sq, a.D);
+        return;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (blockIdx.x == 0 && (int)threadIdx.x < a.nsel) a.cs.flags[a.qsel ? a.qsel[threadIdx.x] : threadIdx.x] = 0;
-    const uint32_t i = blockIdx.x * 4u + (uint32_t)wave;
+    const uint32_t blk = blockIdx.x - nnorm;
+    if (blk == 0 && (int)threadIdx.x < a.nsel) a.cs.flags[a.qsel ? a.qsel[threadIdx.x] : threadIdx.x] = 0;
+    const uint32_t i = blk * 4u + (uint32_t)wave;
     if (i >= a.count) return;
     const int64_t pos = (int64_t)(((uint64_t)i * (uint64_t)a.span) / a.count); // i, span < 2^32
     const int64_t row = a.rowmap ? (int64_t)a.rowmap[pos] : pos;
@@ -512,56 +553,65 @@ __global__ __launch_bounds__(256) void sample_scores_kernel(SampleArgs a)
     }
 }
 
-void launch_sample_scores(int metric, const float *X, int D, int64_t span, uint32_t count, const uint32_t *rowmap,
-                          const uint8_t *mask, const float *Q, const int *qsel, int nsel, CandState cs, hipStream_t s)
+void launch_sample_scores(int metric, int order, const float *X, int D, int64_t span, uint32_t count,
+                          const uint32_t *rowmap, const uint8_t *mask, const float *Q, const int *qsel, int nsel,
+                          CandState cs, float *qna, hipStream_t s)
 {
     if (count == 0 || nsel <= 0) return;
     SampleArgs a;
+    a.qna = metric == METRIC_COS ? qna : nullptr;
+    a.order = order;
     a.X = X; a.D = D; a.span = span; a.count = count; a.rowmap = rowmap; a.mask = mask;
     a.Q = Q; a.qsel = qsel; a.nsel = nsel < SS_MAXQ ? nsel : SS_MAXQ; a.cs = cs;
     a.aligned = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && ((reinterpret_cast<uintptr_t>(Q) & 15) == 0);
-    dim3 grid((count + 3) / 4), block(256);
-    if (metric == METRIC_L2) hipLaunchKernelGGL(sample_scores_kernel<METRIC_L2>, grid, block, 0, s, a);
-    else if (metric == METRIC_COS) hipLaunchKernelGGL(sample_scores_kernel<METRIC_COS>, grid, block, 0, s, a);
-    else hipLaunchKernelGGL(sample_scores_kernel<METRIC_DOT>, grid, block, 0, s, a);
+    a.nblocks = (count + 3) / 4;
+    dim3 grid(a.nblocks + (a.qna ? (unsigned)a.nsel : 0u)), block(256);
+    const size_t shmem = a.qna ? (size_t)((D + 3) & ~3) * sizeof(float) : 0;
+    if (metric == METRIC_L2) hipLaunchKernelGGL(sample_scores_kernel<METRIC_L2>, grid, block, shmem, s, a);
+    else if (metric == METRIC_COS) hipLaunchKernelGGL(sample_scores_kernel<METRIC_COS>, grid, block, shmem, s, a);
+    else hipLaunchKernelGGL(sample_scores_kernel<METRIC_DOT>, grid, block, shmem, s, a);
 }
 
 // tau[q] = m-th smallest of the first `count` entries of list q (row bits saturated), cnt[q] = 0.
 // m is small (8..32): m rounds of a workgroup-wide minimum over register-resident entries beat a
-// radix select by 3-4x here.  Workgroups [nsel, 2*nsel) compute the exact query norms of the same
-// slots (cosine; qna != null) so that launch rides along instead of preceding the scan.
+// radix select by 3-4x here.  The wave-level minimum runs on DPP lane permutes (no LDS round trips).
 constexpr int ST_THREADS = 1024;
 constexpr int ST_PER = 8;
 
-template <int ORDER>
-__global__ __launch_bounds__(ST_THREADS) void sample_tau_kernel(CandState cs, const int *qsel, int nsel, uint32_t count,
-                                                                int m, const float *Q, int D, float *qna)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint64_t min_dpp_u64(uint64_t v)
 {
-    extern __shared__ __attribute__((aligned(16))) float sq[];
+    const int lo = (int)(uint32_t)v, hi = (int)(uint32_t)(v >> 32);
+    const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    const int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    const uint64_t o = ((uint64_t)(uint32_t)ohi << 32) | (uint64_t)(uint32_t)olo;
+    return o < v ? o : v;
+}
+// minimum over each row of 16 lanes, left in every lane of the row
+__device__ __forceinline__ uint64_t row16_min_u64(uint64_t v)
+{
+    v = min_dpp_u64<0xB1, 0xf>(v);  // quad_perm [1,0,3,2]
+    v = min_dpp_u64<0x4E, 0xf>(v);  // quad_perm [2,3,0,1]
+    v = min_dpp_u64<0x141, 0xf>(v); // row_half_mirror
+    v = min_dpp_u64<0x140, 0xf>(v); // row_mirror
+    return v;
+}
+// minimum over the 64 lanes, returned wave-uniform
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
+{
+    v = row16_min_u64(v);
+    v = min_dpp_u64<0x142, 0xa>(v); // row_bcast15: rows 1,3 <- lane 15 of rows 0,2
+    v = min_dpp_u64<0x143, 0xc>(v); // row_bcast31: rows 2,3 <- lane 31
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(ST_THREADS) void sample_tau_kernel(CandState cs, const int *qsel, int nsel, uint32_t count, int m,
+                                                                int zero_stripes)
+{
     __shared__ uint64_t wmin[2][ST_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if ((int)blockIdx.x >= nsel) { // exact ||q||^2 in the requested order (as query_norms_kernel)
-        const int j = (int)blockIdx.x - nsel;
-        const float *q = Q + (int64_t)(qsel ? qsel[j] : j) * D;
-        const int Dpad = (D + 3) & ~3;
-        for (int i = tid; i < Dpad; i += ST_THREADS) sq[i] = i < D ? q[i] : 0.f;
-        __syncthreads();
-        if (tid != 0) return;
-        Acc<ORDER> a;
-        a.zero();
-        const int dmain = D & ~3;
-#pragma unroll 8
-        for (int i = 0; i < dmain; i += 4) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(&sq[i]);
-            a.template add<0>(v.x * v.x);
-            a.template add<1>(v.y * v.y);
-            a.template add<2>(v.z * v.z);
-            a.template add<3>(v.w * v.w);
-        }
-        for (int i = dmain; i < D; i++) a.add_tail(sq[i] * sq[i]);
-        qna[j] = a.total();
-        return;
-    }
     const int q = qsel ? qsel[blockIdx.x] : blockIdx.x;
     const uint64_t *list = cs.lists + (size_t)q * cs.cap;
     uint64_t e[ST_PER];
@@ -570,48 +620,47 @@ __global__ __launch_bounds__(ST_THREADS) void sample_tau_kernel(CandState cs, co
         const uint32_t idx = (uint32_t)tid + (uint32_t)ST_THREADS * i;
         e[i] = idx < count ? list[idx] : kEntryMax;
     }
-    uint64_t lo = 0; // entries are unique: round r takes the smallest entry >= lo
+    // each thread sorts its 8 entries once (19 compare-exchanges); a round then only looks at the heads
+    static_assert(ST_PER == 8, "the sorting network below is for 8 entries");
+#define LB_CE(i, j)                         \
+    {                                       \
+        const uint64_t x = e[i], y = e[j];  \
+        e[i] = x < y ? x : y;               \
+        e[j] = x < y ? y : x;               \
+    }
+    LB_CE(0, 1) LB_CE(2, 3) LB_CE(4, 5) LB_CE(6, 7) LB_CE(0, 2) LB_CE(1, 3) LB_CE(4, 6) LB_CE(5, 7) LB_CE(1, 2)
+    LB_CE(5, 6) LB_CE(0, 4) LB_CE(3, 7) LB_CE(1, 5) LB_CE(2, 6) LB_CE(1, 4) LB_CE(3, 6) LB_CE(2, 4) LB_CE(3, 5)
+    LB_CE(3, 4)
+#undef LB_CE
     uint64_t kth = kEntryMax;
     for (int r = 0; r < m; r++) {
-        uint64_t v = kEntryMax;
-#pragma unroll
-        for (int i = 0; i < ST_PER; i++)
-            if (e[i] >= lo && e[i] < v) v = e[i];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const uint64_t o = __shfl_xor(v, off);
-            v = o < v ? o : v;
-        }
+        uint64_t v = wave_min_u64(e[0]);
         if (lane == 0) wmin[r & 1][wave] = v;
         __syncthreads();
-        v = wmin[r & 1][lane & (ST_THREADS / 64 - 1)];
-#pragma unroll
-        for (int off = ST_THREADS / 128; off > 0; off >>= 1) {
-            const uint64_t o = __shfl_xor(v, off);
-            v = o < v ? o : v;
-        }
+        static_assert(ST_THREADS / 64 == 16, "one row of 16 lanes reduces the per-wave minima");
+        v = row16_min_u64(wmin[r & 1][lane & 15]);
         kth = v;
         if (v == kEntryMax) break; // fewer than m visible sample rows: no threshold
-        lo = v + 1;
+        if (e[0] == v) {           // entries are unique: exactly one thread pops its head
+#pragma unroll
+            for (int i = 0; i + 1 < ST_PER; i++) e[i] = e[i + 1];
+            e[ST_PER - 1] = kEntryMax;
+        }
     }
     if (tid == 0) {
         cs.tau[q] = kth == kEntryMax ? kEntryMax : (kth | 0xffffffffull);
         cs.cnt[q] = 0;
     }
+    if (zero_stripes && tid < LB_STRIPES) cs.stripes[(blockIdx.x * LB_STRIPES + tid) * LB_STRIPE_PAD] = 0;
 }
 
 bool sample_tau_supported(uint32_t count, int m) { return count <= (uint32_t)(ST_THREADS * ST_PER) && m >= 1 && m <= 64; }
 
-void launch_sample_tau(int order, CandState cs, const int *qsel, int nsel, uint32_t count, int m, const float *Q, int D,
-                       float *qna, hipStream_t s)
+void launch_sample_tau(CandState cs, const int *qsel, int nsel, uint32_t count, int m, bool zero_stripes, hipStream_t s)
 {
     if (nsel <= 0) return;
-    dim3 grid(qna ? 2 * nsel : nsel), block(ST_THREADS);
-    const size_t shmem = qna ? (size_t)((D + 3) & ~3) * sizeof(float) : 0;
-    if (order == ORDER_UNROLL4)
-        hipLaunchKernelGGL(sample_tau_kernel<ORDER_UNROLL4>, grid, block, shmem, s, cs, qsel, nsel, count, m, Q, D, qna);
-    else
-        hipLaunchKernelGGL(sample_tau_kernel<ORDER_SEQ>, grid, block, shmem, s, cs, qsel, nsel, count, m, Q, D, qna);
+    hipLaunchKernelGGL(sample_tau_kernel, dim3(nsel), dim3(ST_THREADS), 0, s, cs, qsel, nsel, count, m,
+                       (zero_stripes && cs.stripes != nullptr) ? 1 : 0);
 }
 
 int g_scan_nbuf = [] { const char *e = getenv("LB_SCAN_NBUF"); return e ? atoi(e) : 1; }();
@@ -642,10 +691,11 @@ static void launch_scan_nq(int nq_t, dim3 grid, hipStream_t s, const ScanArgs &a
 void launch_scan(int metric, int order, bool raw_dot, const float *X, int64_t row_begin,
                       int64_t row_end, int D, const float *Q, const int *qsel, int nsel,
                       const float *qna, const uint8_t *mask, const uint32_t *rowmap, CandState cs, bool boot,
-                      float *all_out, int64_t ld, hipStream_t s)
+                      float *all_out, int64_t ld, hipStream_t s, bool striped)
 {
     if (row_end <= row_begin || nsel <= 0) return;
     ScanArgs a;
+    a.striped = (striped && cs.stripes != nullptr && !boot) ? 1 : 0;
     a.rowmap = rowmap;
     a.boot = boot ? 1 : 0;
     a.X = X; a.row_begin = row_begin; a.row_end = row_end; a.D = D;

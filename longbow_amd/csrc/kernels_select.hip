@@ -90,10 +90,34 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
     return v;
 }
 
+// lane permutes on the DPP path (no LDS round trip): OR / AND of a u64 over the 64 lanes, result in lane 63
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint64_t dpp_u64(uint64_t v)
+{
+    const int lo = (int)(uint32_t)v, hi = (int)(uint32_t)(v >> 32);
+    const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    const int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    return ((uint64_t)(uint32_t)ohi << 32) | (uint64_t)(uint32_t)olo;
+}
+__device__ __forceinline__ void wave_or_and_u64(uint64_t &o, uint64_t &a)
+{
+#define LB_STEP(CTRL, RM)                 \
+    o |= dpp_u64<CTRL, RM>(o);            \
+    a &= dpp_u64<CTRL, RM>(a);
+    LB_STEP(0xB1, 0xf)  // quad_perm [1,0,3,2]
+    LB_STEP(0x4E, 0xf)  // quad_perm [2,3,0,1]
+    LB_STEP(0x141, 0xf) // row_half_mirror
+    LB_STEP(0x140, 0xf) // row_mirror
+    LB_STEP(0x142, 0xa) // row_bcast15 -> rows 1,3 (disabled rows keep their own value: x|x, x&x)
+    LB_STEP(0x143, 0xc) // row_bcast31 -> rows 2,3
+#undef LB_STEP
+}
+
 template <int NT> // threads per workgroup: 256 (throughput, many queries) or 1024 (latency, few queries)
 __global__ __launch_bounds__(NT) void select_kernel(CandState cs, const int *qsel, int kc,
                                                              uint32_t boot_rows, uint32_t tau_only,
-                                                             uint32_t need_at_least)
+                                                             uint32_t need_at_least, uint32_t sort_max,
+                                                             EmitArgs em, uint32_t striped)
 {
     // tau_only: the list holds a *sample* of the rows; publish its kc-th entry (row bits saturated) as
     // the admission threshold and leave the list empty.  need_at_least: a list shorter than this means a
@@ -103,16 +127,48 @@ __global__ __launch_bounds__(NT) void select_kernel(CandState cs, const int *qse
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     // boot_rows > 0: the bootstrap chunk stored one entry per row without atomics
+    // striped: positions s, s+16, ... of the list were handed out by 16 counters (slot = blockIdx.x);
+    // the list then has holes, which are read as kEntryMax exactly like masked rows of a bootstrap chunk
+    uint32_t my_stripe_cnt = 0;
+    if (striped) {
+        __shared__ uint32_t s_stripe[LB_STRIPES];
+        if (tid < LB_STRIPES) s_stripe[tid] = cs.stripes[(blockIdx.x * LB_STRIPES + tid) * LB_STRIPE_PAD];
+        __syncthreads();
+        uint32_t mx = 0;
+#pragma unroll
+        for (int st = 0; st < LB_STRIPES; st++) mx = s_stripe[st] > mx ? s_stripe[st] : mx;
+        my_stripe_cnt = s_stripe[tid & (LB_STRIPES - 1)];
+        boot_rows = mx * LB_STRIPES; // (0 admissions -> the plain path below sees cnt[q] == 0)
+    }
     const uint32_t raw = boot_rows ? boot_rows : cs.cnt[q];
     uint32_t n = raw < cs.cap ? raw : cs.cap;
     uint64_t *list = cs.lists + (size_t)q * cs.cap;
     if (raw > cs.cap && tid == 0) atomicOr(&cs.flags[q], 1u);
+    // last select of a scan-path search: write the k results (and the slot's status word, to pinned host
+    // memory) from the sorted prefix sorted[0..nsorted) instead of launching emit_lists_kernel
+    auto emit = [&](const uint64_t *sorted, uint32_t nsorted) {
+        if (em.out_dist == nullptr) return;
+        for (int r = tid; r < em.k; r += NT) {
+            float d = FLT_MAX;
+            int64_t lab = -1;
+            if ((uint32_t)r < nsorted) {
+                const uint64_t e = sorted[r];
+                d = entry_key(e);
+                const uint32_t row = entry_row(e);
+                lab = em.ids ? em.ids[row] : (int64_t)row;
+            }
+            em.out_dist[(int64_t)q * em.k + r] = d;
+            em.out_labels[(int64_t)q * em.k + r] = lab;
+        }
+        if (em.flags_host && tid == 0) em.flags_host[q] = atomicOr(&cs.flags[q], 0u);
+    };
     if (n == 0) {
         if (tid == 0) {
             cs.tau[q] = kEntryMax;
             cs.cnt[q] = 0;
             if (need_at_least) atomicOr(&cs.flags[q], 4u);
         }
+        emit(nullptr, 0);
         return;
     }
     const uint32_t P = next_pow2(n);
@@ -122,14 +178,17 @@ __global__ __launch_bounds__(NT) void select_kernel(CandState cs, const int *qse
 
     if (tid == 0) { scal[2] = 0; scal[3] = 0; }
     uint32_t myvalid = 0;
-    for (uint32_t i = tid; i < P; i += NT) {
-        const uint64_t e = i < n ? list[i] : kEntryMax;
+    for (uint32_t i = tid; i < P; i += NT) { // (NT is a multiple of 16: a thread stays in one stripe)
+        const bool there = i < n && (!striped || (i / LB_STRIPES) < my_stripe_cnt);
+        const uint64_t e = there ? list[i] : kEntryMax;
         sh[i] = e;
         myvalid += (e != kEntryMax) ? 1u : 0u;
     }
     __syncthreads();
     if (boot_rows) { // masked-out rows of the bootstrap chunk hold kEntryMax: count the real ones
-        if (myvalid) atomicAdd(&scal[3], myvalid);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) myvalid += __shfl_xor(myvalid, off); // one LDS atomic per wave
+        if (lane == 0 && myvalid) atomicAdd(&scal[3], myvalid);
         __syncthreads();
         n = scal[3];
         __syncthreads();
@@ -139,13 +198,14 @@ __global__ __launch_bounds__(NT) void select_kernel(CandState cs, const int *qse
                 cs.cnt[q] = 0;
                 if (need_at_least) atomicOr(&cs.flags[q], 4u);
             }
+            emit(nullptr, 0);
             return;
         }
     }
     const uint32_t keep = n < (uint32_t)kc ? n : (uint32_t)kc;
     if (n < need_at_least && tid == 0) atomicOr(&cs.flags[q], 4u);
 
-    if (P <= 2u * next_pow2((uint32_t)kc) || n <= (uint32_t)kc) {
+    if (P <= 2u * next_pow2((uint32_t)kc) || n <= (uint32_t)kc || P <= sort_max) {
         bitonic_sort_u64(sh, P, tid, NT); // kEntryMax padding sorts last
         if (tau_only) {
             if (tid == 0) {
@@ -159,6 +219,7 @@ __global__ __launch_bounds__(NT) void select_kernel(CandState cs, const int *qse
             cs.cnt[q] = keep;
             cs.tau[q] = n >= (uint32_t)kc ? sh[kc - 1] : kEntryMax;
         }
+        emit(sh, keep);
         return;
     }
 
@@ -173,8 +234,11 @@ __global__ __launch_bounds__(NT) void select_kernel(CandState cs, const int *qse
             const uint64_t e = sh[i];
             if (e != kEntryMax) { o |= e; an &= e; }
         }
-        atomicOr(&red[0], (unsigned long long)o);
-        atomicAnd(&red[1], (unsigned long long)an);
+        wave_or_and_u64(o, an); // one pair of LDS atomics per wave, not per thread
+        if (lane == 63) {
+            atomicOr(&red[0], (unsigned long long)o);
+            atomicAnd(&red[1], (unsigned long long)an);
+        }
     }
     __syncthreads();
     const uint64_t diff = red[0] ^ red[1]; // bit positions that differ among real entries
@@ -234,18 +298,21 @@ __global__ __launch_bounds__(NT) void select_kernel(CandState cs, const int *qse
         }
         return;
     }
-    // compact the kc entries <= pivot into the front of the global list (unordered), then sort them
+    // compact the kc entries <= pivot (unordered), then sort them.  The staging area is the unused tail of
+    // the LDS entry array when there is room, else the front of the global list.
+    const uint32_t Pk = next_pow2((uint32_t)kc);
+    uint64_t *stage = (P + Pk <= next_pow2(cs.cap)) ? sh + P : list;
     __syncthreads();
     for (uint32_t i = tid; i < P; i += NT) {
         const uint64_t e = sh[i];
         if (e <= pivot) {
             const uint32_t pos = atomicAdd(&scal[2], 1u);
-            list[pos] = e; // pos < kc by construction
+            stage[pos] = e; // pos < kc by construction
         }
     }
     __syncthreads();
-    const uint32_t Pk = next_pow2((uint32_t)kc);
-    for (uint32_t i = tid; i < Pk; i += NT) sh[i] = i < (uint32_t)kc ? list[i] : kEntryMax;
+    // (this path has P > 2 * Pk, so sh[0..Pk) and the staging tail sh[P..P+Pk) do not overlap)
+    for (uint32_t i = tid; i < Pk; i += NT) sh[i] = i < (uint32_t)kc ? stage[i] : kEntryMax;
     __syncthreads();
     bitonic_sort_u64(sh, Pk, tid, NT);
     for (uint32_t i = tid; i < (uint32_t)kc; i += NT) list[i] = sh[i];
@@ -253,6 +320,7 @@ __global__ __launch_bounds__(NT) void select_kernel(CandState cs, const int *qse
         cs.cnt[q] = (uint32_t)kc;
         cs.tau[q] = pivot;
     }
+    emit(sh, (uint32_t)kc);
 }
 
 // smap[i] = corpus row behind the i-th of `count` evenly spaced positions of [0, span)
@@ -272,18 +340,25 @@ void launch_sample_map(const uint32_t *rowmap, int64_t span, uint32_t count, uin
 }
 
 void launch_select(CandState cs, const int *qsel, int nsel, int kc, uint32_t boot_rows, hipStream_t s,
-                   bool tau_only, uint32_t need_at_least)
+                   bool tau_only, uint32_t need_at_least, const EmitArgs *emit, bool striped)
 {
+    EmitArgs em{};
+    if (emit) em = *emit;
     if (nsel <= 0) return;
     const size_t shmem = (size_t)next_pow2_host(cs.cap) * sizeof(uint64_t) + (256 + 4 + 8) * sizeof(uint32_t);
+    // lists up to this size are simply sorted (one 1024-thread workgroup); larger ones take the radix select
+    static const uint32_t sort_max_big = [] { const char *e = getenv("LB_SELECT_SORT_MAX"); return e ? (uint32_t)atoi(e) : 0u; }();
+    const uint32_t sort_max = nsel <= 32 ? sort_max_big : 0u;
     if (nsel <= 32) { // few queries: one big workgroup each, latency matters
         allow_big_lds(select_kernel<1024>, shmem);
         hipLaunchKernelGGL(select_kernel<1024>, dim3(nsel), dim3(1024), shmem, s, cs, qsel, kc, boot_rows,
-                           tau_only ? 1u : 0u, need_at_least);
+                           tau_only ? 1u : 0u, need_at_least, sort_max, em,
+                           (striped && cs.stripes) ? 1u : 0u);
     } else {
         allow_big_lds(select_kernel<256>, shmem);
         hipLaunchKernelGGL(select_kernel<256>, dim3(nsel), dim3(256), shmem, s, cs, qsel, kc, boot_rows,
-                           tau_only ? 1u : 0u, need_at_least);
+                           tau_only ? 1u : 0u, need_at_least, sort_max, em,
+                           (striped && cs.stripes) ? 1u : 0u);
     }
 }
 

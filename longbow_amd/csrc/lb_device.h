@@ -71,7 +71,13 @@ struct CandState {
     uint64_t *tau;   // [nq] admission threshold: entry admitted iff e < tau
     uint32_t *flags; // [nq] bit0 = list overflowed, bit1 = containment bound failed, bit2 = sampled threshold too tight
     uint32_t cap;
+    // Optional (scan path, sampled pass): 16 admission counters per slot, LB_STRIPE_PAD u32 apart.  Stripe s
+    // hands out list positions s, s+16, s+32, ... so the admissions of one query do not serialise on a
+    // single hot counter; the following select reads the counters and skips the holes.
+    uint32_t *stripes;
 };
+constexpr int LB_STRIPES = 16;
+constexpr int LB_STRIPE_PAD = 32; // u32 words between counters (128 B)
 
 // ---------------------------------------------------------------------------
 // Launchers (implemented in kernels_*.hip).  All are asynchronous on `s`.
@@ -101,17 +107,27 @@ void launch_split_bf16(const float *src, float *dst, int64_t rows, int D, hipStr
 // launch (one entry per row at index row - row_begin, no atomics; masked rows hold kEntryMax).
 // tau_only: the list is a row *sample*; publish its kc-th entry as threshold and empty the list.
 // need_at_least: flag bit 2 when fewer entries than this were admitted (sampled threshold too tight).
+// emit: the search's last select also writes the k results per slot (what launch_emit_lists would do)
+struct EmitArgs {
+    int k;
+    const int64_t *ids;
+    float *out_dist;
+    int64_t *out_labels;
+    uint32_t *flags_host;
+};
 void launch_select(CandState cs, const int *qsel, int nsel, int kc, uint32_t boot_rows, hipStream_t s,
-                   bool tau_only = false, uint32_t need_at_least = 0);
+                   bool tau_only = false, uint32_t need_at_least = 0, const EmitArgs *emit = nullptr,
+                   bool striped = false);
 // approximate distances of `count` evenly spaced positions of [0, span) for up to 8 query slots, written
-// as entries to lists[q][0..count) (also clears the slots' flags)
-void launch_sample_scores(int metric, const float *X, int D, int64_t span, uint32_t count, const uint32_t *rowmap,
-                          const uint8_t *mask, const float *Q, const int *qsel, int nsel, CandState cs, hipStream_t s);
-// tau[q] = m-th smallest of lists[q][0..count) with the row bits saturated, cnt[q] = 0; with qna != null the
-// same launch also computes the exact query norms of the slots (cosine)
+// as entries to lists[q][0..count) (also clears the slots' flags); cosine: `nsel` extra workgroups compute
+// the slots' exact ||q||^2 into qna in the requested order
+void launch_sample_scores(int metric, int order, const float *X, int D, int64_t span, uint32_t count,
+                          const uint32_t *rowmap, const uint8_t *mask, const float *Q, const int *qsel, int nsel,
+                          CandState cs, float *qna, hipStream_t s);
+// tau[q] = m-th smallest of lists[q][0..count) with the row bits saturated, cnt[q] = 0
 bool sample_tau_supported(uint32_t count, int m);
-void launch_sample_tau(int order, CandState cs, const int *qsel, int nsel, uint32_t count, int m, const float *Q, int D,
-                       float *qna, hipStream_t s);
+// zero_stripes: also reset the slots' striped admission counters (at most 8 slots: the scan path)
+void launch_sample_tau(CandState cs, const int *qsel, int nsel, uint32_t count, int m, bool zero_stripes, hipStream_t s);
 // smap[i] = row behind the i-th of `count` evenly spaced positions of [0, span) (through rowmap if given)
 void launch_sample_map(const uint32_t *rowmap, int64_t span, uint32_t count, uint32_t *smap, hipStream_t s);
 
@@ -131,7 +147,7 @@ void launch_query_norms(int order, const float *Q, const int *qsel, int nsel, in
 void launch_scan(int metric, int order, bool raw_dot, const float *X, int64_t row_begin,
                  int64_t row_end, int D, const float *Q, const int *qsel, int nsel,
                  const float *qna, const uint8_t *mask, const uint32_t *rowmap, CandState cs, bool boot,
-                 float *all_out, int64_t ld, hipStream_t s);
+                 float *all_out, int64_t ld, hipStream_t s, bool striped = false);
 
 // after the last select of the scan path: lists already hold exact distances.
 void launch_emit_lists(CandState cs, const int *qsel, int nsel, int k, const int64_t *ids,
