@@ -138,6 +138,13 @@ struct lb_gpu_index {
     int64_t rowmap_cap = 0, cscratch_words = 0;
     int64_t n_visible = 0;
     bool rowmap_on = false;
+    // strided sample of the current corpus view (sample_plan), built by the first batched search after
+    // a change and shared by all searches with the same plan
+    std::mutex smap_mu;
+    uint32_t *d_smap = nullptr;
+    int64_t smap_span = 0;
+    uint32_t smap_count = 0, smap_cap = 0;
+    bool smap_valid = false;
     // optional split-bf16 image of the corpus for the 3x-bf16 candidate contraction (same byte shape as d_X)
     std::atomic<int> cand_mode{0};
     float *d_Xs = nullptr;
@@ -338,11 +345,14 @@ bool run_scan_path(lb_gpu_index *h, Workspace *w, hipStream_t s, const float *d_
         bool emitted = false;
         const EmitArgs em{k, h->has_ids ? h->d_ids : nullptr, d_dist, d_lab, w->h_flags};
         if (sp.on) {
-            {   // sample scores (clear the flags; exact query norms ride along), threshold, one pass
-                ProfScope p(w, s, prof, 3);
+            {   // sample scores (clear the flags; exact query norms ride along), threshold
+                ProfScope p(w, s, prof, 1);
                 launch_sample_scores(metric, order, h->d_X, h->dim, sp.span, sp.count, rv.rowmap, mask, d_q, use_sel,
                                      gn, w->cs, w->d_qna, s);
                 launch_sample_tau(w->cs, use_sel, gn, sp.count, sp.m, /*zero_stripes=*/true, s);
+            }
+            {   // one pass over the span
+                ProfScope p(w, s, prof, 3);
                 launch_scan(metric, order, false, h->d_X, 0, sp.span, h->dim, d_q, use_sel, gn, w->d_qna, mask,
                             rv.rowmap, w->cs, /*boot=*/false, nullptr, 0, s, /*striped=*/true);
             }
@@ -454,8 +464,14 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     }
 
     // ---- batched path: MFMA candidate generation + exact re-rank --------------------
-    launch_init_cand(w->cs, nullptr, nq, s);
-    if (metric == LB_METRIC_COSINE) launch_query_norms(order, d_q, nullptr, nq, h->dim, w->d_qna, s);
+    const SamplePlan sp = sample_plan(n, kc, w->cap);
+    // up to 8 queries the sample is scored by the wave-per-row kernel (candidate keys; 22-28 us against
+    // 44 us for 8192 rows through the 32-workgroup MFMA launch); larger batches sample through the MFMA
+    // kernel itself.  Up to 64 queries the exact query norms ride in the threshold launch.
+    const bool light_sample = sp.on && nq <= 8;
+    const bool norm_riders = sp.on && nq <= 64 && metric == LB_METRIC_COSINE;
+    if (!light_sample) launch_init_cand(w->cs, nullptr, nq, s);
+    if (metric == LB_METRIC_COSINE && !norm_riders) launch_query_norms(order, d_q, nullptr, nq, h->dim, w->d_qna, s);
     // candidate contraction: exact f32 MFMA, or 3 x bf16 MFMA on the split images
     const bool split = h->cand_mode.load() == 1 && h->d_Xs != nullptr && h->xs_rows == h->n && h->dim % 32 == 0;
     const float *gx = h->d_X, *gq = d_q;
@@ -487,13 +503,38 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     };
     int64_t pos = 0;
     int step = 0;
-    const SamplePlan sp = sample_plan(n, kc, w->cap);
     if (sp.on) { // sampled threshold, then one pass over the span (see sample_plan)
-        launch_sample_map(rv.rowmap, sp.span, sp.count, w->d_smap, s);
-        candidates(0, sp.count, w->d_smap, /*boot=*/true);
-        {
+        if (light_sample) {
             ProfScope p(w, s, prof, 1);
-            launch_sample_tau(w->cs, nullptr, nq, sp.count, sp.m, false, s);
+            launch_sample_scores(metric, order, h->d_X, h->dim, sp.span, sp.count, rv.rowmap, mask, d_q, nullptr, nq,
+                                 w->cs, nullptr, s, h->d_norm2, h->d_rnorm);
+            launch_sample_tau(w->cs, nullptr, nq, sp.count, sp.m, false, s, d_q, h->dim,
+                              norm_riders ? w->d_qna : nullptr, order);
+        } else {
+            const uint32_t *smap = w->d_smap;
+            {
+                std::lock_guard<std::mutex> g(h->smap_mu);
+                if (!h->smap_valid) {
+                    if (h->smap_cap < sp.count) {
+                        if (h->d_smap) (void)hipFree(h->d_smap);
+                        h->d_smap = nullptr;
+                        h->smap_cap = 0;
+                        LB_HIP(hipMalloc(&h->d_smap, (size_t)sp.count * sizeof(uint32_t)));
+                        h->smap_cap = sp.count;
+                    }
+                    launch_sample_map(rv.rowmap, sp.span, sp.count, h->d_smap, s);
+                    LB_HIP(hipStreamSynchronize(s));
+                    h->smap_span = sp.span;
+                    h->smap_count = sp.count;
+                    h->smap_valid = true;
+                }
+                if (h->smap_span == sp.span && h->smap_count == sp.count) smap = h->d_smap;
+            }
+            if (smap == w->d_smap) launch_sample_map(rv.rowmap, sp.span, sp.count, w->d_smap, s);
+            candidates(0, sp.count, smap, /*boot=*/true);
+            ProfScope p(w, s, prof, 1);
+            launch_sample_tau(w->cs, nullptr, nq, sp.count, sp.m, false, s, d_q, h->dim,
+                              norm_riders ? w->d_qna : nullptr, order);
         }
         candidates(0, sp.span, rv.rowmap, /*boot=*/false);
         {
@@ -517,10 +558,10 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     {
         ProfScope p(w, s, prof, 2);
         launch_rerank(metric, order, h->d_X, h->dim, d_q, nq, w->d_qna, w->cs, kc, k, h->d_maxnorm2, gamma,
-                      h->has_ids ? h->d_ids : nullptr, d_dist, d_lab, s);
+                      h->has_ids ? h->d_ids : nullptr, d_dist, d_lab, s, w->h_flags);
     }
     std::vector<int> bad;
-    if (collect_flagged(w, s, nq, 3u | 4u, nullptr, 0, bad) > 0) {
+    if (collect_flagged(w, s, nq, 3u | 4u, nullptr, 0, bad, /*on_host=*/true) > 0) {
         fallbacks += (int64_t)bad.size();
         scan_with_retry(h, w, s, d_q, nq, bad, k, d_dist, d_lab, prof);
     }
@@ -600,6 +641,7 @@ void sync_split_image(lb_gpu_index *h);
 // 90 %, 4.5 ms at 50 %, 1.16 ms at 10 % for 256 queries -- so only near-total masks keep the per-row test).
 void rebuild_rowmap(lb_gpu_index *h)
 {
+    h->smap_valid = false; // the corpus view changes (callers hold the exclusive lock)
     h->rowmap_on = false;
     h->n_visible = h->n;
     if (!h->has_mask || h->n == 0) return;
@@ -821,6 +863,7 @@ void lb_gpu_index_free(lb_gpu_index *h)
         if (h->d_ids) (void)hipFree(h->d_ids);
         if (h->d_mask) (void)hipFree(h->d_mask);
         if (h->d_rowmap) (void)hipFree(h->d_rowmap);
+        if (h->d_smap) (void)hipFree(h->d_smap);
         if (h->d_cscratch) (void)hipFree(h->d_cscratch);
         if (h->d_maxnorm2) (void)hipFree(h->d_maxnorm2);
         if (h->d_Xs) (void)hipFree(h->d_Xs);
@@ -946,7 +989,7 @@ int lb_gpu_index_set_filter(lb_gpu_index *h, const uint8_t *mask, int64_t n)
     if (!h) return LB_ERR_INVALID_ARG;
     std::unique_lock<std::shared_mutex> g(h->mu);
     if (h->closed) return LB_ERR_CLOSED;
-    if (!mask) { h->has_mask = false; h->rowmap_on = false; return LB_OK; }
+    if (!mask) { h->has_mask = false; h->rowmap_on = false; h->smap_valid = false; return LB_OK; }
     if (n != h->n) { h->set_error("filter mask has %lld bytes, index has %lld rows", (long long)n, (long long)h->n); return LB_ERR_INVALID_ARG; }
     try {
         LB_HIP(hipSetDevice(h->device));

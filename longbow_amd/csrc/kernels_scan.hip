@@ -423,7 +423,8 @@ void launch_query_norms(int order, const float *Q, const int *qsel, int nsel, in
 // does not matter; a threshold that admits too few or too many rows is detected and the query is
 // redone by the classic schedule.
 // ---------------------------------------------------------------------------
-constexpr int SS_MAXQ = 8;
+constexpr int SS_MAXQ = 8;        // query slots scored together (register accumulators)
+constexpr int SS_MAX_SLOTS = 64;  // query slots per launch (groups of SS_MAXQ)
 
 struct SampleArgs {
     const float *X;
@@ -440,6 +441,9 @@ struct SampleArgs {
     float *qna;       // cosine: exact ||q||^2 per slot, computed by `nsel` extra workgroups of this launch
     int order;
     uint32_t nblocks; // workgroups that score sample rows
+    // keys mode (batched path): entries carry the MFMA pipeline's candidate key instead of the distance
+    int keys;
+    const float *norm2, *rnorm;
 };
 
 __device__ __forceinline__ float wave_sum(float v)
@@ -467,7 +471,9 @@ __device__ __forceinline__ float exact_sq_norm_lds(const float *sq, int D)
     return a.total();
 }
 
-template <int METRIC>
+// R = sampled rows per wave: every query chunk fetched from L2 is used for R rows (with 32 query
+// slots and R = 1 the launch is bound by 8192 x 96 KB of L2 reads: 97 us; R = 4: a quarter of that)
+template <int METRIC, int R>
 __global__ __launch_bounds__(256) void sample_scores_kernel(SampleArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float sq[];
@@ -485,91 +491,146 @@ __global__ __launch_bounds__(256) void sample_scores_kernel(SampleArgs a)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t blk = blockIdx.x - nnorm;
     if (blk == 0 && (int)threadIdx.x < a.nsel) a.cs.flags[a.qsel ? a.qsel[threadIdx.x] : threadIdx.x] = 0;
-    const uint32_t i = blk * 4u + (uint32_t)wave;
-    if (i >= a.count) return;
-    const int64_t pos = (int64_t)(((uint64_t)i * (uint64_t)a.span) / a.count); // i, span < 2^32
-    const int64_t row = a.rowmap ? (int64_t)a.rowmap[pos] : pos;
+    const uint32_t i0 = (blk * 4u + (uint32_t)wave) * R; // this wave's first sample index
+    if (i0 >= a.count) return;
     const int D = a.D;
-    const bool hidden = a.mask != nullptr && !a.mask[row];
-    float acc[SS_MAXQ], qq[SS_MAXQ], xx = 0.f;
+    int64_t row[R];
+    bool live[R], hidden[R];
+    const float *x[R];
 #pragma unroll
-    for (int j = 0; j < SS_MAXQ; j++) { acc[j] = 0.f; qq[j] = 0.f; }
-    if (!hidden) {
-        const float *x = a.X + row * (int64_t)D;
+    for (int r = 0; r < R; r++) {
+        uint32_t i = i0 + r;
+        live[r] = i < a.count;
+        if (!live[r]) i = a.count - 1;
+        const int64_t pos = (int64_t)(((uint64_t)i * (uint64_t)a.span) / a.count); // i, span < 2^32
+        row[r] = a.rowmap ? (int64_t)a.rowmap[pos] : pos;
+        hidden[r] = a.mask != nullptr && !a.mask[row[r]];
+        x[r] = a.X + row[r] * (int64_t)D;
+    }
+    const bool plain_dot = METRIC != METRIC_L2 || a.keys; // L2 keys come from the inner product too
+    const bool want_norms = METRIC == METRIC_COS && !a.keys;
+    for (int g0 = 0; g0 < a.nsel; g0 += SS_MAXQ) { // groups of 8 query slots; the rows stay hot in L1/L2
+        const int gn = a.nsel - g0 < SS_MAXQ ? a.nsel - g0 : SS_MAXQ;
+        float acc[SS_MAXQ][R], qq[SS_MAXQ], xx[R];
+#pragma unroll
+        for (int j = 0; j < SS_MAXQ; j++) {
+            qq[j] = 0.f;
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[j][r] = 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) xx[r] = 0.f;
         if (a.aligned) {
             for (int k = lane * 4; k < D; k += 256) {
-                const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + k);
-                if (METRIC == METRIC_COS) xx += xv.x * xv.x + xv.y * xv.y + xv.z * xv.z + xv.w * xv.w;
+                f32x4 xv[R];
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    xv[r] = *reinterpret_cast<const f32x4 *>(x[r] + k);
+                    if (want_norms) xx[r] += xv[r].x * xv[r].x + xv[r].y * xv[r].y + xv[r].z * xv[r].z + xv[r].w * xv[r].w;
+                }
 #pragma unroll
                 for (int j = 0; j < SS_MAXQ; j++) {
-                    if (j >= a.nsel) break;
-                    const f32x4 qv = *reinterpret_cast<const f32x4 *>(a.Q + (int64_t)(a.qsel ? a.qsel[j] : j) * D + k);
-                    if (METRIC == METRIC_L2) {
-                        const float e0 = qv.x - xv.x, e1 = qv.y - xv.y, e2 = qv.z - xv.z, e3 = qv.w - xv.w;
-                        acc[j] += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
-                    } else {
-                        acc[j] += qv.x * xv.x + qv.y * xv.y + qv.z * xv.z + qv.w * xv.w;
-                        if (METRIC == METRIC_COS) qq[j] += qv.x * qv.x + qv.y * qv.y + qv.z * qv.z + qv.w * qv.w;
+                    if (j >= gn) break;
+                    const int qj = a.qsel ? a.qsel[g0 + j] : g0 + j;
+                    const f32x4 qv = *reinterpret_cast<const f32x4 *>(a.Q + (int64_t)qj * D + k);
+                    if (want_norms) qq[j] += qv.x * qv.x + qv.y * qv.y + qv.z * qv.z + qv.w * qv.w;
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        if (!plain_dot) {
+                            const float e0 = qv.x - xv[r].x, e1 = qv.y - xv[r].y, e2 = qv.z - xv[r].z, e3 = qv.w - xv[r].w;
+                            acc[j][r] += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
+                        } else {
+                            acc[j][r] += qv.x * xv[r].x + qv.y * xv[r].y + qv.z * xv[r].z + qv.w * xv[r].w;
+                        }
                     }
                 }
             }
         } else {
             for (int k = lane; k < D; k += 64) {
-                const float xv = x[k];
-                if (METRIC == METRIC_COS) xx += xv * xv;
+                float xv[R];
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    xv[r] = x[r][k];
+                    if (want_norms) xx[r] += xv[r] * xv[r];
+                }
 #pragma unroll
                 for (int j = 0; j < SS_MAXQ; j++) {
-                    if (j >= a.nsel) break;
-                    const float qv = a.Q[(int64_t)(a.qsel ? a.qsel[j] : j) * D + k];
-                    if (METRIC == METRIC_L2) {
-                        const float e = qv - xv;
-                        acc[j] += e * e;
-                    } else {
-                        acc[j] += qv * xv;
-                        if (METRIC == METRIC_COS) qq[j] += qv * qv;
+                    if (j >= gn) break;
+                    const int qj = a.qsel ? a.qsel[g0 + j] : g0 + j;
+                    const float qv = a.Q[(int64_t)qj * D + k];
+                    if (want_norms) qq[j] += qv * qv;
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        if (!plain_dot) {
+                            const float e = qv - xv[r];
+                            acc[j][r] += e * e;
+                        } else {
+                            acc[j][r] += qv * xv[r];
+                        }
                     }
                 }
             }
         }
-    }
-    if (METRIC == METRIC_COS) xx = wave_sum(xx);
+        if (want_norms) {
 #pragma unroll
-    for (int j = 0; j < SS_MAXQ; j++) {
-        if (j >= a.nsel) break;
-        const float t = wave_sum(acc[j]);
-        float dist;
-        if (METRIC == METRIC_L2) {
-            dist = sqrtf(t);
-        } else if (METRIC == METRIC_COS) {
-            const float na = wave_sum(qq[j]);
-            dist = (na == 0.f || xx == 0.f) ? 1.0f : 1.0f - t * rsqrtf(na * xx);
-        } else {
-            dist = -t;
+            for (int r = 0; r < R; r++) xx[r] = wave_sum(xx[r]);
         }
-        if (lane == 0) {
-            const int qj = a.qsel ? a.qsel[j] : j;
-            a.cs.lists[(size_t)qj * a.cs.cap + i] = hidden ? kEntryMax : pack_entry(dist, (uint32_t)row);
+#pragma unroll
+        for (int j = 0; j < SS_MAXQ; j++) {
+            if (j >= gn) break;
+            const int qj = a.qsel ? a.qsel[g0 + j] : g0 + j;
+            const float na = want_norms ? wave_sum(qq[j]) : 0.f;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const float t = wave_sum(acc[j][r]);
+                float v;
+                if (a.keys) { // as gemm_filter_kernel's key_of
+                    if (METRIC == METRIC_L2) v = fmaf(-2.0f, t, a.norm2[row[r]]);
+                    else if (METRIC == METRIC_COS) v = -t * a.rnorm[row[r]];
+                    else v = -t;
+                } else if (METRIC == METRIC_L2) {
+                    v = sqrtf(t);
+                } else if (METRIC == METRIC_COS) {
+                    v = (na == 0.f || xx[r] == 0.f) ? 1.0f : 1.0f - t * rsqrtf(na * xx[r]);
+                } else {
+                    v = -t;
+                }
+                if (lane == 0 && live[r])
+                    a.cs.lists[(size_t)qj * a.cs.cap + i0 + r] = hidden[r] ? kEntryMax : pack_entry(v, (uint32_t)row[r]);
+            }
         }
     }
 }
 
 void launch_sample_scores(int metric, int order, const float *X, int D, int64_t span, uint32_t count,
                           const uint32_t *rowmap, const uint8_t *mask, const float *Q, const int *qsel, int nsel,
-                          CandState cs, float *qna, hipStream_t s)
+                          CandState cs, float *qna, hipStream_t s, const float *norm2, const float *rnorm)
 {
     if (count == 0 || nsel <= 0) return;
     SampleArgs a;
-    a.qna = metric == METRIC_COS ? qna : nullptr;
+    a.keys = norm2 != nullptr ? 1 : 0;
+    a.norm2 = norm2;
+    a.rnorm = rnorm;
+    a.qna = (metric == METRIC_COS && !a.keys) ? qna : nullptr;
     a.order = order;
     a.X = X; a.D = D; a.span = span; a.count = count; a.rowmap = rowmap; a.mask = mask;
-    a.Q = Q; a.qsel = qsel; a.nsel = nsel < SS_MAXQ ? nsel : SS_MAXQ; a.cs = cs;
+    a.Q = Q; a.qsel = qsel; a.nsel = nsel < SS_MAX_SLOTS ? nsel : SS_MAX_SLOTS; a.cs = cs;
     a.aligned = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && ((reinterpret_cast<uintptr_t>(Q) & 15) == 0);
-    a.nblocks = (count + 3) / 4;
+    static const int env_r = [] { const char *e = getenv("LB_SAMPLE_ROWS_PER_WAVE"); return e ? atoi(e) : 0; }();
+    const int R = (env_r == 1 || env_r == 2 || env_r == 4) ? env_r : (a.nsel > SS_MAXQ ? 4 : 1);
+    a.nblocks = (count + 4 * R - 1) / (4 * R);
     dim3 grid(a.nblocks + (a.qna ? (unsigned)a.nsel : 0u)), block(256);
     const size_t shmem = a.qna ? (size_t)((D + 3) & ~3) * sizeof(float) : 0;
-    if (metric == METRIC_L2) hipLaunchKernelGGL(sample_scores_kernel<METRIC_L2>, grid, block, shmem, s, a);
-    else if (metric == METRIC_COS) hipLaunchKernelGGL(sample_scores_kernel<METRIC_COS>, grid, block, shmem, s, a);
-    else hipLaunchKernelGGL(sample_scores_kernel<METRIC_DOT>, grid, block, shmem, s, a);
+#define LB_SS(M)                                                                                      \
+    do {                                                                                              \
+        if (R == 4) hipLaunchKernelGGL((sample_scores_kernel<M, 4>), grid, block, shmem, s, a);       \
+        else if (R == 2) hipLaunchKernelGGL((sample_scores_kernel<M, 2>), grid, block, shmem, s, a);  \
+        else hipLaunchKernelGGL((sample_scores_kernel<M, 1>), grid, block, shmem, s, a);              \
+    } while (0)
+    if (metric == METRIC_L2) LB_SS(METRIC_L2);
+    else if (metric == METRIC_COS) LB_SS(METRIC_COS);
+    else LB_SS(METRIC_DOT);
+#undef LB_SS
 }
 
 // tau[q] = m-th smallest of the first `count` entries of list q (row bits saturated), cnt[q] = 0.
@@ -608,10 +669,20 @@ __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
 }
 
 __global__ __launch_bounds__(ST_THREADS) void sample_tau_kernel(CandState cs, const int *qsel, int nsel, uint32_t count, int m,
-                                                                int zero_stripes)
+                                                                int zero_stripes, const float *Q, int D, float *qna, int order)
 {
+    extern __shared__ __attribute__((aligned(16))) float sq[];
     __shared__ uint64_t wmin[2][ST_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if ((int)blockIdx.x >= nsel) { // optional riders (qna != null): exact ||q||^2 of slot blockIdx.x - nsel
+        const int j = (int)blockIdx.x - nsel;
+        const float *q = Q + (int64_t)(qsel ? qsel[j] : j) * D;
+        const int Dpad = (D + 3) & ~3;
+        for (int i = tid; i < Dpad; i += ST_THREADS) sq[i] = i < D ? q[i] : 0.f;
+        __syncthreads();
+        if (tid == 0) qna[j] = order == ORDER_UNROLL4 ? exact_sq_norm_lds<ORDER_UNROLL4>(sq, D) : exact_sq_norm_lds<ORDER_SEQ>(sq, D);
+        return;
+    }
     const int q = qsel ? qsel[blockIdx.x] : blockIdx.x;
     const uint64_t *list = cs.lists + (size_t)q * cs.cap;
     uint64_t e[ST_PER];
@@ -656,11 +727,13 @@ __global__ __launch_bounds__(ST_THREADS) void sample_tau_kernel(CandState cs, co
 
 bool sample_tau_supported(uint32_t count, int m) { return count <= (uint32_t)(ST_THREADS * ST_PER) && m >= 1 && m <= 64; }
 
-void launch_sample_tau(CandState cs, const int *qsel, int nsel, uint32_t count, int m, bool zero_stripes, hipStream_t s)
+void launch_sample_tau(CandState cs, const int *qsel, int nsel, uint32_t count, int m, bool zero_stripes, hipStream_t s,
+                       const float *Q, int D, float *qna, int order)
 {
     if (nsel <= 0) return;
-    hipLaunchKernelGGL(sample_tau_kernel, dim3(nsel), dim3(ST_THREADS), 0, s, cs, qsel, nsel, count, m,
-                       (zero_stripes && cs.stripes != nullptr) ? 1 : 0);
+    const size_t shmem = qna ? (size_t)((D + 3) & ~3) * sizeof(float) : 0;
+    hipLaunchKernelGGL(sample_tau_kernel, dim3(qna ? 2 * nsel : nsel), dim3(ST_THREADS), shmem, s, cs, qsel, nsel, count,
+                       m, (zero_stripes && cs.stripes != nullptr) ? 1 : 0, Q, D, qna, order);
 }
 
 int g_scan_nbuf = [] { const char *e = getenv("LB_SCAN_NBUF"); return e ? atoi(e) : 1; }();

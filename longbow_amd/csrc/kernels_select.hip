@@ -404,6 +404,7 @@ struct RerankArgs {
     float *out_dist;
     int64_t *out_labels;
     int aligned;
+    uint32_t *flags_host; // pinned host copy of the slots' status words (no D2H copy after the batch), or null
 };
 
 // Shared tail of the re-rank kernels: containment check, final (distance,row) ordering, output.
@@ -465,6 +466,7 @@ __device__ __forceinline__ void rerank_finish(const RerankArgs &a, int qi, int t
         a.out_dist[(int64_t)qi * a.k + r] = d;
         a.out_labels[(int64_t)qi * a.k + r] = lab;
     }
+    if (a.flags_host && tid == 0) a.flags_host[qi] = atomicOr(&a.cs.flags[qi], 0u);
 }
 
 // One workgroup per query.  LDS: q[D] | sort keys u64[P] | cmp values f32[P]
@@ -692,10 +694,11 @@ __global__ __launch_bounds__(SEL_THREADS) void rerank_tiled_kernel(RerankArgs a)
 
 void launch_rerank(int metric, int order, const float *X, int D, const float *Q, int nq,
                    const float *qna, CandState cs, int kc, int k, const uint32_t *d_maxnorm2, float gamma,
-                   const int64_t *ids, float *out_dist, int64_t *out_labels, hipStream_t s)
+                   const int64_t *ids, float *out_dist, int64_t *out_labels, hipStream_t s, uint32_t *flags_host)
 {
     if (nq <= 0) return;
     RerankArgs a;
+    a.flags_host = flags_host;
     a.X = X; a.D = D; a.Q = Q; a.qna = qna; a.cs = cs; a.kc = kc; a.k = k;
     a.maxnorm2 = d_maxnorm2; a.gamma = gamma; a.ids = ids; a.out_dist = out_dist; a.out_labels = out_labels;
     a.aligned = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);

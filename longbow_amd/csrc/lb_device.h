@@ -120,14 +120,18 @@ void launch_select(CandState cs, const int *qsel, int nsel, int kc, uint32_t boo
                    bool striped = false);
 // approximate distances of `count` evenly spaced positions of [0, span) for up to 8 query slots, written
 // as entries to lists[q][0..count) (also clears the slots' flags); cosine: `nsel` extra workgroups compute
-// the slots' exact ||q||^2 into qna in the requested order
+// the slots' exact ||q||^2 into qna in the requested order.  norm2/rnorm given ("keys" mode, up to 64 slots):
+// the entries carry the MFMA pipeline's candidate keys instead of distances
 void launch_sample_scores(int metric, int order, const float *X, int D, int64_t span, uint32_t count,
                           const uint32_t *rowmap, const uint8_t *mask, const float *Q, const int *qsel, int nsel,
-                          CandState cs, float *qna, hipStream_t s);
+                          CandState cs, float *qna, hipStream_t s, const float *norm2 = nullptr,
+                          const float *rnorm = nullptr);
 // tau[q] = m-th smallest of lists[q][0..count) with the row bits saturated, cnt[q] = 0
 bool sample_tau_supported(uint32_t count, int m);
 // zero_stripes: also reset the slots' striped admission counters (at most 8 slots: the scan path)
-void launch_sample_tau(CandState cs, const int *qsel, int nsel, uint32_t count, int m, bool zero_stripes, hipStream_t s);
+// qna != null: `nsel` extra workgroups compute the slots' exact ||q||^2 (order) alongside
+void launch_sample_tau(CandState cs, const int *qsel, int nsel, uint32_t count, int m, bool zero_stripes, hipStream_t s,
+                       const float *Q = nullptr, int D = 0, float *qna = nullptr, int order = 0);
 // smap[i] = row behind the i-th of `count` evenly spaced positions of [0, span) (through rowmap if given)
 void launch_sample_map(const uint32_t *rowmap, int64_t span, uint32_t count, uint32_t *smap, hipStream_t s);
 
@@ -135,7 +139,7 @@ void launch_sample_map(const uint32_t *rowmap, int64_t span, uint32_t count, uin
 // gamma: relative rounding-error bound of the candidate inner products (depends on the contraction)
 void launch_rerank(int metric, int order, const float *X, int D, const float *Q, int nq,
                    const float *qna, CandState cs, int kc, int k, const uint32_t *d_maxnorm2, float gamma,
-                   const int64_t *ids, float *out_dist, int64_t *out_labels, hipStream_t s);
+                   const int64_t *ids, float *out_dist, int64_t *out_labels, hipStream_t s, uint32_t *flags_host = nullptr);
 
 // ||q||^2 per selected query slot in the requested accumulation order (cosine).
 void launch_query_norms(int order, const float *Q, const int *qsel, int nsel, int D, float *qna,
