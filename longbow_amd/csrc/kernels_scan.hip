@@ -365,7 +365,13 @@ __global__ __launch_bounds__(256) void scan_generic_kernel(ScanArgs a)
                 if (a.boot) {
                     a.cs.lists[(size_t)qj * a.cs.cap + (pos - a.row_begin)] = ent;
                 } else if (ent < a.cs.tau[qj]) {
-                    uint32_t pos = atomicAdd(&a.cs.cnt[qj], 1u);
+                    uint32_t pos;
+                    if (a.striped) {
+                        const uint32_t st = blockIdx.x & (LB_STRIPES - 1);
+                        pos = st + LB_STRIPES * atomicAdd(&a.cs.stripes[(j * LB_STRIPES + st) * LB_STRIPE_PAD], 1u);
+                    } else {
+                        pos = atomicAdd(&a.cs.cnt[qj], 1u);
+                    }
                     if (pos < a.cs.cap) a.cs.lists[(size_t)qj * a.cs.cap + pos] = ent;
                 }
             }
