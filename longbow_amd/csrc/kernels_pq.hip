@@ -151,7 +151,7 @@ __global__ __launch_bounds__(ADC_DMA_WAVES * 64) void adc_scan_dma_kernel(AdcArg
             if (src > last16) src = last16; // tail tile: stay inside the buffer (rows past the end are discarded)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(stage + slot * (64 * M) + i * 1024),
-                                             16, 0, 0);
+                                             16, 0, 2 /* nt: the codes stream through once */);
         }
     };
 

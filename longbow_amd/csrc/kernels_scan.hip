@@ -137,7 +137,7 @@ __global__ __launch_bounds__(SC_ROWS) void scan_kernel(ScanArgs a)
             if (MAPPED) row = rid[MAPPED ? i : 0];
             int k = d0 + p * 4;
             if (k > D - 4) k = D - 4; // D % 4 == 0 here; chunks past D are never consumed
-            stg[i] = *reinterpret_cast<const f32x4 *>(a.X + row * (int64_t)D + k);
+            stg[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(a.X + row * (int64_t)D + k)); // streamed once
         }
     };
     auto write_stage = [&](int st) {
