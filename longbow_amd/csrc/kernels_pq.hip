@@ -222,6 +222,48 @@ static bool try_launch_adc_dma(const AdcArgs &a, hipStream_t s)
     return true;
 }
 
+// Exact ADC distances of `count` evenly spaced rows of [0, n) (sampled admission threshold, see
+// index.hip: sample_plan): the table sits in LDS as in the scan kernels, one lane per sampled row.
+__global__ __launch_bounds__(ADC_THREADS) void adc_sample_kernel(const float *table, int M, const uint8_t *codes, int64_t n,
+                                                                 uint32_t count, uint64_t *out, int vec16)
+{
+    extern __shared__ __attribute__((aligned(16))) float tab[];
+    for (int i = threadIdx.x; i < M * 256; i += ADC_THREADS) tab[i] = table[i];
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * ADC_THREADS + threadIdx.x; i < count; i += gridDim.x * ADC_THREADS) {
+        const int64_t row = (int64_t)(((uint64_t)i * (uint64_t)n) / count); // i, n < 2^32
+        const uint8_t *c = codes + row * (int64_t)M;
+        float sum = 0.f;
+        if (vec16) {
+            for (int g = 0; g < M / 16; g++) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(c + g * 16);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+#pragma unroll
+                    for (int b2 = 0; b2 < 4; b2++)
+                        sum = sum + tab[(g * 16 + t * 4 + b2) * 256 + ((w[t] >> (8 * b2)) & 0xffu)];
+            }
+        } else {
+            for (int j = 0; j < M; j++) sum = sum + tab[j * 256 + c[j]];
+        }
+        out[i] = pack_entry((float)sqrt((double)sum), (uint32_t)row);
+    }
+}
+
+void launch_adc_sample(const float *table, int M, const uint8_t *codes, int64_t n, uint32_t count, uint64_t *out,
+                       hipStream_t s)
+{
+    if (count == 0) return;
+    const int vec16 = (M % 16 == 0) && ((reinterpret_cast<uintptr_t>(codes) & 15) == 0);
+    const size_t shmem = (size_t)M * 256 * sizeof(float);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(adc_sample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)shmem);
+    uint32_t blocks = (count + ADC_THREADS - 1) / ADC_THREADS;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(adc_sample_kernel, dim3(blocks), dim3(ADC_THREADS), shmem, s, table, M, codes, n, count, out, vec16);
+}
+
 int g_adc_ablation = 0; // profiling aid (tools/bench_pq.py)
 
 void launch_adc_scan(const float *table, int M, const uint8_t *codes, int64_t row_begin, int64_t row_end,

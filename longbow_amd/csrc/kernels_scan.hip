@@ -731,6 +731,57 @@ __global__ __launch_bounds__(ST_THREADS) void sample_tau_kernel(CandState cs, co
     if (zero_stripes && tid < LB_STRIPES) cs.stripes[(blockIdx.x * LB_STRIPES + tid) * LB_STRIPE_PAD] = 0;
 }
 
+// Level 1 of a two-level threshold for samples larger than one list (PQ at 100M rows samples 390k
+// codes): workgroup g leaves the m smallest of in[g*8192 .. +8192) at lists[slot][g*m .. +m) (padded
+// with kEntryMax); sample_tau_kernel over those G*m entries then yields the exact m-th smallest of
+// the whole sample.
+__global__ __launch_bounds__(ST_THREADS) void sample_topm_kernel(const uint64_t *in, uint32_t count_total, int m,
+                                                                 CandState cs, int slot)
+{
+    __shared__ uint64_t wmin[2][ST_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t base = blockIdx.x * (uint32_t)(ST_THREADS * ST_PER);
+    uint64_t e[ST_PER];
+#pragma unroll
+    for (int i = 0; i < ST_PER; i++) {
+        const uint32_t idx = base + (uint32_t)tid + (uint32_t)ST_THREADS * i;
+        e[i] = idx < count_total ? in[idx] : kEntryMax;
+    }
+#define LB_CE(i, j)                         \
+    {                                       \
+        const uint64_t x = e[i], y = e[j];  \
+        e[i] = x < y ? x : y;               \
+        e[j] = x < y ? y : x;               \
+    }
+    LB_CE(0, 1) LB_CE(2, 3) LB_CE(4, 5) LB_CE(6, 7) LB_CE(0, 2) LB_CE(1, 3) LB_CE(4, 6) LB_CE(5, 7) LB_CE(1, 2)
+    LB_CE(5, 6) LB_CE(0, 4) LB_CE(3, 7) LB_CE(1, 5) LB_CE(2, 6) LB_CE(1, 4) LB_CE(3, 6) LB_CE(2, 4) LB_CE(3, 5)
+    LB_CE(3, 4)
+#undef LB_CE
+    uint64_t *out = cs.lists + (size_t)slot * cs.cap + (size_t)blockIdx.x * m;
+    for (int r = 0; r < m; r++) {
+        uint64_t v = wave_min_u64(e[0]);
+        if (lane == 0) wmin[r & 1][wave] = v;
+        __syncthreads();
+        v = row16_min_u64(wmin[r & 1][lane & 15]);
+        if (tid == 0) out[r] = v; // kEntryMax once the group is exhausted
+        if (v != kEntryMax && e[0] == v) {
+#pragma unroll
+            for (int i = 0; i + 1 < ST_PER; i++) e[i] = e[i + 1];
+            e[ST_PER - 1] = kEntryMax;
+        }
+    }
+}
+
+// returns the number of level-1 groups (entries for level 2 = groups * m), 0 if it does not fit the list
+uint32_t launch_sample_topm(const uint64_t *in, uint32_t count_total, int m, CandState cs, int slot, hipStream_t s)
+{
+    const uint32_t per = (uint32_t)(ST_THREADS * ST_PER);
+    const uint32_t groups = (count_total + per - 1) / per;
+    if (groups == 0 || (uint64_t)groups * (uint64_t)m > (uint64_t)per || (uint64_t)groups * (uint64_t)m > cs.cap) return 0;
+    hipLaunchKernelGGL(sample_topm_kernel, dim3(groups), dim3(ST_THREADS), 0, s, in, count_total, m, cs, slot);
+    return groups;
+}
+
 bool sample_tau_supported(uint32_t count, int m) { return count <= (uint32_t)(ST_THREADS * ST_PER) && m >= 1 && m <= 64; }
 
 void launch_sample_tau(CandState cs, const int *qsel, int nsel, uint32_t count, int m, bool zero_stripes, hipStream_t s,

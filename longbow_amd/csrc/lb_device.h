@@ -175,6 +175,12 @@ void launch_adc_scan(const float *table, int M, const uint8_t *codes, int64_t ro
                      int slot, const uint8_t *mask, CandState cs, bool boot, float *all_out,
                      int64_t out_base, hipStream_t s);
 
+// sampled threshold for the ADC scan: exact ADC entries of `count` evenly spaced rows -> out[count];
+// launch_sample_topm reduces them to groups*m entries at lists[slot] (returns groups, 0 = does not fit)
+void launch_adc_sample(const float *table, int M, const uint8_t *codes, int64_t n, uint32_t count, uint64_t *out,
+                       hipStream_t s);
+uint32_t launch_sample_topm(const uint64_t *in, uint32_t count_total, int m, CandState cs, int slot, hipStream_t s);
+
 // predicate masks (kernels_filter.hip): op = simd.CompareOp value; validity = Arrow LSB bitmap or null
 void launch_match_int64(const int64_t *src, int64_t n, int64_t val, int op, const uint8_t *validity,
                         int64_t valid_offset, uint8_t *dst, int combine, hipStream_t s);

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <mutex>
 #include <shared_mutex>
@@ -43,6 +44,9 @@ struct lb_gpu_pq {
     uint8_t *d_codes = nullptr;
     int64_t n = 0, capacity = 0;
     hipStream_t stream = nullptr;
+    // sample buffers (sampled admission threshold) are pooled: a 3 MB hipMalloc per search costs 0.25 ms
+    std::mutex samp_mu;
+    std::vector<std::pair<uint64_t *, size_t>> samp_free;
     mutable std::mutex err_mu;
     std::string last_error;
     void set_error(const char *fmt, ...)
@@ -87,9 +91,20 @@ struct PqScratch {
     CandState cs{};
     float *d_tables = nullptr;
     int *d_slots = nullptr;
+    uint64_t *d_samp = nullptr; // ADC entries of the sampled rows (borrowed from the handle's pool)
+    size_t samp_entries = 0;
+    lb_gpu_pq *owner = nullptr;
     ~PqScratch()
     {
         if (d_slots) (void)hipFree(d_slots);
+        if (d_samp && owner) {
+            std::lock_guard<std::mutex> g(owner->samp_mu);
+            if (owner->samp_free.size() < 4) {
+                owner->samp_free.emplace_back(d_samp, samp_entries);
+                d_samp = nullptr;
+            }
+        }
+        if (d_samp) (void)hipFree(d_samp);
         if (cs.lists) (void)hipFree(cs.lists);
         if (cs.cnt) (void)hipFree(cs.cnt);
         if (cs.tau) (void)hipFree(cs.tau);
@@ -139,6 +154,8 @@ void lb_gpu_pq_free(lb_gpu_pq *p)
         (void)hipDeviceSynchronize();
         if (p->d_codebooks) (void)hipFree(p->d_codebooks);
         if (p->d_codes) (void)hipFree(p->d_codes);
+        for (auto &b : p->samp_free) (void)hipFree(b.first);
+        p->samp_free.clear();
         if (p->stream) (void)hipStreamDestroy(p->stream);
     }
     delete p;
@@ -247,13 +264,57 @@ int lb_gpu_pq_search_device(lb_gpu_pq *p, int64_t nq, const float *d_queries, in
         for (int q = 0; q < nqi; q++) slots[q] = q;
         LBP_HIP(hipMalloc(&sc.d_slots, (size_t)nqi * sizeof(int)));
         LBP_HIP(hipMemcpyAsync(sc.d_slots, slots.data(), (size_t)nqi * sizeof(int), hipMemcpyHostToDevice, s));
-        auto scan_query = [&](int q, bool safe) {
+        // Sampled admission threshold (same reasoning as index.hip: sample_plan): one row in `stride` is scored
+        // exactly, the m-th best sample entry becomes tau, and the codes are walked once.  About m*stride rows
+        // pass (2048 at 100M rows); fewer than k or more than the list holds is detected by the select and
+        // the query is redone by the bootstrap schedule.  Two-level m-th minimum: the sample (390k entries at
+        // 100M rows) is larger than one list.
+        static const int sample_on = [] { const char *e = getenv("LB_SAMPLE_TAU"); return e ? atoi(e) : 1; }();
+        uint32_t samp_count = 0;
+        int samp_m = 0;
+        if (sample_on && p->n >= 65536 && p->n < ((int64_t)1 << 32)) {
+            const int64_t cnt = std::max<int64_t>(8192, (p->n + 255) / 256);
+            const double lambda = (double)k * (double)cnt / (double)p->n;
+            const int m = std::max(8, (int)std::ceil(lambda + 5.0 * std::sqrt(lambda) + 4.0));
+            const double loose = (double)m * ((double)p->n / (double)cnt) * (1.0 + 5.0 / std::sqrt((double)m));
+            if (m <= 32 && loose <= (double)(cap - (uint32_t)k) && cnt <= (int64_t)8192 * (8192 / m)) {
+                samp_count = (uint32_t)cnt;
+                samp_m = m;
+                sc.owner = p;
+                {
+                    std::lock_guard<std::mutex> g2(p->samp_mu);
+                    for (size_t i = 0; i < p->samp_free.size(); i++)
+                        if (p->samp_free[i].second >= samp_count) {
+                            sc.d_samp = p->samp_free[i].first;
+                            sc.samp_entries = p->samp_free[i].second;
+                            p->samp_free.erase(p->samp_free.begin() + (long)i);
+                            break;
+                        }
+                }
+                if (!sc.d_samp) {
+                    LBP_HIP(hipMalloc(&sc.d_samp, (size_t)samp_count * sizeof(uint64_t)));
+                    sc.samp_entries = samp_count;
+                }
+            }
+        }
+        // mode 0: sampled threshold, 1: bootstrap chunks, 2: chunks that cannot overflow the list
+        auto scan_query = [&](int q, int mode) {
             const float *tab = sc.d_tables + (size_t)q * p->M * 256;
             launch_init_cand(sc.cs, sc.d_slots + q, 1, s);
+            if (mode == 0 && samp_count) {
+                launch_adc_sample(tab, p->M, p->d_codes, p->n, samp_count, sc.d_samp, s);
+                const uint32_t groups = launch_sample_topm(sc.d_samp, samp_count, samp_m, sc.cs, q, s);
+                if (groups) {
+                    launch_sample_tau(sc.cs, sc.d_slots + q, 1, groups * (uint32_t)samp_m, samp_m, false, s);
+                    launch_adc_scan(tab, p->M, p->d_codes, 0, p->n, q, nullptr, sc.cs, false, nullptr, 0, s);
+                    launch_select(sc.cs, sc.d_slots + q, 1, k, 0u, s, false, (uint32_t)std::min<int64_t>(k, p->n));
+                    return;
+                }
+            }
             int64_t pos = 0;
             int step = 0;
             while (pos < p->n) {
-                const int64_t end = chunk_end_host(step, pos, p->n, k, cap, safe, /*big_boot=*/true);
+                const int64_t end = chunk_end_host(step, pos, p->n, k, cap, mode == 2, /*big_boot=*/true);
                 const bool boot = step == 0;
                 launch_adc_scan(tab, p->M, p->d_codes, pos, end, q, nullptr, sc.cs, boot, nullptr, 0, s);
                 launch_select(sc.cs, sc.d_slots + q, 1, k, boot ? (uint32_t)(end - pos) : 0u, s);
@@ -261,12 +322,21 @@ int lb_gpu_pq_search_device(lb_gpu_pq *p, int64_t nq, const float *d_queries, in
                 step++;
             }
         };
-        for (int q = 0; q < nqi; q++) scan_query(q, false);
+        for (int q = 0; q < nqi; q++) scan_query(q, 0);
         std::vector<uint32_t> flags(nqi);
-        LBP_HIP(hipMemcpyAsync(flags.data(), sc.cs.flags, (size_t)nqi * 4, hipMemcpyDeviceToHost, s));
-        LBP_HIP(hipStreamSynchronize(s));
+        auto read_flags = [&]() {
+            LBP_HIP(hipMemcpyAsync(flags.data(), sc.cs.flags, (size_t)nqi * 4, hipMemcpyDeviceToHost, s));
+            LBP_HIP(hipStreamSynchronize(s));
+        };
+        read_flags();
+        if (samp_count) {
+            bool any = false;
+            for (int q = 0; q < nqi; q++)
+                if (flags[q] & (1u | 4u)) { scan_query(q, 1); any = true; } // the sampled threshold missed
+            if (any) read_flags();
+        }
         for (int q = 0; q < nqi; q++)
-            if (flags[q] & 1u) scan_query(q, true); // chunks that cannot overflow the list
+            if (flags[q] & 1u) scan_query(q, 2); // chunks that cannot overflow the list
         launch_emit_lists(sc.cs, nullptr, nqi, k, nullptr, d_dist, d_labels, nullptr, s);
         LBP_HIP(hipStreamSynchronize(s));
     } catch (const HipErrP &e) {

@@ -70,6 +70,32 @@ def test_adc_search(oracle, n, nq, k):
     enc.Close()
 
 
+@pytest.mark.parametrize("n,dims,M,k", [(2_600_000, 64, 16, 100), (300_000, 40, 5, 7), (150_000, 32, 16, 1500)])
+def test_adc_search_sampled_threshold(oracle, n, dims, M, k):
+    """corpora >= 64k codes take the sampled admission threshold (two-level m-th minimum once the sample
+    exceeds one list: 2.6M rows -> 10157 sampled rows); heavy duplication makes the threshold tie and
+    forces the bootstrap fallback; k = 1500 is beyond what sampling supports at this size"""
+    gpu_or_skip()
+    rng, cb, codes, enc = _setup(oracle, dims, M, n, n + k)
+    Q = rng.random((2, dims), dtype=F)
+    lab, dist = enc.Search(Q, k)
+    for b in range(2):
+        d = oracle.adc_batch(oracle.build_adc_table(cb, Q[b]), codes)
+        oi, od, cnt = oracle.topk_canonical(d, k)
+        assert np.array_equal(lab[b], oi) and np.array_equal(dist[b], od)
+    enc.Close()
+    # 50 distinct code rows only: every distance ties thousands of times
+    from longbow_amd import pq
+    codes2 = codes[rng.integers(0, 50, min(n, 200_000))]
+    enc2 = pq.PQEncoder(pq.serialize_codebooks(cb))
+    enc2.add_codes(codes2)
+    lab, dist = enc2.Search(Q[:1], min(k, 100))
+    d = oracle.adc_batch(oracle.build_adc_table(cb, Q[0]), codes2)
+    oi, od, cnt = oracle.topk_canonical(d, min(k, 100))
+    assert np.array_equal(lab[0], oi) and np.array_equal(dist[0], od)
+    enc2.Close()
+
+
 def test_blob_validation():
     """DeserializePQEncoder error cases (persistence.go:38-56) and the K == 256 restriction"""
     gpu_or_skip()
