@@ -1,0 +1,170 @@
+// gpu_index_test.cpp -- the reference's own GPU-index tests (internal/gpu/gpu_test.go:13-83) restated
+// against the C++ host mirror (include/longbow_gpu.hpp), plus a brute-force parity check against the CPU
+// oracle (oracle/longbow_oracle.h: BruteForceIndex.SearchVectors semantics).  Test infrastructure: this is
+// one of the few places allowed to link the oracle.
+//
+// exit code 0 = all passed, 77 = skipped (no GPU: NewIndexWithConfig returned ErrGPUNotAvailable, the
+// reference's t.Skipf branch), anything else = failure.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <random>
+#include <vector>
+
+#include "longbow_gpu.hpp"
+extern "C" {
+#include "longbow_oracle.h"
+}
+
+using longbow::gpu::GPUConfig;
+using longbow::gpu::Index;
+using longbow::gpu::NewIndex;
+using longbow::gpu::NewIndexWithConfig;
+
+static int failures = 0;
+#define REQUIRE(cond, ...)                                                      \
+    do {                                                                        \
+        if (!(cond)) {                                                          \
+            std::fprintf(stderr, "FAIL %s:%d: %s -- ", __FILE__, __LINE__, #cond); \
+            std::fprintf(stderr, __VA_ARGS__);                                  \
+            std::fprintf(stderr, "\n");                                         \
+            failures++;                                                         \
+            return;                                                             \
+        }                                                                       \
+    } while (0)
+
+// TestGPUIndex_Basic (gpu_test.go:13-46)
+static void TestGPUIndex_Basic(bool &skipped)
+{
+    auto [raw, err] = NewIndexWithConfig(GPUConfig{0, 128});
+    if (err) { std::printf("SKIP GPU not available: %s\n", err.message.c_str()); skipped = true; return; }
+    std::unique_ptr<Index> idx(raw);
+    std::vector<float> vectors(128 * 10);
+    for (size_t i = 0; i < vectors.size(); i++) vectors[i] = (float)i * 0.01f;
+    std::vector<int64_t> ids(10);
+    for (size_t i = 0; i < ids.size(); i++) ids[i] = (int64_t)i;
+    err = idx->Add(ids, vectors);
+    REQUIRE(!err, "%s", err.message.c_str());
+    std::vector<float> query(vectors.begin(), vectors.begin() + 128);
+    std::vector<int64_t> rids;
+    std::vector<float> dist;
+    err = idx->Search(query, 5, rids, dist);
+    REQUIRE(!err, "%s", err.message.c_str());
+    REQUIRE(rids.size() == 5 && dist.size() == 5, "len %zu %zu", rids.size(), dist.size());
+    REQUIRE(rids[0] == 0, "first result %lld", (long long)rids[0]);
+    REQUIRE(dist[0] < 0.01f, "distance %g", dist[0]);
+    // Close is idempotent and later calls report "index is closed" (faiss_gpu.go:79,111,147-167)
+    REQUIRE(!idx->Close(), "close");
+    REQUIRE(!idx->Close(), "second close");
+    err = idx->Search(query, 5, rids, dist);
+    REQUIRE(err && err.message == "index is closed", "%s", err.message.c_str());
+    std::printf("ok   TestGPUIndex_Basic\n");
+}
+
+// TestGPUIndex_InvalidDimension (gpu_test.go:48-54)
+static void TestGPUIndex_InvalidDimension()
+{
+    auto [raw, err] = NewIndexWithConfig(GPUConfig{0, -1});
+    REQUIRE(raw == nullptr && err, "expected an error");
+    REQUIRE(err.message == "dimension must be positive, got -1", "%s", err.message.c_str());
+    std::printf("ok   TestGPUIndex_InvalidDimension\n");
+}
+
+// argument validation of Add / Search (faiss_gpu.go:83-90,115-117)
+static void TestGPUIndex_Validation()
+{
+    auto [raw, err] = NewIndex(); // device 0, dimension 128 (gpu_enabled.go:8-14)
+    REQUIRE(!err, "%s", err.message.c_str());
+    std::unique_ptr<Index> idx(raw);
+    err = idx->Add({0}, std::vector<float>(127));
+    REQUIRE(err && err.message == "vector data length 127 not divisible by dimension 128", "%s", err.message.c_str());
+    err = idx->Add({0, 1}, std::vector<float>(128));
+    REQUIRE(err && err.message == "id count 2 does not match vector count 1", "%s", err.message.c_str());
+    std::vector<int64_t> rids;
+    std::vector<float> dist;
+    err = idx->Search(std::vector<float>(64), 3, rids, dist);
+    REQUIRE(err && err.message == "query vector dimension 64 does not match index dimension 128", "%s", err.message.c_str());
+    // k > N: min(k, N) results (adaptive_index.go:215-222)
+    err = idx->Add({7, 8}, std::vector<float>(256, 0.5f));
+    REQUIRE(!err, "%s", err.message.c_str());
+    err = idx->Search(std::vector<float>(128, 0.5f), 10, rids, dist);
+    REQUIRE(!err && rids.size() == 2 && rids[0] == 7 && rids[1] == 8, "k > N gave %zu results", rids.size());
+    std::printf("ok   TestGPUIndex_Validation\n");
+}
+
+// BenchmarkGPUSearch's fixture (gpu_test.go:57-83) as a parity test against the oracle's brute force
+static void TestGPUIndex_BenchFixtureMatchesBruteForce()
+{
+    auto [raw, err] = NewIndexWithConfig(GPUConfig{0, 128});
+    REQUIRE(!err, "%s", err.message.c_str());
+    std::unique_ptr<Index> idx(raw);
+    const int n = 10000, d = 128, k = 10;
+    std::vector<float> vectors((size_t)n * d);
+    std::vector<int64_t> ids(n);
+    for (int i = 0; i < n; i++) {
+        ids[i] = i;
+        for (int j = 0; j < d; j++) vectors[(size_t)i * d + j] = (float)(i * d + j) * 0.001f;
+    }
+    err = idx->Add(ids, vectors);
+    REQUIRE(!err, "%s", err.message.c_str());
+    for (int probe : {0, 1, 4999, 9999}) {
+        std::vector<float> query(vectors.begin() + (size_t)probe * d, vectors.begin() + (size_t)(probe + 1) * d);
+        std::vector<int64_t> rids;
+        std::vector<float> dist;
+        err = idx->Search(query, k, rids, dist);
+        REQUIRE(!err, "%s", err.message.c_str());
+        std::vector<int64_t> oi(k);
+        std::vector<float> od(k);
+        lbo_search_batch(0, 0, query.data(), 1, vectors.data(), n, d, k, nullptr, nullptr, oi.data(), od.data(), 1);
+        for (int r = 0; r < k; r++) {
+            REQUIRE(rids[r] == oi[r], "probe %d rank %d: id %lld vs oracle %lld", probe, r, (long long)rids[r], (long long)oi[r]);
+            REQUIRE(dist[r] == od[r], "probe %d rank %d: distance %.9g vs oracle %.9g", probe, r, dist[r], od[r]);
+        }
+    }
+    std::printf("ok   TestGPUIndex_BenchFixtureMatchesBruteForce\n");
+}
+
+// all three metrics, batched, random data, ids != positions, against the oracle (bit-exact)
+static void TestGPUIndex_BatchedMetricsMatchOracle()
+{
+    const int n = 30000, d = 96, k = 25, nq = 70;
+    std::mt19937 rng(7);
+    std::uniform_real_distribution<float> u(0.f, 1.f);
+    std::vector<float> X((size_t)n * d), Q((size_t)nq * d);
+    for (auto &v : X) v = u(rng);
+    for (auto &v : Q) v = u(rng);
+    std::vector<int64_t> ids(n);
+    for (int i = 0; i < n; i++) ids[i] = 5 * (int64_t)i + 11;
+    for (int metric = 0; metric < 3; metric++) {
+        auto [raw, err] = NewIndexWithConfig(GPUConfig{0, d, metric});
+        REQUIRE(!err, "%s", err.message.c_str());
+        std::unique_ptr<Index> idx(raw);
+        err = idx->Add(ids, X);
+        REQUIRE(!err, "%s", err.message.c_str());
+        std::vector<int64_t> lab((size_t)nq * k), oi((size_t)nq * k);
+        std::vector<float> dist((size_t)nq * k), od((size_t)nq * k);
+        err = idx->SearchBatch(Q.data(), nq, k, lab.data(), dist.data());
+        REQUIRE(!err, "%s", err.message.c_str());
+        lbo_search_batch(metric, 0, Q.data(), nq, X.data(), n, d, k, nullptr, ids.data(), oi.data(), od.data(), 4);
+        for (size_t i = 0; i < lab.size(); i++) {
+            REQUIRE(lab[i] == oi[i], "metric %d entry %zu: id %lld vs %lld", metric, i, (long long)lab[i], (long long)oi[i]);
+            REQUIRE(dist[i] == od[i], "metric %d entry %zu: %.9g vs %.9g", metric, i, dist[i], od[i]);
+        }
+    }
+    std::printf("ok   TestGPUIndex_BatchedMetricsMatchOracle\n");
+}
+
+int main()
+{
+    TestGPUIndex_InvalidDimension(); // needs no device
+    bool skipped = false;
+    TestGPUIndex_Basic(skipped);
+    if (skipped) return failures ? 1 : 77;
+    TestGPUIndex_Validation();
+    TestGPUIndex_BenchFixtureMatchesBruteForce();
+    TestGPUIndex_BatchedMetricsMatchOracle();
+    if (failures) { std::fprintf(stderr, "%d test(s) failed\n", failures); return 1; }
+    std::printf("PASS\n");
+    return 0;
+}
