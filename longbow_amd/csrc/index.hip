@@ -492,9 +492,15 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         // 3D/16 MFMA accumulations + <=16-term block sums, plus the dropped lo*lo / residual terms
         gamma = 1.05f * ((float)(3 * h->dim / 16 + 24) * u24 + 3.0f * 3.8146973e-6f);
     }
+    // Tile choice by padded work (measured at 1M x 768: one 32-query tile pass 0.43 ms, one 128-query tile
+    // pass 1.49 ms; beyond ~10 query tiles the narrow kernel degrades): e.g. 128 and 256 queries take the
+    // wide tile, 160-192 and 320 the narrow one.
+    const int tiles_n = (nq + 31) / 32, tiles_w = (nq + 127) / 128;
+    const bool use_narrow = !split && narrow_ok && nq <= narrow_max &&
+                            (nq <= 32 || (tiles_n <= 10 && 0.43 * tiles_n < 1.49 * tiles_w));
     auto candidates = [&](int64_t b, int64_t e, const uint32_t *rowmap, bool boot) {
         ProfScope p(w, s, prof, 0);
-        if (!split && narrow_ok && nq <= narrow_max)
+        if (use_narrow)
             launch_gemm_filter_narrow(metric, gx, h->d_norm2, h->d_rnorm, b, e, h->dim, gq, nq, mask, rowmap,
                                       w->cs, boot, s);
         else
