@@ -134,7 +134,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_filter_kernel(GemmArgs a
     for (int tn = 0; tn < 2; tn++) {
         const int qj = q0 + wc * 64 + tn * 32 + l31;
         const uint64_t t = (qj < a.nq && !a.boot) ? a.cs.tau[qj] : 0ull;
-        tau_key[tn] = entry_key(t);
+        tau_key[tn] = tau_key_of(t);
         tau_row[tn] = entry_row(t);
     }
 

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
     const int qj = q0 + l31;
     const bool qok = qj < a.nq;
     const uint64_t tau = (qok && !a.boot) ? a.cs.tau[qj] : 0ull;
-    const float tk = entry_key(tau);
+    const float tk = tau_key_of(tau);
     const uint32_t tr = entry_row(tau);
 
     // DMA sources: A instruction i of this wave fills rows 64*wave + 8i .. +7; the wave's single

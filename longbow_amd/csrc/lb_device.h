@@ -27,6 +27,13 @@ __host__ __device__ __forceinline__ uint64_t pack_entry(float key, uint32_t row)
 }
 __host__ __device__ __forceinline__ float entry_key(uint64_t e) { return sortable_f32((uint32_t)(e >> 32)); }
 __host__ __device__ __forceinline__ uint32_t entry_row(uint64_t e) { return (uint32_t)e; }
+// Threshold in the (key, row) form the MFMA kernels test in the float domain.  "No threshold yet"
+// (kEntryMax: e.g. a bootstrap chunk with fewer visible rows than candidates to keep) decodes to
+// a NaN key, which would admit nothing -- it must admit every row instead.
+__host__ __device__ __forceinline__ float tau_key_of(uint64_t tau)
+{
+    return tau == ~0ull ? __builtin_huge_valf() : entry_key(tau);
+}
 
 inline uint32_t next_pow2_host(uint32_t v)
 {

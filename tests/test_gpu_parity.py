@@ -250,6 +250,28 @@ def test_sampled_threshold_first_pass(oracle):
         lib.lb_debug_set_sample_tau(1)
 
 
+def test_bootstrap_chunk_entirely_hidden(oracle):
+    """a predicate that hides a contiguous prefix (e.g. `timestamp > T` on time-ordered rows) leaves the
+    bootstrap chunk without a single visible row: the "no threshold yet" state must then admit every row
+    of the next chunk (regression: the MFMA kernels decoded it as NaN and admitted nothing)"""
+    gpu_or_skip()
+    rng = np.random.default_rng(99)
+    n, d = 60000, 64                              # below the sampled-threshold limit: classic schedule
+    X = rng.random((n, d), dtype=F)
+    Q = rng.random((300, d), dtype=F)
+    mask = np.ones(n, np.uint8)
+    mask[:2500] = 0                               # 95.8 % visible: the per-row mask test, not the compacted list
+    for metric in (0, 1, 2):
+        idx = new_index(d, metric)
+        idx.Add(None, X)
+        idx.set_filter(mask)
+        for nq in (1, 6, 16, 300):
+            lab, dist = idx.SearchBatch(Q[:nq], 50)
+            oi, od = oracle.search_batch(metric, Q[:nq], X, 50, mask=mask, nthreads=8)
+            assert_same(lab, dist, oi, od, f"metric {metric} nq {nq}")
+        idx.Close()
+
+
 def test_adversarial_order_forces_list_overflow(oracle):
     """rows sorted from worst to best: every row is admitted, the candidate lists overflow, and the
     library must fall back to overflow-proof chunking and still be exact"""
