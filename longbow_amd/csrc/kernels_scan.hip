@@ -9,8 +9,12 @@
 // BruteForceIndex.SearchVectors (internal/store/adaptive_index.go:180-211).
 // Each lane owns one corpus row and carries that row's f32 accumulator chain(s)
 // across the D dimension in the reference's order; rows are staged through LDS in
-// coalesced 256-B pieces (128 rows x 64 floats per stage, double buffered) so HBM
-// sees full lines while every lane walks its own row.  No FMA contraction here.
+// coalesced 256-B pieces (128 rows x 64 floats per stage; one LDS stage plus a
+// register-held prefetch, non-temporal loads) so HBM sees full lines while every lane
+// walks its own row.  No FMA contraction here.
+//
+// Also here: the sampled admission threshold (sample_scores_kernel, sample_tau_kernel,
+// sample_topm_kernel; see index.hip: sample_plan) that lets a search walk the corpus once.
 #include "lb_device.h"
 
 #pragma clang fp contract(off)
