@@ -51,3 +51,18 @@ def search_hybrid_candidates(index, query, k, is_live=None):
         keep &= np.array([bool(is_live(int(i))) if i >= 0 else False for i in ids])
     ids, dist = ids[keep][:k], dist[keep][:k]
     return ids, dist
+
+
+def calculate_adaptive_limit(k, matches, total):
+    """calculateAdaptiveLimit (internal/store/adaptive_search.go:7-39): search depth for POST-filtered search,
+    k * clamp(total / matches, 2, 50) clamped to [k, total].  The GPU path does not need it (predicates are
+    applied inside the search: lb_gpu_index_set_filter / filter_int64), but callers that post-filter HNSW results
+    keep the reference's rule."""
+    if total == 0 or matches == 0:
+        return int(k)
+    factor = 1.0 / (float(matches) / float(total))
+    factor = 50.0 if factor > 50.0 else factor
+    factor = 2.0 if factor < 2.0 else factor
+    limit = int(float(k) * factor)
+    limit = total if limit > total else limit
+    return int(k) if limit < k else int(limit)

@@ -177,6 +177,12 @@ def main():
                   "op": "rrf", "dense": [0, 1], "sparse": [1, 0], "k": 1, "limit": 10, "expected_ids": [0, 1],
                   "expected_scores": [float(np.float32(0.5 + 1.0 / 3.0))] * 2, "expect_top": None})
 
+    # calculateAdaptiveLimit table (internal/store/adaptive_search_test.go:7-72): (k, matches, total) -> want
+    cases.append({"name": "adaptive_limit_table", "src": "internal/store/adaptive_search_test.go:7-72",
+                  "op": "adaptive_limit",
+                  "rows": [[10, 1000, 1000, 20], [10, 500, 1000, 20], [10, 100, 1000, 100], [10, 20, 1000, 500],
+                           [10, 10, 1000, 500], [10, 0, 1000, 10], [10, 0, 0, 10], [100, 50, 200, 200]]})
+
     # pack/unpack 8 bytes <-> 2 floats (internal/store/hnsw_pq_test.go:37-70): layout only
     cases.append({"name": "pq_pack_8bytes", "src": "internal/store/hnsw_pq_test.go:61-69",
                   "op": "pack", "bytes": [1, 2, 3, 4, 250, 251, 252, 253], "n_floats": 2})

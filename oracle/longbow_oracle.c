@@ -615,3 +615,17 @@ void lbo_fill_codes(uint8_t *dst, int64_t n, uint64_t seed, int64_t offset)
     for (int64_t i = 0; i < n; i++)
         dst[i] = (uint8_t)(splitmix64_at(seed, (uint64_t)(offset + i)) >> 56);
 }
+
+/* internal/store/adaptive_search.go:7-39 */
+int lbo_adaptive_limit(int k, uint64_t matches, int total)
+{
+    if (total == 0 || matches == 0) return k;
+    const double selectivity = (double)matches / (double)total;
+    double factor = 1.0 / selectivity;
+    if (factor > 50.0) factor = 50.0;
+    if (factor < 2.0) factor = 2.0;
+    int limit = (int)((double)k * factor);
+    if (limit > total) limit = total;
+    if (limit < k) limit = k;
+    return limit;
+}

@@ -134,6 +134,11 @@ void lbo_and_bytes(uint8_t *dst, const uint8_t *src, int64_t n);
 /* store.ReciprocalRankFusion (internal/store/rrf.go:10-51): f64 accumulation dense then sparse,
  * Score = float32(sum); sorted by score descending (canonical tie order: lower id first).
  * ids < 0 are padding.  Returns the number of fused results written (<= limit if limit > 0). */
+/* calculateAdaptiveLimit (internal/store/adaptive_search.go:7-39): search depth for post-filtered
+ * search from the filter's selectivity: k * clamp(total/matches, 2, 50), clamped to [k, total];
+ * k when total == 0 or matches == 0. */
+int lbo_adaptive_limit(int k, uint64_t matches, int total);
+
 int lbo_rrf(const int64_t *dense, int nd, const int64_t *sparse, int ns, int k, int limit,
             int64_t *out_ids, float *out_scores);
 

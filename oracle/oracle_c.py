@@ -84,6 +84,8 @@ def lib():
         L.lbo_match_float32.argtypes = [_f32p, C.c_int64, C.c_float, C.c_int, _u8p]
         L.lbo_and_bytes.restype = None
         L.lbo_and_bytes.argtypes = [_u8p, _u8p, C.c_int64]
+        L.lbo_adaptive_limit.restype = C.c_int
+        L.lbo_adaptive_limit.argtypes = [C.c_int, C.c_uint64, C.c_int]
         L.lbo_rrf.restype = C.c_int
         L.lbo_rrf.argtypes = [_i64p, C.c_int, _i64p, C.c_int, C.c_int, C.c_int, _i64p, _f32p]
         L.lbo_fill_uniform.restype = None
@@ -290,3 +292,8 @@ def cpu_baseline(metric, queries, flat, k, nthreads, simd=1):
     secs = lib().lbo_cpu_baseline(metric, queries, nq, flat.reshape(-1), flat.shape[0], dims, k,
                                   nthreads, simd, oi, od)
     return secs, oi, od
+
+
+def adaptive_limit(k, matches, total):
+    """calculateAdaptiveLimit (internal/store/adaptive_search.go:7-39)"""
+    return int(lib().lbo_adaptive_limit(int(k), int(matches), int(total)))

@@ -175,3 +175,11 @@ def splitmix64_uniform(n, seed, offset=0):
         z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
         z = z ^ (z >> np.uint64(31))
     return ((z >> np.uint64(40)).astype(np.float32) * F(1.0 / 16777216.0)).astype(F)
+
+
+def adaptive_limit(k, matches, total):
+    """calculateAdaptiveLimit (internal/store/adaptive_search.go:7-39), independent restatement"""
+    if total == 0 or matches == 0:
+        return k
+    factor = min(max(1.0 / (float(matches) / float(total)), 2.0), 50.0)
+    return max(min(int(float(k) * factor), total), k)

@@ -43,3 +43,12 @@ def test_codebook_blob_layout():
     assert struct.unpack("<III", blob[:12]) == (8, 2, 256)
     assert len(blob) == 12 + 2 * 256 * 4 * 4
     assert np.array_equal(np.frombuffer(blob[12:], "<f4").reshape(2, 256, 4), cb)
+
+
+def test_calculate_adaptive_limit_matches_oracle(oracle):
+    """host mirror of calculateAdaptiveLimit against the oracle over a grid (incl. the clamps)"""
+    from longbow_amd import hybrid
+    for k in (1, 10, 100):
+        for total in (0, 1, 50, 1000, 10**6):
+            for matches in (0, 1, 2, total // 50 if total else 0, total // 10 if total else 0, total):
+                assert hybrid.calculate_adaptive_limit(k, matches, total) == oracle.adaptive_limit(k, matches, total)

@@ -310,3 +310,12 @@ def test_golden_rrf(oracle, golden):
     assert len(oracle.rrf([], [], 60, 10)[0]) == 0            # both empty -> nil
     ids, sc = oracle.rrf([5, 6, 7], [7, 8], 0, 2)             # k <= 0 -> 60; limit
     assert len(ids) == 2 and ids[0] == 7
+
+
+def test_golden_adaptive_limit(oracle, golden):
+    from oracle import oracle_np
+    rows = [c for c in golden if c["op"] == "adaptive_limit"][0]["rows"]
+    assert len(rows) == 8
+    for k, matches, total, want in rows:
+        assert oracle.adaptive_limit(k, matches, total) == want
+        assert oracle_np.adaptive_limit(k, matches, total) == want
