@@ -495,14 +495,22 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     // Tile choice by padded work (measured at 1M x 768: one 32-query tile pass 0.43 ms, one 128-query tile
     // pass 1.49 ms; beyond ~10 query tiles the narrow kernel degrades): e.g. 128 and 256 queries take the
     // wide tile, 160-192 and 320 the narrow one.
-    const int tiles_n = (nq + 31) / 32, tiles_w = (nq + 127) / 128;
-    const bool use_narrow = !split && narrow_ok && nq <= narrow_max &&
-                            (nq <= 32 || (tiles_n <= 10 && 0.43 * tiles_n < 1.49 * tiles_w));
+    // Costs per corpus pass in ms at 1M x 768 (only their ratios matter): 32-query tile 0.43, 64-query tile
+    // 0.80 (MFMA-bound: 0.63 ms of f32 MFMA per pass), 128-query tile 1.49.
+    static const int force64 = [] { const char *e = getenv("LB_NARROW_TILE64"); return e ? atoi(e) : -1; }();
+    const double kCost64 = 0.80; // measured: 64 queries 0.97 ms, 192 queries 2.48 ms per search
+    const int tiles_n = (nq + 31) / 32, tiles_64 = (nq + 63) / 64, tiles_w = (nq + 127) / 128;
+    const double c32 = (nq <= 32 || tiles_n <= 10) ? 0.43 * tiles_n : 1e9, c64 = kCost64 * tiles_64, cw = 1.49 * tiles_w;
+    const bool narrow_allowed = !split && narrow_ok && nq <= narrow_max;
+    bool use_narrow = narrow_allowed && (nq <= 32 || std::min(c32, c64) < cw);
+    bool tile64 = use_narrow && nq > 32 && c64 <= c32;
+    if (force64 == 0) { tile64 = false; use_narrow = narrow_allowed && (nq <= 32 || c32 < cw); }
+    if (force64 == 1 && narrow_allowed && nq > 32) { use_narrow = true; tile64 = true; }
     auto candidates = [&](int64_t b, int64_t e, const uint32_t *rowmap, bool boot) {
         ProfScope p(w, s, prof, 0);
         if (use_narrow)
             launch_gemm_filter_narrow(metric, gx, h->d_norm2, h->d_rnorm, b, e, h->dim, gq, nq, mask, rowmap,
-                                      w->cs, boot, s);
+                                      w->cs, boot, s, tile64);
         else
             launch_gemm_filter(metric, gx, h->d_norm2, h->d_rnorm, b, e, h->dim, gq, nq, mask, rowmap, w->cs,
                                boot, split, s);

@@ -10,6 +10,11 @@
 // tile; LDS 2 x (32 + 4) KiB, two workgroups per CU = 64 KiB of corpus bytes in flight per CU.
 // LDS image, swizzle, k permutation and the epilogue (key, branch-free admission, one atomic per
 // lane) are those of the wide kernel.
+//
+// The kernel is a template over the tile: <256 rows, 32 queries> (above) and <128 rows, 64 queries>
+// for batches of 33..~200 queries (each wave 32 rows x 64 queries, again 2 MFMA tiles; LDS
+// 2 x (16 + 8) KiB, three workgroups per CU), which would otherwise pay a second corpus pass per
+// extra 32 queries.
 #include "lb_device.h"
 
 namespace lb {
@@ -17,8 +22,6 @@ namespace lb {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int NBM = 256; // corpus rows per tile
-constexpr int NBN = 32;  // queries per tile
 constexpr int NBK = 32;
 constexpr int NTHREADS = 256;
 
@@ -39,9 +42,15 @@ struct NarrowArgs {
 
 __device__ __forceinline__ int nswz(int row, int chunk) { return row * NBK + ((chunk ^ ((row >> 1) & 7)) << 2); }
 
-template <int METRIC>
+template <int METRIC, int NBM, int NBN> // NBM corpus rows x NBN queries per tile: <256, 32> or <128, 64>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowArgs a)
 {
+    constexpr int WROWS = NBM / 4;   // corpus rows per wave
+    constexpr int TM = WROWS / 32;   // MFMA row tiles per wave
+    constexpr int TN = NBN / 32;     // MFMA query tiles per wave
+    constexpr int NA = WROWS / 8;    // A DMA instructions per wave and K-step (8 rows x 128 B each)
+    constexpr int NB = NBN / 32;     // B DMA instructions per wave and K-step
+    static_assert(TM * TN == 2, "two MFMA tiles (32 accumulator VGPRs) per wave");
     const int b = blockIdx.x;
     const int xcd = b & 7;
     const int in_xcd = b >> 3;
@@ -68,53 +77,63 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
         if (pos > last_row) pos = last_row;
         return a.rowmap ? (int64_t)a.rowmap[pos] : pos;
     };
-    {
+    if (tid < NBM) {
         const bool in_range = row0 + tid <= last_row;
         const int64_t ri = corpus_row(row0 + tid);
         s_aux[tid] = METRIC == METRIC_L2 ? a.norm2[ri] : (METRIC == METRIC_COS ? a.rnorm[ri] : 0.f);
         s_vis[tid] = (in_range && (!a.mask || a.mask[ri])) ? (uint8_t)1 : (uint8_t)0;
         s_rowid[tid] = (uint32_t)ri;
     }
-    const int qj = q0 + l31;
-    const bool qok = qj < a.nq;
-    const uint64_t tau = (qok && !a.boot) ? a.cs.tau[qj] : 0ull;
-    const float tk = tau_key_of(tau);
-    const uint32_t tr = entry_row(tau);
-
-    // DMA sources: A instruction i of this wave fills rows 64*wave + 8i .. +7; the wave's single
-    // B instruction fills query rows 8*wave .. +7.  Lane l lands at (row l/8, chunk position l%8).
-    const float *srcA[8];
+    float tk[TN];
+    uint32_t tr[TN];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int row = wave * 64 + i * 8 + (lane >> 3);
+    for (int tn = 0; tn < TN; tn++) {
+        const int qj = q0 + tn * 32 + l31;
+        const uint64_t tau = (qj < a.nq && !a.boot) ? a.cs.tau[qj] : 0ull;
+        tk[tn] = tau_key_of(tau);
+        tr[tn] = entry_row(tau);
+    }
+
+    // DMA sources: A instruction i of this wave fills rows WROWS*wave + 8i .. +7 (the rows the wave
+    // consumes); its B instructions fill query rows 8*NB*wave + 8i .. +7.  Lane l lands at (row l/8,
+    // chunk position l%8).
+    const float *srcA[NA];
+#pragma unroll
+    for (int i = 0; i < NA; i++) {
+        const int row = wave * WROWS + i * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((row >> 1) & 7);
         srcA[i] = a.X + corpus_row(row0 + row) * (int64_t)a.D + 4 * c;
     }
-    const float *srcB;
-    {
-        const int row = wave * 8 + (lane >> 3);
+    const float *srcB[NB];
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+        const int row = (wave * NB + i) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((row >> 1) & 7);
         int qr = q0 + row;
         if (qr > last_q) qr = last_q;
-        srcB = a.Q + (int64_t)qr * a.D + 4 * c;
+        srcB[i] = a.Q + (int64_t)qr * a.D + 4 * c;
     }
     auto stage_in = [&](int stage, int k0) {
         float *A = lds_all + stage * STAGE_F;
         float *B = A + NBM * NBK;
 #pragma unroll
-        for (int i = 0; i < 8; i++)
+        for (int i = 0; i < NA; i++)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcA[i] + k0),
-                                             (__attribute__((address_space(3))) void *)(A + (wave * 64 + i * 8) * NBK),
+                                             (__attribute__((address_space(3))) void *)(A + (wave * WROWS + i * 8) * NBK),
                                              16, 0, 2 /* nt: the corpus streams through once */);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcB + k0),
-                                         (__attribute__((address_space(3))) void *)(B + wave * 8 * NBK), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NB; i++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcB[i] + k0),
+                                             (__attribute__((address_space(3))) void *)(B + (wave * NB + i) * 8 * NBK), 16, 0, 0);
     };
 
-    f32x16 acc[2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < TM; i++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
     const int nk = a.D / NBK; // D % 32 == 0 (launcher)
     stage_in(0, 0);
@@ -124,38 +143,42 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
         if (kt + 1 < nk) stage_in(cur ^ 1, (kt + 1) * NBK);
         const float *As = lds_all + cur * STAGE_F;
         const float *Bs = As + NBM * NBK;
-        f32x4 fa[2][2], fb[2];
+        f32x4 fa[2][TM], fb[2][TN];
 #pragma unroll
-        for (int t = 0; t < 2; t++) fa[0][t] = *reinterpret_cast<const f32x4 *>(&As[nswz(wave * 64 + t * 32 + l31, h)]);
-        fb[0] = *reinterpret_cast<const f32x4 *>(&Bs[nswz(l31, h)]);
+        for (int t = 0; t < TM; t++) fa[0][t] = *reinterpret_cast<const f32x4 *>(&As[nswz(wave * WROWS + t * 32 + l31, h)]);
+#pragma unroll
+        for (int t = 0; t < TN; t++) fb[0][t] = *reinterpret_cast<const f32x4 *>(&Bs[nswz(t * 32 + l31, h)]);
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             const int cb = s & 1, nb = cb ^ 1;
             if (s < 3) {
                 const int ch = 2 * (s + 1) + h;
 #pragma unroll
-                for (int t = 0; t < 2; t++)
-                    fa[nb][t] = *reinterpret_cast<const f32x4 *>(&As[nswz(wave * 64 + t * 32 + l31, ch)]);
-                fb[nb] = *reinterpret_cast<const f32x4 *>(&Bs[nswz(l31, ch)]);
+                for (int t = 0; t < TM; t++)
+                    fa[nb][t] = *reinterpret_cast<const f32x4 *>(&As[nswz(wave * WROWS + t * 32 + l31, ch)]);
+#pragma unroll
+                for (int t = 0; t < TN; t++) fb[nb][t] = *reinterpret_cast<const f32x4 *>(&Bs[nswz(t * 32 + l31, ch)]);
             }
 #pragma unroll
             for (int e = 0; e < 4; e++)
 #pragma unroll
-                for (int tm = 0; tm < 2; tm++)
-                    acc[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb][tm][e], fb[cb][e], acc[tm], 0, 0, 0);
+                for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+                    for (int tn = 0; tn < TN; tn++)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb][tm][e], fb[cb][tn][e], acc[tm][tn], 0, 0, 0);
         }
         __syncthreads();
     }
 
     // ---- epilogue (as in gemm_filter_kernel) -------------------------------------------------
-    float aux[2][4][4];
-    uint32_t rid[2][4][4];
-    uint32_t vbits = 0;
+    float aux[TM][4][4];
+    uint32_t rid[TM][4][4];
+    uint32_t vbits = 0; // bit (tm*16 + g*4 + e)
 #pragma unroll
-    for (int tm = 0; tm < 2; tm++)
+    for (int tm = 0; tm < TM; tm++)
 #pragma unroll
         for (int g = 0; g < 4; g++) {
-            const int lr = wave * 64 + tm * 32 + 8 * g + 4 * h;
+            const int lr = wave * WROWS + tm * 32 + 8 * g + 4 * h;
             const f32x4 av = *reinterpret_cast<const f32x4 *>(&s_aux[lr]);
             const uint4 rv = *reinterpret_cast<const uint4 *>(&s_rowid[lr]);
             rid[tm][g][0] = rv.x; rid[tm][g][1] = rv.y; rid[tm][g][2] = rv.z; rid[tm][g][3] = rv.w;
@@ -169,51 +192,56 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
         if (METRIC == METRIC_COS) return -dot * ax;
         return -dot;
     };
-    uint64_t *list = a.cs.lists + (size_t)(qok ? qj : 0) * a.cs.cap;
-    if (a.boot) {
-        if (qok) {
 #pragma unroll
-            for (int tm = 0; tm < 2; tm++)
+    for (int tn = 0; tn < TN; tn++) {
+        const int qj = q0 + tn * 32 + l31;
+        const bool qok = qj < a.nq;
+        uint64_t *list = a.cs.lists + (size_t)(qok ? qj : 0) * a.cs.cap;
+        if (a.boot) {
+            if (qok) {
 #pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    const int64_t rbase = row0 + wave * 64 + tm * 32 + 8 * g + 4 * h;
+                for (int tm = 0; tm < TM; tm++)
 #pragma unroll
-                    for (int e = 0; e < 4; e++)
-                        if (rbase + e < a.row_end)
-                            list[rbase + e - a.row_begin] =
-                                ((vbits >> (tm * 16 + g * 4 + e)) & 1u)
-                                    ? pack_entry(key_of(acc[tm][4 * g + e], aux[tm][g][e]), rid[tm][g][e])
-                                    : kEntryMax;
-                }
-        }
-        return;
-    }
-    uint32_t bits = 0;
+                    for (int g = 0; g < 4; g++) {
+                        const int64_t rbase = row0 + wave * WROWS + tm * 32 + 8 * g + 4 * h;
 #pragma unroll
-    for (int tm = 0; tm < 2; tm++)
-#pragma unroll
-        for (int g = 0; g < 4; g++)
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const float key = key_of(acc[tm][4 * g + e], aux[tm][g][e]);
-                const uint32_t ri = rid[tm][g][e];
-                const uint32_t lt = (uint32_t)(key < tk) | ((uint32_t)(key == tk) & (uint32_t)(ri < tr));
-                bits |= lt << (tm * 16 + g * 4 + e);
+                        for (int e = 0; e < 4; e++)
+                            if (rbase + e < a.row_end)
+                                list[rbase + e - a.row_begin] =
+                                    ((vbits >> (tm * 16 + g * 4 + e)) & 1u)
+                                        ? pack_entry(key_of(acc[tm][tn][4 * g + e], aux[tm][g][e]), rid[tm][g][e])
+                                        : kEntryMax;
+                    }
             }
-    bits &= vbits; // out-of-range rows and queries never pass (tau of a padded query decodes to NaN)
-    if (bits) {
-        uint32_t pos = atomicAdd(&a.cs.cnt[qj], (uint32_t)__builtin_popcount(bits));
+            continue;
+        }
+        uint32_t bits = 0;
 #pragma unroll
-        for (int tm = 0; tm < 2; tm++)
+        for (int tm = 0; tm < TM; tm++)
 #pragma unroll
             for (int g = 0; g < 4; g++)
 #pragma unroll
-                for (int e = 0; e < 4; e++)
-                    if (bits & (1u << (tm * 16 + g * 4 + e))) {
-                        const uint32_t ri = rid[tm][g][e];
-                        if (pos < a.cs.cap) list[pos] = pack_entry(key_of(acc[tm][4 * g + e], aux[tm][g][e]), ri);
-                        pos++;
-                    }
+                for (int e = 0; e < 4; e++) {
+                    const float key = key_of(acc[tm][tn][4 * g + e], aux[tm][g][e]);
+                    const uint32_t ri = rid[tm][g][e];
+                    const uint32_t lt = (uint32_t)(key < tk[tn]) | ((uint32_t)(key == tk[tn]) & (uint32_t)(ri < tr[tn]));
+                    bits |= lt << (tm * 16 + g * 4 + e);
+                }
+        bits &= vbits; // out-of-range rows and queries never pass (tau of a padded query decodes to NaN)
+        if (bits) {
+            uint32_t pos = atomicAdd(&a.cs.cnt[qj], (uint32_t)__builtin_popcount(bits));
+#pragma unroll
+            for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        if (bits & (1u << (tm * 16 + g * 4 + e))) {
+                            const uint32_t ri = rid[tm][g][e];
+                            if (pos < a.cs.cap) list[pos] = pack_entry(key_of(acc[tm][tn][4 * g + e], aux[tm][g][e]), ri);
+                            pos++;
+                        }
+        }
     }
 }
 
@@ -221,20 +249,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
 void launch_gemm_filter_narrow(int metric, const float *X, const float *norm2, const float *rnorm,
                                int64_t row_begin, int64_t row_end, int D, const float *Q, int nq,
                                const uint8_t *mask, const uint32_t *rowmap, CandState cs, bool boot,
-                               hipStream_t s)
+                               hipStream_t s, bool tile64)
 {
     if (row_end <= row_begin || nq <= 0) return;
     NarrowArgs a;
     a.rowmap = rowmap;
     a.X = X; a.norm2 = norm2; a.rnorm = rnorm; a.row_begin = row_begin; a.row_end = row_end; a.D = D;
     a.Q = Q; a.nq = nq; a.mask = mask; a.cs = cs; a.boot = boot ? 1 : 0;
-    a.n_row_tiles = (int)((row_end - row_begin + NBM - 1) / NBM);
-    a.n_q_tiles = (nq + NBN - 1) / NBN;
+    const int bm = tile64 ? 128 : 256, bn = tile64 ? 64 : 32;
+    a.n_row_tiles = (int)((row_end - row_begin + bm - 1) / bm);
+    a.n_q_tiles = (nq + bn - 1) / bn;
     const int groups = (a.n_row_tiles + 7) / 8;
     dim3 grid((unsigned)(groups * 8 * a.n_q_tiles));
-    if (metric == METRIC_L2) hipLaunchKernelGGL(gemm_filter_narrow_kernel<METRIC_L2>, grid, dim3(NTHREADS), 0, s, a);
-    else if (metric == METRIC_COS) hipLaunchKernelGGL(gemm_filter_narrow_kernel<METRIC_COS>, grid, dim3(NTHREADS), 0, s, a);
-    else hipLaunchKernelGGL(gemm_filter_narrow_kernel<METRIC_DOT>, grid, dim3(NTHREADS), 0, s, a);
+#define LB_NARROW(M)                                                                                          \
+    do {                                                                                                      \
+        if (tile64) hipLaunchKernelGGL((gemm_filter_narrow_kernel<M, 128, 64>), grid, dim3(NTHREADS), 0, s, a); \
+        else hipLaunchKernelGGL((gemm_filter_narrow_kernel<M, 256, 32>), grid, dim3(NTHREADS), 0, s, a);        \
+    } while (0)
+    if (metric == METRIC_L2) LB_NARROW(METRIC_L2);
+    else if (metric == METRIC_COS) LB_NARROW(METRIC_COS);
+    else LB_NARROW(METRIC_DOT);
+#undef LB_NARROW
 }
 
 } // namespace lb
