@@ -128,6 +128,7 @@ struct lb_gpu_index {
     int64_t n = 0, capacity = 0;
     float *d_norm2 = nullptr, *d_rnorm = nullptr;
     uint32_t *d_maxnorm2 = nullptr;
+    bool nonfinite = false; // some row holds an inf / NaN: every search takes the exact scan path
     int64_t *d_ids = nullptr;
     bool has_ids = false;
     uint8_t *d_mask = nullptr;
@@ -456,7 +457,9 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     const bool narrow_ok = h->dim % 32 == 0 && ((reinterpret_cast<uintptr_t>(d_q) & 15) == 0);
     static const int narrow_min = [] { const char *e = getenv("LB_NARROW_MINQ"); return e ? atoi(e) : 5; }();
     static const int narrow_max = [] { const char *e = getenv("LB_NARROW_MAXQ"); return e ? atoi(e) : 384; }();
-    if (nq < (narrow_ok ? narrow_min : kGemmMinQ)) {
+    // rows with inf / NaN components: the MFMA pipeline's keys and error bounds assume finite data;
+    // the scan path orders non-finite distances canonically (NaN last)
+    if (h->nonfinite || nq < (narrow_ok ? narrow_min : kGemmMinQ)) {
         std::vector<int> all(nq);
         for (int i = 0; i < nq; i++) all[i] = i;
         scan_with_retry(h, w, s, d_q, nq, all, k, d_dist, d_lab, prof);
@@ -710,7 +713,10 @@ void finish_add(lb_gpu_index *h, int64_t n, const int64_t *ids_src, bool ids_on_
         hipLaunchKernelGGL(iota_ids_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->d_ids, start, n);
     }
     LB_HIP(hipMemsetAsync(h->d_mask + start, 1, (size_t)n, s));
+    uint32_t maxbits = 0; // max ||x||^2 so far, as float bits: >= +inf <=> a row with an inf or NaN component
+    LB_HIP(hipMemcpyAsync(&maxbits, h->d_maxnorm2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     LB_HIP(hipStreamSynchronize(s));
+    h->nonfinite = maxbits >= 0x7f800000u;
     h->n += n;
     sync_split_image(h);
     rebuild_rowmap(h); // appended rows are visible; keep the list in step with the corpus

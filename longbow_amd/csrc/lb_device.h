@@ -21,9 +21,14 @@ __host__ __device__ __forceinline__ float sortable_f32(uint32_t s)
     uint32_t u = (s & 0x80000000u) ? (s & 0x7fffffffu) : ~s;
     return __builtin_bit_cast(float, u);
 }
+// Canonical order of the reported lists: ascending distance, every NaN after +inf (whatever its sign
+// bit), ties by row.  (The reference's heap has no defined behaviour for NaN distances -- a NaN never
+// displaces anything, adaptive_index.go:206 -- so this only fixes what it leaves open.)
 __host__ __device__ __forceinline__ uint64_t pack_entry(float key, uint32_t row)
 {
-    return ((uint64_t)f32_sortable(key + 0.0f) << 32) | row; // +0.0f: -0 -> +0
+    key = key + 0.0f; // -0 -> +0
+    const uint32_t sk = (key != key) ? 0xffc00000u /* sortable image of the positive quiet NaN */ : f32_sortable(key);
+    return ((uint64_t)sk << 32) | row;
 }
 __host__ __device__ __forceinline__ float entry_key(uint64_t e) { return sortable_f32((uint32_t)(e >> 32)); }
 __host__ __device__ __forceinline__ uint32_t entry_row(uint64_t e) { return (uint32_t)e; }

@@ -227,8 +227,15 @@ int lbo_bruteforce_goheap(int metric, int order, const float *q, const float *fl
  * ====================================================================== */
 typedef struct { float d; int64_t i; } cand;
 
+/* canonical order: ascending distance, every NaN after +inf, ties by row index (the reference's heap
+ * leaves NaN undefined: a NaN never satisfies `dist < root`, adaptive_index.go:206) */
 static int cand_less(const cand *a, const cand *b)
 {
+    const int an = a->d != a->d, bn = b->d != b->d;
+    if (an || bn) {
+        if (an != bn) return bn;
+        return a->i < b->i;
+    }
     if (a->d < b->d) return 1;
     if (a->d > b->d) return 0;
     return a->i < b->i;

@@ -272,6 +272,33 @@ def test_bootstrap_chunk_entirely_hidden(oracle):
         idx.Close()
 
 
+def test_non_finite_rows_and_queries_rank_canonically(oracle):
+    """inf / NaN components: distances that are NaN rank after +inf, ties by row position, on every batch
+    size (an index holding non-finite rows always takes the exact scan path; a NaN query falls back to it)"""
+    gpu_or_skip()
+    rng = np.random.default_rng(404)
+    n, d = 70_000, 16
+    X = rng.random((n, d), dtype=F)
+    X[5] = np.inf
+    X[6] = np.nan
+    X[7] = -np.inf
+    X[40000, 3] = np.nan
+    Q = rng.random((20, d), dtype=F)
+    Q[3, 0] = np.nan
+    Q[11] = np.inf
+    clean = rng.random((n, d), dtype=F)
+    for metric in (0, 1, 2):
+        for corpus in (X, clean):
+            idx = new_index(d, metric)
+            idx.Add(None, corpus)
+            for nq in (1, 4, 20):
+                lab, dist = idx.SearchBatch(Q[:nq], 10)
+                oi, od = oracle.search_batch(metric, Q[:nq], corpus, 10, nthreads=4)
+                assert np.array_equal(lab, oi), f"metric {metric} nq {nq}: {np.argwhere(lab != oi)[:4]}"
+                assert np.array_equal(dist, od, equal_nan=True), f"metric {metric} nq {nq}"
+            idx.Close()
+
+
 def test_adversarial_order_forces_list_overflow(oracle):
     """rows sorted from worst to best: every row is admitted, the candidate lists overflow, and the
     library must fall back to overflow-proof chunking and still be exact"""

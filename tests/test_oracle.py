@@ -319,3 +319,14 @@ def test_golden_adaptive_limit(oracle, golden):
     for k, matches, total, want in rows:
         assert oracle.adaptive_limit(k, matches, total) == want
         assert oracle_np.adaptive_limit(k, matches, total) == want
+
+
+def test_canonical_order_puts_nan_last(oracle):
+    """canonical top-k: ascending, every NaN (either sign) after +inf, ties by index -- C and numpy agree"""
+    from oracle import oracle_np
+    d = np.array([0.5, np.nan, np.inf, 0.25, -np.inf, np.nan, 0.25, 3.0], F)
+    d[5] = np.frombuffer(np.uint32(0xFFC00000).tobytes(), F)[0]          # negative quiet NaN
+    ci, cd, cnt = oracle.topk_canonical(d, 8)
+    assert list(ci) == [4, 3, 6, 0, 7, 2, 1, 5] and cnt == 8
+    ni, nd = oracle_np.topk_canonical(d, 8)
+    assert list(ni) == list(ci) and np.array_equal(nd, cd, equal_nan=True)
