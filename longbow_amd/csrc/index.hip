@@ -300,11 +300,11 @@ struct SamplePlan {
     int m = 0;
 };
 std::atomic<int> g_sample_tau{[] { const char *e = getenv("LB_SAMPLE_TAU"); return e ? atoi(e) : 1; }()};
-static SamplePlan sample_plan(int64_t n, int keep, uint32_t cap)
+static SamplePlan sample_plan(int64_t n, int keep, uint32_t cap, uint32_t count_max = 8192u)
 {
     SamplePlan p;
     if (!g_sample_tau.load() || n < 65536) return p;
-    const uint32_t count = std::min<uint32_t>(cap, 8192u);
+    const uint32_t count = std::min<uint32_t>(cap, count_max);
     int m = 8;
     int64_t span = 0;
     for (int it = 0; it < 8; it++) {
@@ -336,7 +336,10 @@ bool run_scan_path(lb_gpu_index *h, Workspace *w, hipStream_t s, const float *d_
     const uint8_t *mask = rv.mask;
     const int kkeep = std::max(k, 1);
     const bool safe = mode == 2;
-    const SamplePlan sp = mode == 0 ? sample_plan(n, kkeep, w->cap) : SamplePlan{};
+    // (the latency path samples half as many rows: the sample launches are on its critical path, and the
+    // extra admissions -- ~2k instead of ~1.2k at 1M rows -- are spread over the striped counters)
+    static const uint32_t scan_count = [] { const char *e = getenv("LB_SCAN_SAMPLE"); return e ? (uint32_t)atoi(e) : 4096u; }();
+    const SamplePlan sp = mode == 0 ? sample_plan(n, kkeep, w->cap, scan_count) : SamplePlan{};
     if (!sp.on) launch_init_cand(w->cs, d_sel, nsel, s);
     for (int g0 = 0; g0 < nsel; g0 += kScanMaxQ) {
         const int gn = std::min(kScanMaxQ, nsel - g0);
