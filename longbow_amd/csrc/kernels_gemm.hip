@@ -120,23 +120,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_filter_kernel(GemmArgs a
         if (pos > last_row) pos = last_row;
         return a.rowmap ? (int64_t)a.rowmap[pos] : pos;
     };
-    if (tid < BM) {
-        const int64_t ri = corpus_row(row0 + tid);
-        s_aux[tid] = METRIC == METRIC_L2 ? a.norm2[ri] : (METRIC == METRIC_COS ? a.rnorm[ri] : 0.f);
-        const bool in_range = row0 + tid <= last_row;
-        s_vis[tid] = (in_range && (!a.mask || a.mask[ri])) ? (uint8_t)1 : (uint8_t)0;
-        s_rowid[tid] = (uint32_t)ri;
-    }
-    // admission thresholds of this lane's two queries, split into (key, row)
-    float tau_key[2];
-    uint32_t tau_row[2];
-#pragma unroll
-    for (int tn = 0; tn < 2; tn++) {
-        const int qj = q0 + wc * 64 + tn * 32 + l31;
-        const uint64_t t = (qj < a.nq && !a.boot) ? a.cs.tau[qj] : 0ull;
-        tau_key[tn] = tau_key_of(t);
-        tau_row[tn] = entry_row(t);
-    }
+    // (the tile's side inputs and thresholds are fetched AFTER the first stage's DMA has been issued, see
+    // below: they are not needed before the epilogue and would otherwise put two to three serial memory
+    // round trips in front of the first K-step)
+    const int64_t side_ri = corpus_row(row0 + (tid & (BM - 1)));
 
     // staging assignment: 4 chunks of 16 B per operand per thread
     int st_row[4], st_ch[4];
@@ -196,9 +183,33 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_filter_kernel(GemmArgs a
     };
 
     // prologue: stage 0
-    if (GLDS) {
-        glds_stage(0, 0);
-    } else {
+    if (GLDS) glds_stage(0, 0);
+    // one burst behind the DMA: side inputs of tile row (tid & 127) and this lane's two thresholds; nothing
+    // is consumed before every load has been issued
+    const float side_aux = METRIC == METRIC_L2 ? a.norm2[side_ri] : (METRIC == METRIC_COS ? a.rnorm[side_ri] : 0.f);
+    uint8_t side_vis = 1;
+    if (a.mask) side_vis = a.mask[side_ri];
+    uint64_t tau_raw[2];
+#pragma unroll
+    for (int tn = 0; tn < 2; tn++) {
+        const int qj = q0 + wc * 64 + tn * 32 + l31;
+        tau_raw[tn] = a.boot ? 0ull : a.cs.tau[qj < a.nq ? qj : a.nq - 1];
+        if (qj >= a.nq) tau_raw[tn] = 0ull;
+    }
+    if (tid < BM) {
+        s_aux[tid] = side_aux;
+        s_vis[tid] = (row0 + tid <= last_row && side_vis) ? (uint8_t)1 : (uint8_t)0;
+        s_rowid[tid] = (uint32_t)side_ri;
+    }
+    // admission thresholds of this lane's two queries, split into (key, row)
+    float tau_key[2];
+    uint32_t tau_row[2];
+#pragma unroll
+    for (int tn = 0; tn < 2; tn++) {
+        tau_key[tn] = tau_key_of(tau_raw[tn]);
+        tau_row[tn] = entry_row(tau_raw[tn]);
+    }
+    if (!GLDS) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             ra[i] = load_chunk<ALIGNED>(a.X, st_xrow[i], a.D, st_ch[i] * 4);
