@@ -77,22 +77,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
         if (pos > last_row) pos = last_row;
         return a.rowmap ? (int64_t)a.rowmap[pos] : pos;
     };
-    if (tid < NBM) {
-        const bool in_range = row0 + tid <= last_row;
-        const int64_t ri = corpus_row(row0 + tid);
-        s_aux[tid] = METRIC == METRIC_L2 ? a.norm2[ri] : (METRIC == METRIC_COS ? a.rnorm[ri] : 0.f);
-        s_vis[tid] = (in_range && (!a.mask || a.mask[ri])) ? (uint8_t)1 : (uint8_t)0;
-        s_rowid[tid] = (uint32_t)ri;
-    }
-    float tk[TN];
-    uint32_t tr[TN];
-#pragma unroll
-    for (int tn = 0; tn < TN; tn++) {
-        const int qj = q0 + tn * 32 + l31;
-        const uint64_t tau = (qj < a.nq && !a.boot) ? a.cs.tau[qj] : 0ull;
-        tk[tn] = tau_key_of(tau);
-        tr[tn] = entry_row(tau);
-    }
+    // (side inputs and thresholds are fetched behind the first stage's DMA, see below)
+    const int64_t side_ri = corpus_row(row0 + (tid & (NBM - 1)));
 
     // DMA sources: A instruction i of this wave fills rows WROWS*wave + 8i .. +7 (the rows the wave
     // consumes); its B instructions fill query rows 8*NB*wave + 8i .. +7.  Lane l lands at (row l/8,
@@ -137,6 +123,25 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
 
     const int nk = a.D / NBK; // D % 32 == 0 (launcher)
     stage_in(0, 0);
+    // one burst behind the DMA (not needed before the epilogue): the tile's side inputs and the thresholds
+    const float side_aux = METRIC == METRIC_L2 ? a.norm2[side_ri] : (METRIC == METRIC_COS ? a.rnorm[side_ri] : 0.f);
+    uint8_t side_vis = 1;
+    if (a.mask) side_vis = a.mask[side_ri];
+    float tk[TN];
+    uint32_t tr[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; tn++) {
+        const int qj = q0 + tn * 32 + l31;
+        uint64_t tau = a.boot ? 0ull : a.cs.tau[qj < a.nq ? qj : a.nq - 1];
+        if (qj >= a.nq) tau = 0ull;
+        tk[tn] = tau_key_of(tau);
+        tr[tn] = entry_row(tau);
+    }
+    if (tid < NBM) {
+        s_aux[tid] = side_aux;
+        s_vis[tid] = (row0 + tid <= last_row && side_vis) ? (uint8_t)1 : (uint8_t)0;
+        s_rowid[tid] = (uint32_t)side_ri;
+    }
     __syncthreads();
     for (int kt = 0; kt < nk; kt++) {
         const int cur = kt & 1;
