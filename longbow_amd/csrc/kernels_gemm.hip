@@ -536,7 +536,16 @@ void launch_gemm_filter(int metric, const float *X, const float *norm2, const fl
         case 2: hipLaunchKernelGGL((gemm_filter_kernel<METRIC_COS, 2, 2>), grid, dim3(GEMM_THREADS), 0, s, a); return;
         case 3: hipLaunchKernelGGL((gemm_filter_kernel<METRIC_COS, 2, 3>), grid, dim3(GEMM_THREADS), 0, s, a); return;
         case 4: hipLaunchKernelGGL((gemm_filter_kernel<METRIC_COS, 2, 4>), grid, dim3(GEMM_THREADS), 0, s, a); return;
-        case 5: hipLaunchKernelGGL((gemm_filter_kernel<METRIC_COS, 2, 5>), grid, dim3(GEMM_THREADS), 0, s, a); return;
+        case 5: {
+            // LB_GEMM_1WG=1: pad the LDS request so that only ONE workgroup fits a CU (diagnostic: main-loop
+            // cycles of a wave that has its SIMD to itself)
+            static const int one_wg = [] { const char *e = getenv("LB_GEMM_1WG"); return e ? atoi(e) : 0; }();
+            const size_t pad = one_wg ? 40 * 1024 : 0;
+            if (pad) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_filter_kernel<METRIC_COS, 2, 5>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+            hipLaunchKernelGGL((gemm_filter_kernel<METRIC_COS, 2, 5>), grid, dim3(GEMM_THREADS), pad, s, a);
+            return;
+        }
         case 6: hipLaunchKernelGGL((gemm_filter_kernel<METRIC_COS, 2, 6>), grid, dim3(GEMM_THREADS), 0, s, a); return;
         case 7: hipLaunchKernelGGL((gemm_filter_kernel<METRIC_COS, 2, 7>), grid, dim3(GEMM_THREADS), 0, s, a); return;
         default: break;

@@ -11,7 +11,7 @@ idx = gpu.NewIndexWithConfig(gpu.GPUConfig(0, D, 1)); idx.reserve(rows); idx.add
 od = torch.empty((B, K), device="cuda"); ol = torch.empty((B, K), dtype=torch.int64, device="cuda")
 raw = C.CDLL(_lib.SO_PATH); raw.lb_debug_set_gemm_ablation.argtypes = [C.c_int]; raw.lb_debug_set_gemm_glds.argtypes = [C.c_int]
 probe = (C.c_ulonglong * 8)()
-for phase, abl in (("warm (default kernel) x40", 0), ("clock-stamped kernel x40", 5)):
+for phase, abl in (("warm (default kernel) x40", 0), ("clock-stamped kernel (register-staged) x40", 5)):
     raw.lb_debug_set_gemm_glds(-1 if abl else 0); raw.lb_debug_set_gemm_ablation(abl)
     raw.lb_debug_read_clock_probe(probe, 1)
     t0 = time.perf_counter()
@@ -21,6 +21,7 @@ for phase, abl in (("warm (default kernel) x40", 0), ("clock-stamped kernel x40"
     raw.lb_debug_read_clock_probe(probe, 1)
     msg = f"{phase}: {dt*1e3:.3f} ms/batch"
     if probe[1]:
-        msg += f"; shader clock {probe[0] / probe[1] * 100:.0f} MHz over {probe[2]} workgroups"
+        msg += (f"; shader clock {probe[0] / probe[1] * 100:.0f} MHz over {probe[2]} workgroups; mean cycles per workgroup: "
+                f"prologue {probe[3] / probe[2]:.0f}, main loop {probe[0] / probe[2]:.0f}, epilogue {probe[4] / probe[2]:.0f}")
     print(msg, flush=True)
 raw.lb_debug_set_gemm_ablation(0); raw.lb_debug_set_gemm_glds(0)
