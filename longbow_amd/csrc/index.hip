@@ -1184,6 +1184,16 @@ int lb_gpu_index_last_timing(const lb_gpu_index *hc, float ms[5], int n_launch[5
 // profiling aid, not part of the public header: selects a timing-only ablation of the GEMM kernel
 void lb_debug_set_gemm_ablation(int v) { lb::g_gemm_ablation = v; }
 void lb_debug_set_sample_tau(int v) { g_sample_tau.store(v); } // 0: classic bootstrap schedule only
+// host-only: the sampled-threshold plan for a view of n rows (tests check its invariants without a GPU);
+// out = {on, span, count, m}
+void lb_debug_sample_plan(long long n, int keep, unsigned cap, unsigned count_max, long long *out)
+{
+    const SamplePlan p = sample_plan((int64_t)n, keep, cap, count_max ? count_max : 8192u);
+    out[0] = p.on ? 1 : 0;
+    out[1] = p.span;
+    out[2] = p.count;
+    out[3] = p.m;
+}
 void lb_debug_set_gemm_glds(int v) { lb::g_gemm_glds = v; }
 void lb_debug_set_adc_ablation(int v) { lb::g_adc_ablation = v; }
 int lb_debug_gemm_occupancy(void) { return lb::debug_gemm_occupancy(); }

@@ -52,3 +52,38 @@ def test_calculate_adaptive_limit_matches_oracle(oracle):
         for total in (0, 1, 50, 1000, 10**6):
             for matches in (0, 1, 2, total // 50 if total else 0, total // 10 if total else 0, total):
                 assert hybrid.calculate_adaptive_limit(k, matches, total) == oracle.adaptive_limit(k, matches, total)
+
+
+def test_sample_plan_invariants():
+    """the sampled-threshold plan (index.hip: sample_plan) over a grid of corpus sizes, k and list capacities:
+    the sample fits one list, m is in [8, 32], the too-tight tail is below 1e-6 and mean + 5 sigma admitted
+    rows fit the list -- checked on the host, no GPU needed"""
+    import ctypes as C
+    import math
+    from longbow_amd import _lib
+    lib = _lib.load()
+    lib.lb_debug_sample_plan.argtypes = [C.c_longlong, C.c_int, C.c_uint, C.c_uint, C.POINTER(C.c_longlong)]
+    lib.lb_debug_sample_plan.restype = None
+    out = (C.c_longlong * 4)()
+    seen_on = 0
+    for n in (1000, 65535, 65536, 10**5, 10**6, 2_500_000, 10**7, 10**8, 4 * 10**9):
+        for keep in (1, 10, 100, 256, 512, 1024, 4096):
+            for cap in (8192, 16384, 32768):
+                for count_max in (4096, 8192):
+                    if keep > cap:
+                        continue
+                    lib.lb_debug_sample_plan(n, keep, cap, count_max, out)
+                    on, span, count, m = out[0], out[1], out[2], out[3]
+                    if not on:
+                        continue
+                    seen_on += 1
+                    assert n >= 65536 and 0 < span <= n
+                    assert count <= min(cap, count_max) and span >= 8 * count
+                    assert 8 <= m <= 32
+                    lam = keep * count / span
+                    # P(Poisson(lam) >= m): the threshold admits fewer than `keep` rows
+                    tail = 1.0 - sum(math.exp(-lam) * lam ** i / math.factorial(i) for i in range(m))
+                    assert tail < 1e-6, (n, keep, cap, m, lam, tail)
+                    mean = m * span / count
+                    assert mean * (1 + 5 / math.sqrt(m)) <= (cap - keep) * 1.0001, (n, keep, cap, m, mean)
+    assert seen_on > 50
