@@ -65,7 +65,9 @@ const char *lb_gpu_status_string(int status);
  * Replaces faiss_gpu_resources_new + faiss_gpu_index_flat_l2_new
  * (internal/gpu/faiss_gpu.go:16-19,44-72; interface.go:3-19).  dim <= 0 or an
  * unknown metric -> NULL (gpu_test.go:49-55).  out_status (nullable) receives
- * the reason. */
+ * the reason.  dim > LB_MAX_DIM -> NULL / LB_ERR_UNSUPPORTED (the kernels stage one query row in LDS;
+ * the reference has no cap, embedding widths in practice are <= 4096). */
+#define LB_MAX_DIM 8192
 lb_gpu_index *lb_gpu_index_new(int device, int dim, int metric, int *out_status);
 
 /* Close (faiss_gpu.go:147-167): frees HBM; idempotent on NULL. */
@@ -136,6 +138,21 @@ int lb_gpu_index_filter_float32(lb_gpu_index *h, const float *column, int64_t n,
  * number of queries that needed the exact-scan fallback. */
 int64_t lb_gpu_index_last_fallbacks(const lb_gpu_index *h);
 
+/* Candidate re-rank: the distance step of processChunkInternal
+ * (internal/store/parallel_search.go:274-364).  The reference gathers the candidates' vectors into a
+ * flat buffer and calls simd.EuclideanDistanceBatchFlat (:347), then emits
+ * SearchResult{ID, Distance: d, Score: 1/(1+d)} (:355-362).  Here the candidate rows are gathered from the
+ * corpus already resident in HBM (no PCIe re-upload): rows[i] is a row POSITION (the label Search returns
+ * when Add got no ids, faiss_gpu.go:93-97); dist[i] is the index metric's distance in the requested
+ * accumulation order (LB_ORDER_UNROLL4 is what the reference runs here; -1 = the index's own order),
+ * score[i] = 1/(1+dist[i]) in f32 (nullable).  A row outside [0, ntotal) reports FLT_MAX / 0 -- the value
+ * EuclideanDistanceBatch gives a nil vector (internal/simd/batch_operations.go:39-42).  The caller sorts
+ * and truncates (parallel_search.go:123-130). */
+int lb_gpu_index_rerank(lb_gpu_index *h, const float *query, const int64_t *rows, int64_t n, int order,
+                        float *dist, float *score);
+int lb_gpu_index_rerank_device(lb_gpu_index *h, const float *d_query, const int64_t *d_rows, int64_t n, int order,
+                               float *d_dist, float *d_score, void *stream);
+
 /* ---- internal/simd batch interface on the GPU --------------------------------
  * simd.EuclideanDistanceBatchFlat / CosineDistanceBatch / DotProductBatch
  * (internal/simd/batch_operations.go:64-87,131-157): one query x n rows of
@@ -167,6 +184,27 @@ int64_t lb_gpu_pq_ntotal(const lb_gpu_pq *p);
 /* Append n codes u8[n*M] (row-major, as pq.Encode emits them). */
 int lb_gpu_pq_add_codes(lb_gpu_pq *p, int64_t n, const uint8_t *codes);
 int lb_gpu_pq_add_codes_device(lb_gpu_pq *p, int64_t n, const uint8_t *d_codes);
+int lb_gpu_pq_reserve(lb_gpu_pq *p, int64_t n_total);
+/* Read back stored codes rows [row0, row0+n) as u8[n*M] (e.g. to persist what add_vectors_device encoded). */
+int lb_gpu_pq_get_codes(lb_gpu_pq *p, int64_t row0, int64_t n, uint8_t *codes);
+/* pq.(*PQEncoder).Encode (internal/pq/encoder.go:76-136) for n vectors of f32[dims] -> codes u8[n*M]:
+ * per subspace the FIRST centroid with the strictly smallest float32(sqrt(float64(L2^2))) in the
+ * 4-accumulator order, as simd.FindNearestCentroid's K > 8 branch computes it
+ * (internal/simd/simd.go:305-326, 365-396).  (K <= 16 codebooks -- the encodeSequential branch -- are
+ * rejected at lb_gpu_pq_new with LB_ERR_UNSUPPORTED: K must be 256.) */
+int lb_gpu_pq_encode(lb_gpu_pq *p, int64_t n, const float *vectors, uint8_t *codes);
+int lb_gpu_pq_encode_device(lb_gpu_pq *p, int64_t n, const float *d_vectors, uint8_t *d_codes, void *stream);
+/* Encode n device-resident vectors and append their codes (the ingest step that produces config 4's codes). */
+int lb_gpu_pq_add_vectors_device(lb_gpu_pq *p, int64_t n, const float *d_vectors);
+/* pq.(*PQEncoder).Decode (encoder.go:139-158): codes u8[n*M] -> vectors f32[n*dims]. */
+int lb_gpu_pq_decode(lb_gpu_pq *p, int64_t n, const uint8_t *codes, float *vectors);
+int lb_gpu_pq_decode_device(lb_gpu_pq *p, int64_t n, const uint8_t *d_codes, float *d_vectors, void *stream);
+/* processChunkInternal's PQ branch (internal/store/parallel_search.go:292-345): ADC distance of the stored
+ * code rows rows[0..n) to `query` (table built per call) + score = 1/(1+d) (nullable); rows outside
+ * [0, ntotal) report FLT_MAX / 0. */
+int lb_gpu_pq_rerank(lb_gpu_pq *p, const float *query, const int64_t *rows, int64_t n, float *dist, float *score);
+int lb_gpu_pq_rerank_device(lb_gpu_pq *p, const float *d_query, const int64_t *d_rows, int64_t n, float *d_dist,
+                            float *d_score, void *stream);
 /* pq.BuildADCTable (internal/pq/adc_table.go:15-51): table f32[M*K] for one query. */
 int lb_gpu_pq_build_adc_table(lb_gpu_pq *p, const float *query, float *table);
 /* simd.ADCDistanceBatch (internal/simd/batch_operations.go:119-127, simd.go:345-355):
@@ -184,7 +222,8 @@ int lb_gpu_pq_search_device(lb_gpu_pq *p, int64_t nq, const float *d_queries, in
 /* ---- cross-shard merge ---------------------------------------------------------
  * store.MergeSortedStreams (internal/store/result_merger.go:34-101) for S shards:
  * inputs [S][nq][k] ascending per (shard, query) (padding label -1 / FLT_MAX allowed),
- * output [nq][k] ascending by (distance, label).  Device pointers. */
+ * output [nq][k] ascending by (distance, label); padding sorts last, every NaN after +inf.
+ * nshards * k <= 16384 (k = 2048 on 8 GPUs).  Device pointers. */
 int lb_gpu_merge_topk_device(int device, int nshards, int64_t nq, int k, const float *d_dist_in,
                              const int64_t *d_labels_in, float *d_dist_out, int64_t *d_labels_out,
                              void *stream);

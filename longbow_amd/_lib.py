@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "liblongbow_gpu.so")
+# LB_GPU_SO selects another build of the library (tools/ use the -DLB_DIAG build, liblongbow_gpu_diag.so)
+SO_PATH = os.environ.get("LB_GPU_SO") or os.path.join(_HERE, "liblongbow_gpu.so")
 
 LB_OK = 0
 STATUS = {0: "ok", 1: "invalid argument", 2: "index is closed", 3: "GPU not available",
@@ -51,6 +52,8 @@ SIGNATURES = [
     ("lb_gpu_index_filter_int64", _i, [_vp, _vp, _i64, _i64, _i, _vp, _i64, _i]),
     ("lb_gpu_index_filter_float32", _i, [_vp, _vp, _i64, C.c_float, _i, _vp, _i64, _i]),
     ("lb_gpu_index_last_fallbacks", _i64, [_vp]),
+    ("lb_gpu_index_rerank", _i, [_vp, _vp, _vp, _i64, _i, _vp, _vp]),
+    ("lb_gpu_index_rerank_device", _i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _vp]),
     ("lb_simd_match_int64", _i, [_i, _vp, _i64, _i64, _i, _vp]),
     ("lb_simd_match_float32", _i, [_i, _vp, _i64, C.c_float, _i, _vp]),
     ("lb_simd_and_bytes", _i, [_i, _vp, _vp, _i64]),
@@ -64,6 +67,15 @@ SIGNATURES = [
     ("lb_gpu_pq_ntotal", _i64, [_vp]),
     ("lb_gpu_pq_add_codes", _i, [_vp, _i64, _vp]),
     ("lb_gpu_pq_add_codes_device", _i, [_vp, _i64, _vp]),
+    ("lb_gpu_pq_reserve", _i, [_vp, _i64]),
+    ("lb_gpu_pq_get_codes", _i, [_vp, _i64, _i64, _vp]),
+    ("lb_gpu_pq_encode", _i, [_vp, _i64, _vp, _vp]),
+    ("lb_gpu_pq_encode_device", _i, [_vp, _i64, _vp, _vp, _vp]),
+    ("lb_gpu_pq_add_vectors_device", _i, [_vp, _i64, _vp]),
+    ("lb_gpu_pq_decode", _i, [_vp, _i64, _vp, _vp]),
+    ("lb_gpu_pq_decode_device", _i, [_vp, _i64, _vp, _vp, _vp]),
+    ("lb_gpu_pq_rerank", _i, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    ("lb_gpu_pq_rerank_device", _i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     ("lb_gpu_pq_build_adc_table", _i, [_vp, _vp, _vp]),
     ("lb_gpu_pq_adc_distance_batch", _i, [_vp, _vp, _i64, _i64, _vp]),
     ("lb_gpu_pq_search", _i, [_vp, _i64, _vp, _i, _vp, _vp]),

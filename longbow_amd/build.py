@@ -13,8 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "liblongbow_gpu.so")
 SOURCES = ["index.hip", "pq.hip", "kernels_gemm.hip", "kernels_gemm_narrow.hip", "kernels_scan.hip", "kernels_select.hip",
-           "kernels_pq.hip", "kernels_filter.hip"]
-HEADERS = ["lb_device.h", os.path.join("..", "..", "include", "longbow_gpu.h")]
+           "kernels_pq.hip", "kernels_pq2.hip", "kernels_filter.hip"]
+HEADERS = ["lb_device.h", "lb_host.h", os.path.join("..", "..", "include", "longbow_gpu.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

@@ -9,6 +9,7 @@
 // returns LB_ERR_NO_DEVICE / NULL.
 #include "../../include/longbow_gpu.h"
 #include "lb_device.h"
+#include "lb_host.h"
 
 #include <algorithm>
 #include <atomic>
@@ -34,17 +35,6 @@ constexpr int kScanMaxQ = 8;          // queries per scan launch (register accum
 constexpr int kGemmMinQ = 17;         // below this the exact scan path is used for everything
 constexpr int kMaxBatch = 4096;       // queries per internal batch (workspace sizing)
 constexpr size_t kStageBytes = 32u << 20; // pinned staging slab (x2)
-
-struct HipErr {
-    hipError_t e;
-    const char *what;
-};
-
-#define LB_HIP(call)                                          \
-    do {                                                      \
-        hipError_t _e = (call);                               \
-        if (_e != hipSuccess) throw HipErr{_e, #call};        \
-    } while (0)
 
 struct Event {
     hipEvent_t a = nullptr, b = nullptr;
@@ -118,6 +108,93 @@ struct HostStage {
 
 } // namespace
 
+// The corpus buffer grows IN PLACE: one virtual range the size of the device's HBM is reserved per index
+// and physical chunks are mapped behind it as rows arrive (hipMemAddressReserve / hipMemCreate /
+// hipMemMap).  Appending never copies the rows already resident and never needs old + new at once, so an
+// index can grow to fill the 288 GB.  If the driver refuses any of the calls the index falls back to
+// geometric hipMalloc + copy (vmm.ok == false).
+struct VmmBuf {
+    bool ok = false;
+    int device = 0;
+    char *base = nullptr;
+    size_t reserved = 0, mapped = 0, gran = 0;
+    struct Chunk { hipMemGenericAllocationHandle_t h; size_t off, bytes; };
+    std::vector<Chunk> chunks;
+
+    bool init(int dev)
+    {
+        device = dev;
+        hipMemAllocationProp prop{};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = dev;
+        size_t g = 0;
+        if (hipMemGetAllocationGranularity(&g, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || g == 0) return false;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) return false;
+        // the driver reports 4 KiB, but maps whose offsets are not 64 KiB-aligned are refused by
+        // hipMemSetAccess (measured, tools/probe/vmm_probe.cpp): keep every chunk a multiple of 2 MiB
+        gran = g < ((size_t)2 << 20) ? ((size_t)2 << 20) : g;
+        reserved = ((total_b + gran - 1) / gran) * gran;
+        void *ptr = nullptr;
+        if (hipMemAddressReserve(&ptr, reserved, gran, nullptr, 0) != hipSuccess || !ptr) { (void)hipGetLastError(); return false; }
+        base = static_cast<char *>(ptr);
+        ok = true;
+        return true;
+    }
+    // make [0, need) backed by memory; throws HipErr (OOM) when the device has no more to give
+    void ensure(size_t need)
+    {
+        if (need <= mapped) return;
+        if (need > reserved) throw lb::HipErr{hipErrorOutOfMemory, "corpus larger than the device"};
+        // geometric steps (at least the request, at least what is mapped already, at most 1 GiB beyond the
+        // request): small indexes stay small, 288 GB take ~300 handles
+        size_t want = need - mapped;
+        size_t step = mapped < ((size_t)1 << 30) ? mapped : ((size_t)1 << 30);
+        if (want < step) want = step;
+        want = ((want + gran - 1) / gran) * gran;
+        if (mapped + want > reserved) want = reserved - mapped;
+        hipMemAllocationProp prop{};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = device;
+        hipMemGenericAllocationHandle_t hnd;
+        hipError_t e = hipMemCreate(&hnd, want, &prop, 0);
+        if (e != hipSuccess && want > ((need - mapped + gran - 1) / gran) * gran) { // retry with the exact need
+            (void)hipGetLastError();
+            want = ((need - mapped + gran - 1) / gran) * gran;
+            e = hipMemCreate(&hnd, want, &prop, 0);
+        }
+        if (e != hipSuccess) throw lb::HipErr{hipErrorOutOfMemory, "hipMemCreate (corpus chunk)"};
+        e = hipMemMap(base + mapped, want, 0, hnd, 0);
+        if (e != hipSuccess) { (void)hipMemRelease(hnd); throw lb::HipErr{e, "hipMemMap"}; }
+        hipMemAccessDesc acc{};
+        acc.location.type = hipMemLocationTypeDevice;
+        acc.location.id = device;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        e = hipMemSetAccess(base + mapped, want, &acc, 1);
+        if (e != hipSuccess) {
+            (void)hipMemUnmap(base + mapped, want);
+            (void)hipMemRelease(hnd);
+            throw lb::HipErr{e, "hipMemSetAccess"};
+        }
+        chunks.push_back({hnd, mapped, want});
+        mapped += want;
+    }
+    void destroy()
+    {
+        for (auto &c : chunks) {
+            (void)hipMemUnmap(base + c.off, c.bytes);
+            (void)hipMemRelease(c.h);
+        }
+        chunks.clear();
+        if (base) (void)hipMemAddressFree(base, reserved);
+        base = nullptr;
+        mapped = reserved = 0;
+        ok = false;
+    }
+};
+
 struct lb_gpu_index {
     int device = 0, dim = 0, metric = 0;
     std::atomic<int> order{LB_ORDER_SEQ};
@@ -125,6 +202,8 @@ struct lb_gpu_index {
     bool closed = false;
 
     float *d_X = nullptr;
+    VmmBuf vmm;             // backs d_X when vmm.ok (d_X == vmm.base): rows are appended in place
+    int64_t x_rows_cap = 0; // rows d_X can hold (>= capacity of the side arrays when vmm.ok)
     int64_t n = 0, capacity = 0;
     float *d_norm2 = nullptr, *d_rnorm = nullptr;
     uint32_t *d_maxnorm2 = nullptr;
@@ -184,6 +263,7 @@ namespace {
 
 int fail_hip(lb_gpu_index *h, const HipErr &e)
 {
+    (void)hipGetLastError(); // the failure is reported through the return code; leave no sticky error behind
     h->set_error("HIP error %d (%s) in %s", (int)e.e, hipGetErrorString(e.e), e.what);
     return (e.e == hipErrorOutOfMemory) ? LB_ERR_OOM : LB_ERR_HIP;
 }
@@ -286,7 +366,7 @@ static RowView row_view(const lb_gpu_index *h)
 // so a list that ends with >= keep entries holds exactly the span's best `keep`.
 //   too tight:  fewer than `keep` rows pass iff >= m sampled rows are among the span's best keep-1;
 //               that count is ~Poisson(lambda = keep*count/span), and m = lambda + 5 sqrt(lambda) + 4
-//               puts the tail below 1e-7 (m = 10 for k = 100, 14 for the 256 MFMA candidates at 1M rows);
+//               puts the tail below 1e-6 (m = 10 for k = 100, 14 for the 256 MFMA candidates at 1M rows);
 //   too loose:  about m*span/count rows pass (1.2k-1.8k at 1M rows), relative spread 1/sqrt(m); the span
 //               is capped so that mean + 5 sigma stays below the list capacity.
 // Either miss is detected (flag bit 2 / bit 0) and the query is redone by the classic bootstrap
@@ -299,7 +379,9 @@ struct SamplePlan {
     uint32_t count = 0; // sampled rows
     int m = 0;
 };
-std::atomic<int> g_sample_tau{[] { const char *e = getenv("LB_SAMPLE_TAU"); return e ? atoi(e) : 1; }()};
+std::atomic<int> g_sample_tau{lb_tunable("LB_SAMPLE_TAU", 1)};
+// Add batches of at least this many bytes pin the caller's buffer instead of staging it (0 = never)
+std::atomic<long long> g_add_register_min{(long long)lb_tunable("LB_ADD_REGISTER_MIN_MB", 64) << 20};
 static SamplePlan sample_plan(int64_t n, int keep, uint32_t cap, uint32_t count_max = 8192u)
 {
     SamplePlan p;
@@ -338,7 +420,7 @@ bool run_scan_path(lb_gpu_index *h, Workspace *w, hipStream_t s, const float *d_
     const bool safe = mode == 2;
     // (the latency path samples half as many rows: the sample launches are on its critical path, and the
     // extra admissions -- ~2k instead of ~1.2k at 1M rows -- are spread over the striped counters)
-    static const uint32_t scan_count = [] { const char *e = getenv("LB_SCAN_SAMPLE"); return e ? (uint32_t)atoi(e) : 4096u; }();
+    static const uint32_t scan_count = (uint32_t)lb_tunable("LB_SCAN_SAMPLE", 4096);
     const SamplePlan sp = mode == 0 ? sample_plan(n, kkeep, w->cap, scan_count) : SamplePlan{};
     if (!sp.on) launch_init_cand(w->cs, d_sel, nsel, s);
     for (int g0 = 0; g0 < nsel; g0 += kScanMaxQ) {
@@ -458,8 +540,8 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     // (0.65-0.77 ms); 5..384 queries narrow MFMA tile (0.78 ms at 5-8, 0.87 ms at 32, 3.7 ms at 256);
     // beyond that the 128-query tile.
     const bool narrow_ok = h->dim % 32 == 0 && ((reinterpret_cast<uintptr_t>(d_q) & 15) == 0);
-    static const int narrow_min = [] { const char *e = getenv("LB_NARROW_MINQ"); return e ? atoi(e) : 5; }();
-    static const int narrow_max = [] { const char *e = getenv("LB_NARROW_MAXQ"); return e ? atoi(e) : 384; }();
+    static const int narrow_min = lb_tunable("LB_NARROW_MINQ", 5);
+    static const int narrow_max = lb_tunable("LB_NARROW_MAXQ", 384);
     // rows with inf / NaN components: the MFMA pipeline's keys and error bounds assume finite data;
     // the scan path orders non-finite distances canonically (NaN last)
     if (h->nonfinite || nq < (narrow_ok ? narrow_min : kGemmMinQ)) {
@@ -503,7 +585,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     // wide tile, 160-192 and 320 the narrow one.
     // Costs per corpus pass in ms at 1M x 768 (only their ratios matter): 32-query tile 0.43, 64-query tile
     // 0.80 (MFMA-bound: 0.63 ms of f32 MFMA per pass), 128-query tile 1.49.
-    static const int force64 = [] { const char *e = getenv("LB_NARROW_TILE64"); return e ? atoi(e) : -1; }();
+    static const int force64 = lb_tunable("LB_NARROW_TILE64", -1);
     const double kCost64 = 0.80; // measured: 64 queries 0.97 ms, 192 queries 2.48 ms per search
     const int tiles_n = (nq + 31) / 32, tiles_64 = (nq + 63) / 64, tiles_w = (nq + 127) / 128;
     const double c32 = (nq <= 32 || tiles_n <= 10) ? 0.43 * tiles_n : 1e9, c64 = kCost64 * tiles_64, cw = 1.49 * tiles_w;
@@ -597,6 +679,29 @@ __global__ void fill_empty_kernel(float *dist, int64_t *lab, int64_t n)
     }
 }
 
+// candidate rows (int64 positions) -> u32 row map for the mapped scan; rows outside the corpus read row 0
+// and are overwritten afterwards
+__global__ void rerank_map_kernel(const int64_t *rows, int64_t n, int64_t ntotal, uint32_t *map)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const int64_t r = rows[i];
+        map[i] = (r >= 0 && r < ntotal) ? (uint32_t)r : 0u;
+    }
+}
+// Score = 1/(1+d) (parallel_search.go:360); invalid rows: MaxFloat32 / 0
+__global__ void rerank_score_kernel(const int64_t *rows, int64_t n, int64_t ntotal, float *dist, float *score)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const int64_t r = rows[i];
+        const bool ok = r >= 0 && r < ntotal;
+        const float d = ok ? dist[i] : FLT_MAX;
+        dist[i] = d;
+        if (score) score[i] = ok ? __fdiv_rn(1.0f, 1.0f + d) : 0.f;
+    }
+}
+
 void finish_profile(lb_gpu_index *h, Workspace *w)
 {
     float ms[5] = {0, 0, 0, 0, 0};
@@ -616,35 +721,87 @@ void finish_profile(lb_gpu_index *h, Workspace *w)
     }
 }
 
+// Make room for `need` rows.  The corpus itself grows in place (VmmBuf); only the small per-row side
+// arrays (norms, ids, mask: 17 B per row) are reallocated geometrically and copied.  Without VMM the
+// corpus follows the same malloc + copy scheme (needs old + new resident at once).
 int grow(lb_gpu_index *h, int64_t need)
 {
-    if (need <= h->capacity) return LB_OK;
+    const size_t row_bytes = (size_t)h->dim * sizeof(float);
     int64_t cap = std::max<int64_t>(need, h->capacity * 2);
     cap = std::max<int64_t>(cap, 1024);
-    float *nx = nullptr, *n2 = nullptr, *rn = nullptr;
-    int64_t *ni = nullptr;
-    uint8_t *nm = nullptr;
-    const size_t row_bytes = (size_t)h->dim * sizeof(float);
-    LB_HIP(hipMalloc(&nx, (size_t)cap * row_bytes));
-    LB_HIP(hipMalloc(&n2, (size_t)cap * sizeof(float)));
-    LB_HIP(hipMalloc(&rn, (size_t)cap * sizeof(float)));
-    LB_HIP(hipMalloc(&ni, (size_t)cap * sizeof(int64_t)));
-    LB_HIP(hipMalloc(&nm, (size_t)cap));
+    if (h->vmm.ok) {
+        try {
+            h->vmm.ensure((size_t)need * row_bytes);
+            h->d_X = reinterpret_cast<float *>(h->vmm.base);
+            h->x_rows_cap = (int64_t)(h->vmm.mapped / row_bytes);
+        } catch (const HipErr &e) {
+            (void)hipGetLastError(); // do not leave a sticky error behind for the caller's next HIP call
+            if (e.e == hipErrorOutOfMemory) throw;
+            // The driver refused to extend the mapping (hipMemSetAccess reports "invalid argument" for some
+            // chunk sequences on this stack, tools/probe/): move the rows into one hipMalloc'd buffer and
+            // grow geometrically from here on.
+            float *nx = nullptr;
+            LB_HIP(hipMalloc(&nx, (size_t)cap * row_bytes));
+            if (h->n > 0) {
+                hipError_t ce = hipMemcpyAsync(nx, h->d_X, (size_t)h->n * row_bytes, hipMemcpyDeviceToDevice, h->add_stream);
+                if (ce == hipSuccess) ce = hipStreamSynchronize(h->add_stream);
+                if (ce != hipSuccess) { (void)hipFree(nx); throw HipErr{ce, "hipMemcpyAsync (leaving the mapped corpus)"}; }
+            }
+            h->vmm.destroy();
+            h->d_X = nx;
+            h->x_rows_cap = cap;
+        }
+    }
+    if (need <= h->capacity && (h->vmm.ok || need <= h->x_rows_cap)) return LB_OK;
+    if (need <= h->capacity) cap = h->capacity; // only the corpus buffer (malloc mode) is short
+    struct Guard { // frees whatever was allocated when a later allocation throws
+        float *nx = nullptr, *n2 = nullptr, *rn = nullptr;
+        int64_t *ni = nullptr;
+        uint8_t *nm = nullptr;
+        bool keep = false;
+        ~Guard()
+        {
+            if (keep) return;
+            if (nx) (void)hipFree(nx);
+            if (n2) (void)hipFree(n2);
+            if (rn) (void)hipFree(rn);
+            if (ni) (void)hipFree(ni);
+            if (nm) (void)hipFree(nm);
+        }
+    } g;
+    const bool grow_x = !h->vmm.ok && cap > h->x_rows_cap;
+    const bool grow_side = cap > h->capacity;
+    if (grow_x) LB_HIP(hipMalloc(&g.nx, (size_t)cap * row_bytes));
+    if (grow_side) {
+        LB_HIP(hipMalloc(&g.n2, (size_t)cap * sizeof(float)));
+        LB_HIP(hipMalloc(&g.rn, (size_t)cap * sizeof(float)));
+        LB_HIP(hipMalloc(&g.ni, (size_t)cap * sizeof(int64_t)));
+        LB_HIP(hipMalloc(&g.nm, (size_t)cap));
+    }
     if (h->n > 0) {
-        LB_HIP(hipMemcpyAsync(nx, h->d_X, (size_t)h->n * row_bytes, hipMemcpyDeviceToDevice, h->add_stream));
-        LB_HIP(hipMemcpyAsync(n2, h->d_norm2, (size_t)h->n * sizeof(float), hipMemcpyDeviceToDevice, h->add_stream));
-        LB_HIP(hipMemcpyAsync(rn, h->d_rnorm, (size_t)h->n * sizeof(float), hipMemcpyDeviceToDevice, h->add_stream));
-        LB_HIP(hipMemcpyAsync(ni, h->d_ids, (size_t)h->n * sizeof(int64_t), hipMemcpyDeviceToDevice, h->add_stream));
-        LB_HIP(hipMemcpyAsync(nm, h->d_mask, (size_t)h->n, hipMemcpyDeviceToDevice, h->add_stream));
+        if (g.nx) LB_HIP(hipMemcpyAsync(g.nx, h->d_X, (size_t)h->n * row_bytes, hipMemcpyDeviceToDevice, h->add_stream));
+        if (grow_side) {
+            LB_HIP(hipMemcpyAsync(g.n2, h->d_norm2, (size_t)h->n * sizeof(float), hipMemcpyDeviceToDevice, h->add_stream));
+            LB_HIP(hipMemcpyAsync(g.rn, h->d_rnorm, (size_t)h->n * sizeof(float), hipMemcpyDeviceToDevice, h->add_stream));
+            LB_HIP(hipMemcpyAsync(g.ni, h->d_ids, (size_t)h->n * sizeof(int64_t), hipMemcpyDeviceToDevice, h->add_stream));
+            LB_HIP(hipMemcpyAsync(g.nm, h->d_mask, (size_t)h->n, hipMemcpyDeviceToDevice, h->add_stream));
+        }
         LB_HIP(hipStreamSynchronize(h->add_stream));
     }
-    if (h->d_X) (void)hipFree(h->d_X);
-    if (h->d_norm2) (void)hipFree(h->d_norm2);
-    if (h->d_rnorm) (void)hipFree(h->d_rnorm);
-    if (h->d_ids) (void)hipFree(h->d_ids);
-    if (h->d_mask) (void)hipFree(h->d_mask);
-    h->d_X = nx; h->d_norm2 = n2; h->d_rnorm = rn; h->d_ids = ni; h->d_mask = nm;
-    h->capacity = cap;
+    g.keep = true;
+    if (g.nx) {
+        if (h->d_X) (void)hipFree(h->d_X);
+        h->d_X = g.nx;
+        h->x_rows_cap = cap;
+    }
+    if (grow_side) {
+        if (h->d_norm2) (void)hipFree(h->d_norm2);
+        if (h->d_rnorm) (void)hipFree(h->d_rnorm);
+        if (h->d_ids) (void)hipFree(h->d_ids);
+        if (h->d_mask) (void)hipFree(h->d_mask);
+        h->d_norm2 = g.n2; h->d_rnorm = g.rn; h->d_ids = g.ni; h->d_mask = g.nm;
+        h->capacity = cap;
+    }
     if (h->d_Xs) { // the mirror is rebuilt at the new capacity by the next sync_split_image
         (void)hipFree(h->d_Xs);
         h->d_Xs = nullptr;
@@ -665,7 +822,7 @@ void rebuild_rowmap(lb_gpu_index *h)
     h->rowmap_on = false;
     h->n_visible = h->n;
     if (!h->has_mask || h->n == 0) return;
-    static const int max_pct = [] { const char *e = getenv("LB_ROWMAP_MAX_PCT"); return e ? atoi(e) : 95; }();
+    static const int max_pct = lb_tunable("LB_ROWMAP_MAX_PCT", 95);
     if (max_pct <= 0) return;
     hipStream_t s = h->add_stream;
     if (h->rowmap_cap < h->n) {
@@ -719,10 +876,23 @@ void finish_add(lb_gpu_index *h, int64_t n, const int64_t *ids_src, bool ids_on_
     uint32_t maxbits = 0; // max ||x||^2 so far, as float bits: >= +inf <=> a row with an inf or NaN component
     LB_HIP(hipMemcpyAsync(&maxbits, h->d_maxnorm2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     LB_HIP(hipStreamSynchronize(s));
+    LB_LAUNCH_CHECK();
     h->nonfinite = maxbits >= 0x7f800000u;
-    h->n += n;
-    sync_split_image(h);
-    rebuild_rowmap(h); // appended rows are visible; keep the list in step with the corpus
+    h->n += n; // the rows are committed from here on: nothing below may fail the call (a retry would duplicate them)
+    try {
+        sync_split_image(h);
+    } catch (const HipErr &) { // no room for the bf16 mirror: searches use the f32 contraction
+        (void)hipGetLastError();
+        h->cand_mode.store(0);
+        if (h->d_Xs) { (void)hipFree(h->d_Xs); h->d_Xs = nullptr; h->xs_rows = 0; }
+    }
+    try {
+        rebuild_rowmap(h); // appended rows are visible; keep the list in step with the corpus
+    } catch (const HipErr &) { // searches fall back to the per-row mask test
+        (void)hipGetLastError();
+        h->rowmap_on = false;
+        h->n_visible = h->n;
+    }
 }
 
 // bring the split-bf16 mirror up to date with d_X (no-op unless the mode is enabled)
@@ -743,14 +913,15 @@ void sync_split_image(lb_gpu_index *h)
     }
 }
 
-bool device_ok(int device)
-{
-    int cnt = 0;
-    if (hipGetDeviceCount(&cnt) != hipSuccess) return false;
-    return device >= 0 && device < cnt;
-}
-
 } // namespace
+
+namespace lb {
+BufPool &buf_pool()
+{
+    static BufPool *pool = new BufPool(); // leaked on purpose: must outlive every handle at process exit
+    return *pool;
+}
+} // namespace lb
 
 template <typename T>
 static int filter_column(lb_gpu_index *h, const T *column, int64_t n, T value, int op, const uint8_t *validity,
@@ -764,31 +935,32 @@ static int filter_column(lb_gpu_index *h, const T *column, int64_t n, T value, i
         return LB_ERR_INVALID_ARG;
     }
     if (n == 0) { h->has_mask = true; h->rowmap_on = false; return LB_OK; }
-    T *d_col = nullptr;
-    uint8_t *d_val = nullptr;
     int rc = LB_OK;
     try {
         LB_HIP(hipSetDevice(h->device));
-        LB_HIP(hipMalloc(&d_col, (size_t)n * sizeof(T)));
-        LB_HIP(hipMemcpy(d_col, column, (size_t)n * sizeof(T), hipMemcpyHostToDevice));
+        // column (and validity bitmap) go up through pooled buffers on the index's own stream
+        Lease dcol(h->device, (size_t)n * sizeof(T)), dval;
+        T *d_col = dcol.as<T>();
+        uint8_t *d_val = nullptr;
+        LB_HIP(hipMemcpyAsync(d_col, column, (size_t)n * sizeof(T), hipMemcpyHostToDevice, h->add_stream));
         if (validity) {
             const size_t vb = (size_t)((voff + n + 7) / 8);
-            LB_HIP(hipMalloc(&d_val, vb));
-            LB_HIP(hipMemcpy(d_val, validity, vb, hipMemcpyHostToDevice));
+            dval.reset(h->device, vb);
+            d_val = dval.as<uint8_t>();
+            LB_HIP(hipMemcpyAsync(d_val, validity, vb, hipMemcpyHostToDevice, h->add_stream));
         }
         const int comb = (combine && h->has_mask) ? 1 : 0; // AND into "no filter" == replace
         if constexpr (sizeof(T) == 8)
             launch_match_int64(reinterpret_cast<const int64_t *>(d_col), n, (int64_t)value, op, d_val, voff, h->d_mask, comb, h->add_stream);
         else
             launch_match_float32(reinterpret_cast<const float *>(d_col), n, (float)value, op, d_val, voff, h->d_mask, comb, h->add_stream);
+        LB_LAUNCH_CHECK();
         LB_HIP(hipStreamSynchronize(h->add_stream));
         h->has_mask = true;
         rebuild_rowmap(h);
     } catch (const HipErr &e) {
         rc = fail_hip(h, e);
     }
-    if (d_col) (void)hipFree(d_col);
-    if (d_val) (void)hipFree(d_val);
     return rc;
 }
 
@@ -800,20 +972,18 @@ static int match_host(int device, const T *src, int64_t n, T value, int op, uint
     if (n == 0) return LB_OK;
     if (!src || !dst) return LB_ERR_INVALID_ARG;
     if (!device_ok(device)) return LB_ERR_NO_DEVICE;
-    if (hipSetDevice(device) != hipSuccess) return LB_ERR_HIP;
-    T *d_s = nullptr;
-    uint8_t *d_d = nullptr;
-    int rc = LB_OK;
-    if (hipMalloc(&d_s, (size_t)n * sizeof(T)) != hipSuccess || hipMalloc(&d_d, (size_t)n) != hipSuccess) rc = LB_ERR_OOM;
-    else if (hipMemcpy(d_s, src, (size_t)n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) rc = LB_ERR_HIP;
-    else {
-        if constexpr (sizeof(T) == 8) launch_match_int64(reinterpret_cast<const int64_t *>(d_s), n, (int64_t)value, op, nullptr, 0, d_d, 0, nullptr);
-        else launch_match_float32(reinterpret_cast<const float *>(d_s), n, (float)value, op, nullptr, 0, d_d, 0, nullptr);
-        if (hipMemcpy(dst, d_d, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) rc = LB_ERR_HIP;
+    try {
+        LB_HIP(hipSetDevice(device));
+        Lease ds(device, (size_t)n * sizeof(T)), dd(device, (size_t)n);
+        LB_HIP(hipMemcpy(ds.p, src, (size_t)n * sizeof(T), hipMemcpyHostToDevice));
+        if constexpr (sizeof(T) == 8) launch_match_int64(ds.as<int64_t>(), n, (int64_t)value, op, nullptr, 0, dd.as<uint8_t>(), 0, nullptr);
+        else launch_match_float32(ds.as<float>(), n, (float)value, op, nullptr, 0, dd.as<uint8_t>(), 0, nullptr);
+        LB_LAUNCH_CHECK();
+        LB_HIP(hipMemcpy(dst, dd.p, (size_t)n, hipMemcpyDeviceToHost));
+    } catch (const HipErr &e) {
+        return e.e == hipErrorOutOfMemory ? LB_ERR_OOM : LB_ERR_HIP;
     }
-    if (d_s) (void)hipFree(d_s);
-    if (d_d) (void)hipFree(d_d);
-    return rc;
+    return LB_OK;
 }
 
 
@@ -849,6 +1019,9 @@ lb_gpu_index *lb_gpu_index_new(int device, int dim, int metric, int *out_status)
 {
     auto st = [&](int v) { if (out_status) *out_status = v; };
     if (dim <= 0 || metric < 0 || metric > 2) { st(LB_ERR_INVALID_ARG); return nullptr; }
+    // the kernels stage one query row (and the re-rank a 256 x 64-float tile plus up to 4096 keys) in LDS:
+    // LB_MAX_DIM keeps every launch inside the 160 KB a workgroup may declare
+    if (dim > LB_MAX_DIM) { st(LB_ERR_UNSUPPORTED); return nullptr; }
     if (!device_ok(device)) { st(LB_ERR_NO_DEVICE); return nullptr; }
     auto *h = new (std::nothrow) lb_gpu_index();
     if (!h) { st(LB_ERR_OOM); return nullptr; }
@@ -858,6 +1031,8 @@ lb_gpu_index *lb_gpu_index_new(int device, int dim, int metric, int *out_status)
         LB_HIP(hipStreamCreateWithFlags(&h->add_stream, hipStreamNonBlocking));
         LB_HIP(hipMalloc(&h->d_maxnorm2, sizeof(uint32_t)));
         LB_HIP(hipMemset(h->d_maxnorm2, 0, sizeof(uint32_t)));
+        static const int use_vmm = lb_tunable("LB_VMM", 1);
+        if (use_vmm) (void)h->vmm.init(device); // on failure: geometric hipMalloc + copy
     } catch (const HipErr &e) {
         st(e.e == hipErrorOutOfMemory ? LB_ERR_OOM : LB_ERR_HIP);
         lb_gpu_index_free(h);
@@ -880,7 +1055,9 @@ void lb_gpu_index_free(lb_gpu_index *h)
             h->ws_free.clear();
             h->hs_free.clear();
         }
-        if (h->d_X) (void)hipFree(h->d_X);
+        if (h->vmm.ok) h->vmm.destroy();
+        else if (h->d_X) (void)hipFree(h->d_X);
+        h->d_X = nullptr;
         if (h->d_norm2) (void)hipFree(h->d_norm2);
         if (h->d_rnorm) (void)hipFree(h->d_rnorm);
         if (h->d_ids) (void)hipFree(h->d_ids);
@@ -964,11 +1141,30 @@ int lb_gpu_index_add(lb_gpu_index *h, int64_t n, const float *vectors, const int
             if (!h->h_stage[i]) LB_HIP(hipHostMalloc(&h->h_stage[i], kStageBytes, hipHostMallocDefault));
             if (!h->stage_ev[i]) LB_HIP(hipEventCreateWithFlags(&h->stage_ev[i], hipEventDisableTiming));
         }
-        // host buffer -> pinned slab (memcpy) -> HBM (async DMA), two slabs in flight
         const size_t total = (size_t)n * h->dim * sizeof(float);
         const char *src = reinterpret_cast<const char *>(vectors);
         char *dst = reinterpret_cast<char *>(h->d_X + (size_t)h->n * h->dim);
         size_t off = 0;
+        // Large batches: pin the caller's buffer (the Arrow values buffer) for the duration of the call and
+        // DMA straight out of it -- no host-side copy (SURVEY 8b ownership row: "the shim hipHostRegisters
+        // the Arrow values buffer for the duration of the call").  Small batches, or a buffer the driver
+        // will not pin, go through the double-buffered pinned slabs below.
+        if (total >= (size_t)g_add_register_min.load() && g_add_register_min.load() > 0) {
+            void *reg = const_cast<float *>(vectors);
+            if (hipHostRegister(reg, total, hipHostRegisterDefault) == hipSuccess) {
+                hipError_t e = hipSuccess;
+                const size_t piece = (size_t)256 << 20;
+                for (size_t o = 0; o < total && e == hipSuccess; o += piece)
+                    e = hipMemcpyAsync(dst + o, src + o, std::min(piece, total - o), hipMemcpyHostToDevice, h->add_stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(h->add_stream);
+                (void)hipHostUnregister(reg);
+                if (e != hipSuccess) throw HipErr{e, "hipMemcpyAsync (registered add)"};
+                off = total;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        // host buffer -> pinned slab (memcpy) -> HBM (async DMA), two slabs in flight
         int slab = 0;
         bool used[2] = {false, false};
         while (off < total) {
@@ -1053,19 +1249,18 @@ int lb_simd_and_bytes(int device, uint8_t *dst, const uint8_t *src, int64_t n)
     if (n == 0) return LB_OK;
     if (!dst || !src) return LB_ERR_INVALID_ARG;
     if (!device_ok(device)) return LB_ERR_NO_DEVICE;
-    if (hipSetDevice(device) != hipSuccess) return LB_ERR_HIP;
-    uint8_t *d_a = nullptr, *d_b = nullptr;
-    int rc = LB_OK;
-    if (hipMalloc(&d_a, (size_t)n) != hipSuccess || hipMalloc(&d_b, (size_t)n) != hipSuccess) rc = LB_ERR_OOM;
-    else if (hipMemcpy(d_a, dst, (size_t)n, hipMemcpyHostToDevice) != hipSuccess ||
-             hipMemcpy(d_b, src, (size_t)n, hipMemcpyHostToDevice) != hipSuccess) rc = LB_ERR_HIP;
-    else {
-        launch_and_bytes(d_a, d_b, n, nullptr);
-        if (hipMemcpy(dst, d_a, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) rc = LB_ERR_HIP;
+    try {
+        LB_HIP(hipSetDevice(device));
+        Lease da(device, (size_t)n), db(device, (size_t)n);
+        LB_HIP(hipMemcpy(da.p, dst, (size_t)n, hipMemcpyHostToDevice));
+        LB_HIP(hipMemcpy(db.p, src, (size_t)n, hipMemcpyHostToDevice));
+        launch_and_bytes(da.as<uint8_t>(), db.as<uint8_t>(), n, nullptr);
+        LB_LAUNCH_CHECK();
+        LB_HIP(hipMemcpy(dst, da.p, (size_t)n, hipMemcpyDeviceToHost));
+    } catch (const HipErr &e) {
+        return e.e == hipErrorOutOfMemory ? LB_ERR_OOM : LB_ERR_HIP;
     }
-    if (d_a) (void)hipFree(d_a);
-    if (d_b) (void)hipFree(d_b);
-    return rc;
+    return LB_OK;
 }
 
 int64_t lb_gpu_index_last_fallbacks(const lb_gpu_index *h) { return h ? h->last_fallbacks.load() : 0; }
@@ -1101,6 +1296,7 @@ int lb_gpu_index_search_device(lb_gpu_index *h, int64_t nq, const float *d_queri
                 if (rc != LB_OK) { release_ws(h, std::move(w)); return rc; }
             }
         }
+        LB_LAUNCH_CHECK();
         LB_HIP(hipStreamSynchronize(s));
         h->last_fallbacks.store(fallbacks);
         if (prof) finish_profile(h, w.get());
@@ -1181,9 +1377,9 @@ int lb_gpu_index_last_timing(const lb_gpu_index *hc, float ms[5], int n_launch[5
     return LB_OK;
 }
 
-// profiling aid, not part of the public header: selects a timing-only ablation of the GEMM kernel
-void lb_debug_set_gemm_ablation(int v) { lb::g_gemm_ablation = v; }
+// Test hooks (both settings are exact; they only choose between two schedules / expose host logic).
 void lb_debug_set_sample_tau(int v) { g_sample_tau.store(v); } // 0: classic bootstrap schedule only
+void lb_debug_set_add_register_min(long long bytes) { g_add_register_min.store(bytes); } // ingest A/B (tools/bench_add.py)
 // host-only: the sampled-threshold plan for a view of n rows (tests check its invariants without a GPU);
 // out = {on, span, count, m}
 void lb_debug_sample_plan(long long n, int keep, unsigned cap, unsigned count_max, long long *out)
@@ -1194,10 +1390,82 @@ void lb_debug_sample_plan(long long n, int keep, unsigned cap, unsigned count_ma
     out[2] = p.count;
     out[3] = p.m;
 }
+#ifdef LB_DIAG
+// Diagnostic build only (python -m longbow_amd.build --diag): timing-only ablations whose results are
+// wrong by design, the in-kernel clock probe, staging A/B.  None of this exists in liblongbow_gpu.so.
+void lb_debug_set_gemm_ablation(int v) { lb::g_gemm_ablation = v; }
 void lb_debug_set_gemm_glds(int v) { lb::g_gemm_glds = v; }
 void lb_debug_set_adc_ablation(int v) { lb::g_adc_ablation = v; }
 int lb_debug_gemm_occupancy(void) { return lb::debug_gemm_occupancy(); }
 void lb_debug_read_clock_probe(unsigned long long *out, int reset) { lb::read_clock_probe(out, reset != 0); }
+#endif
+
+// ---- candidate re-rank (processChunkInternal) ------------------------------------------
+int lb_gpu_index_rerank_device(lb_gpu_index *h, const float *d_query, const int64_t *d_rows, int64_t n, int order,
+                               float *d_dist, float *d_score, void *stream)
+{
+    if (!h || n < 0 || (order != -1 && order != LB_ORDER_SEQ && order != LB_ORDER_UNROLL4)) return LB_ERR_INVALID_ARG;
+    if (n == 0) return LB_OK;
+    if (!d_query || !d_rows || !d_dist) return LB_ERR_INVALID_ARG;
+    if (n > (int64_t)0x7fffffff) return LB_ERR_INVALID_ARG;
+    std::shared_lock<std::shared_mutex> g(h->mu);
+    if (h->closed) { h->set_error("index is closed"); return LB_ERR_CLOSED; }
+    try {
+        LB_HIP(hipSetDevice(h->device));
+        const int ord = order == -1 ? h->order.load() : order;
+        Lease map(h->device, (size_t)n * sizeof(uint32_t)), qna(h->device, 16);
+        // a private stream per call when the caller gave none (the null stream would serialise callers)
+        hipStream_t s = (hipStream_t)stream;
+        std::unique_ptr<Workspace> w;
+        if (!s) {
+            int kc; uint32_t cap;
+            cand_geometry(1, kc, cap);
+            w = acquire_ws(h, 1, cap);
+            s = w->stream;
+        }
+        const unsigned blocks = (unsigned)((n + 255) / 256);
+        hipLaunchKernelGGL(rerank_map_kernel, dim3(blocks), dim3(256), 0, s, d_rows, n, h->n, map.as<uint32_t>());
+        if (h->n > 0) {
+            if (h->metric == LB_METRIC_COSINE) launch_query_norms(ord, d_query, nullptr, 1, h->dim, qna.as<float>(), s);
+            CandState cs{};
+            launch_scan(h->metric, ord, /*raw_dot=*/false, h->d_X, 0, n, h->dim, d_query, nullptr, 1, qna.as<float>(), nullptr,
+                        map.as<uint32_t>(), cs, false, d_dist, n, s);
+        }
+        hipLaunchKernelGGL(rerank_score_kernel, dim3(blocks), dim3(256), 0, s, d_rows, n, h->n, d_dist, d_score);
+        LB_LAUNCH_CHECK();
+        LB_HIP(hipStreamSynchronize(s));
+        if (w) release_ws(h, std::move(w));
+    } catch (const HipErr &e) {
+        return fail_hip(h, e);
+    }
+    return LB_OK;
+}
+
+int lb_gpu_index_rerank(lb_gpu_index *h, const float *query, const int64_t *rows, int64_t n, int order, float *dist,
+                        float *score)
+{
+    if (!h || n < 0) return LB_ERR_INVALID_ARG;
+    if (n == 0) return LB_OK;
+    if (!query || !rows || !dist) return LB_ERR_INVALID_ARG;
+    try {
+        LB_HIP(hipSetDevice(h->device));
+        // [query | rows] up through one pinned block, [dist | score] back through another
+        const size_t qb = ((size_t)h->dim * 4 + 15) & ~(size_t)15, rb = (size_t)n * 8, ob = (size_t)n * 4;
+        Lease hin(h->device, qb + rb, true), din(h->device, qb + rb), dout(h->device, 2 * ob), hout(h->device, 2 * ob, true);
+        std::memcpy(hin.p, query, (size_t)h->dim * 4);
+        std::memcpy(hin.as<char>() + qb, rows, rb);
+        LB_HIP(hipMemcpy(din.p, hin.p, qb + rb, hipMemcpyHostToDevice));
+        const int rc = lb_gpu_index_rerank_device(h, din.as<float>(), reinterpret_cast<const int64_t *>(din.as<char>() + qb), n,
+                                                  order, dout.as<float>(), dout.as<float>() + n, nullptr);
+        if (rc != LB_OK) return rc;
+        LB_HIP(hipMemcpy(hout.p, dout.p, 2 * ob, hipMemcpyDeviceToHost));
+        std::memcpy(dist, hout.p, ob);
+        if (score) std::memcpy(score, hout.as<char>() + ob, ob);
+    } catch (const HipErr &e) {
+        return fail_hip(h, e);
+    }
+    return LB_OK;
+}
 
 // ---- simd batch interface ---------------------------------------------------------
 int lb_simd_distance_batch_flat_device(int device, int metric, int order, const float *d_query,
@@ -1206,20 +1474,22 @@ int lb_simd_distance_batch_flat_device(int device, int metric, int order, const 
     if (metric < 0 || metric > 2 || (order != 0 && order != 1) || n < 0 || dims < 0) return LB_ERR_INVALID_ARG;
     if (n == 0) return LB_OK; // batch_operations.go:65-67
     if (!d_query || !d_flat || !d_results || dims == 0) return LB_ERR_INVALID_ARG;
+    if (dims > LB_MAX_DIM) return LB_ERR_UNSUPPORTED;
     if (!device_ok(device)) return LB_ERR_NO_DEVICE;
-    if (hipSetDevice(device) != hipSuccess) return LB_ERR_HIP;
-    hipStream_t s = (hipStream_t)stream;
-    float *d_qna = nullptr;
-    if (metric == LB_METRIC_COSINE) {
-        if (hipMalloc(&d_qna, sizeof(float)) != hipSuccess) return LB_ERR_OOM;
-        launch_query_norms(order, d_query, nullptr, 1, dims, d_qna, s);
+    try {
+        LB_HIP(hipSetDevice(device));
+        hipStream_t s = (hipStream_t)stream;
+        Lease qna(device, 16);
+        if (metric == LB_METRIC_COSINE) launch_query_norms(order, d_query, nullptr, 1, dims, qna.as<float>(), s);
+        CandState cs{};
+        launch_scan(metric, order, /*raw_dot=*/true, d_flat, 0, n, dims, d_query, nullptr, 1, qna.as<float>(), nullptr, nullptr,
+                    cs, false, d_results, n, s);
+        LB_LAUNCH_CHECK();
+        LB_HIP(hipStreamSynchronize(s));
+    } catch (const HipErr &e) {
+        return e.e == hipErrorOutOfMemory ? LB_ERR_OOM : LB_ERR_HIP;
     }
-    CandState cs{};
-    launch_scan(metric, order, /*raw_dot=*/true, d_flat, 0, n, dims, d_query, nullptr, 1, d_qna, nullptr, nullptr, cs,
-                false, d_results, n, s);
-    hipError_t e = hipStreamSynchronize(s);
-    if (d_qna) (void)hipFree(d_qna);
-    return e == hipSuccess ? LB_OK : LB_ERR_HIP;
+    return LB_OK;
 }
 
 int lb_simd_distance_batch_flat(int device, int metric, int order, const float *query, const float *flat,
@@ -1229,43 +1499,40 @@ int lb_simd_distance_batch_flat(int device, int metric, int order, const float *
     if (n == 0) return LB_OK;
     if (!query || !flat || !results || dims == 0) return LB_ERR_INVALID_ARG;
     if (!device_ok(device)) return LB_ERR_NO_DEVICE;
-    if (hipSetDevice(device) != hipSuccess) return LB_ERR_HIP;
-    float *d_q = nullptr, *d_x = nullptr, *d_r = nullptr;
-    int rc = LB_OK;
-    if (hipMalloc(&d_q, (size_t)dims * 4) != hipSuccess || hipMalloc(&d_x, (size_t)n * dims * 4) != hipSuccess ||
-        hipMalloc(&d_r, (size_t)n * 4) != hipSuccess) {
-        rc = LB_ERR_OOM;
-    } else if (hipMemcpy(d_q, query, (size_t)dims * 4, hipMemcpyHostToDevice) != hipSuccess ||
-               hipMemcpy(d_x, flat, (size_t)n * dims * 4, hipMemcpyHostToDevice) != hipSuccess) {
-        rc = LB_ERR_HIP;
-    } else {
-        rc = lb_simd_distance_batch_flat_device(device, metric, order, d_q, d_x, n, dims, d_r, nullptr);
-        if (rc == LB_OK && hipMemcpy(results, d_r, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = LB_ERR_HIP;
+    try {
+        LB_HIP(hipSetDevice(device));
+        Lease dq(device, (size_t)dims * 4), dx(device, (size_t)n * dims * 4), dr(device, (size_t)n * 4);
+        LB_HIP(hipMemcpy(dq.p, query, (size_t)dims * 4, hipMemcpyHostToDevice));
+        LB_HIP(hipMemcpy(dx.p, flat, (size_t)n * dims * 4, hipMemcpyHostToDevice));
+        const int rc = lb_simd_distance_batch_flat_device(device, metric, order, dq.as<float>(), dx.as<float>(), n, dims,
+                                                          dr.as<float>(), nullptr);
+        if (rc != LB_OK) return rc;
+        LB_HIP(hipMemcpy(results, dr.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    } catch (const HipErr &e) {
+        return e.e == hipErrorOutOfMemory ? LB_ERR_OOM : LB_ERR_HIP;
     }
-    if (d_q) (void)hipFree(d_q);
-    if (d_x) (void)hipFree(d_x);
-    if (d_r) (void)hipFree(d_r);
-    return rc;
+    return LB_OK;
 }
 
 // ---- merge / fill -----------------------------------------------------------------
 int lb_gpu_merge_topk_device(int device, int nshards, int64_t nq, int k, const float *d_dist_in,
                              const int64_t *d_labels_in, float *d_dist_out, int64_t *d_labels_out, void *stream)
 {
-    if (nshards <= 0 || nq < 0 || k <= 0 || (int64_t)nshards * k > 8192) return LB_ERR_INVALID_ARG;
+    if (nshards <= 0 || nq < 0 || k <= 0 || (int64_t)nshards * k > 16384) return LB_ERR_INVALID_ARG;
     if (nq == 0) return LB_OK;
     if (!d_dist_in || !d_labels_in || !d_dist_out || !d_labels_out) return LB_ERR_INVALID_ARG;
     if (!device_ok(device)) return LB_ERR_NO_DEVICE;
     if (hipSetDevice(device) != hipSuccess) return LB_ERR_HIP;
     launch_merge_topk(nshards, nq, k, d_dist_in, d_labels_in, nq * k, nq * k, d_dist_out, d_labels_out,
                       (hipStream_t)stream);
+    if (hipGetLastError() != hipSuccess) return LB_ERR_HIP;
     return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? LB_OK : LB_ERR_HIP;
 }
 
 int lb_gpu_merge_topk_packed_device(int device, int nshards, int64_t nq, int k, const void *d_packed,
                                     float *d_dist_out, int64_t *d_labels_out, void *stream)
 {
-    if (nshards <= 0 || nq < 0 || k <= 0 || (int64_t)nshards * k > 8192) return LB_ERR_INVALID_ARG;
+    if (nshards <= 0 || nq < 0 || k <= 0 || (int64_t)nshards * k > 16384) return LB_ERR_INVALID_ARG;
     if (nq == 0) return LB_OK;
     if (!d_packed || !d_dist_out || !d_labels_out) return LB_ERR_INVALID_ARG;
     if (!device_ok(device)) return LB_ERR_NO_DEVICE;
@@ -1277,6 +1544,7 @@ int lb_gpu_merge_topk_packed_device(int device, int nshards, int64_t nq, int k, 
     launch_merge_topk(nshards, nq, k, reinterpret_cast<const float *>(base + nk * 8),
                       reinterpret_cast<const int64_t *>(base), block_bytes / 4, block_bytes / 8, d_dist_out,
                       d_labels_out, (hipStream_t)stream);
+    if (hipGetLastError() != hipSuccess) return LB_ERR_HIP;
     return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? LB_OK : LB_ERR_HIP;
 }
 
@@ -1290,6 +1558,7 @@ int lb_gpu_rrf_fuse_device(int device, int64_t nq, int kd, const int64_t *d_dens
     if (!device_ok(device)) return LB_ERR_NO_DEVICE;
     if (hipSetDevice(device) != hipSuccess) return LB_ERR_HIP;
     launch_rrf(nq, kd, d_dense_ids, ks, d_sparse_ids, k <= 0 ? 60 : k, limit, d_out_ids, d_out_scores, (hipStream_t)stream);
+    if (hipGetLastError() != hipSuccess) return LB_ERR_HIP;
     return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? LB_OK : LB_ERR_HIP;
 }
 
@@ -1300,27 +1569,21 @@ int lb_gpu_rrf_fuse(int device, int64_t nq, int kd, const int64_t *dense_ids, in
     if (nq == 0) return LB_OK;
     if ((kd > 0 && !dense_ids) || (ks > 0 && !sparse_ids) || !out_ids || !out_scores) return LB_ERR_INVALID_ARG;
     if (!device_ok(device)) return LB_ERR_NO_DEVICE;
-    if (hipSetDevice(device) != hipSuccess) return LB_ERR_HIP;
-    int64_t *d_d = nullptr, *d_s = nullptr, *d_o = nullptr;
-    float *d_sc = nullptr;
-    int rc = LB_OK;
-    const size_t bd = (size_t)nq * std::max(kd, 1) * 8, bs = (size_t)nq * std::max(ks, 1) * 8;
-    if (hipMalloc(&d_d, bd) != hipSuccess || hipMalloc(&d_s, bs) != hipSuccess ||
-        hipMalloc(&d_o, (size_t)nq * limit * 8) != hipSuccess || hipMalloc(&d_sc, (size_t)nq * limit * 4) != hipSuccess) {
-        rc = LB_ERR_OOM;
-    } else {
-        if (kd > 0 && hipMemcpy(d_d, dense_ids, (size_t)nq * kd * 8, hipMemcpyHostToDevice) != hipSuccess) rc = LB_ERR_HIP;
-        if (ks > 0 && hipMemcpy(d_s, sparse_ids, (size_t)nq * ks * 8, hipMemcpyHostToDevice) != hipSuccess) rc = LB_ERR_HIP;
-        if (rc == LB_OK) rc = lb_gpu_rrf_fuse_device(device, nq, kd, d_d, ks, d_s, k, limit, d_o, d_sc, nullptr);
-        if (rc == LB_OK && (hipMemcpy(out_ids, d_o, (size_t)nq * limit * 8, hipMemcpyDeviceToHost) != hipSuccess ||
-                            hipMemcpy(out_scores, d_sc, (size_t)nq * limit * 4, hipMemcpyDeviceToHost) != hipSuccess))
-            rc = LB_ERR_HIP;
+    try {
+        LB_HIP(hipSetDevice(device));
+        const size_t bd = (size_t)nq * std::max(kd, 1) * 8, bs = (size_t)nq * std::max(ks, 1) * 8;
+        Lease dd(device, bd), ds(device, bs), dout(device, (size_t)nq * limit * 8), dsc(device, (size_t)nq * limit * 4);
+        if (kd > 0) LB_HIP(hipMemcpy(dd.p, dense_ids, (size_t)nq * kd * 8, hipMemcpyHostToDevice));
+        if (ks > 0) LB_HIP(hipMemcpy(ds.p, sparse_ids, (size_t)nq * ks * 8, hipMemcpyHostToDevice));
+        const int rc = lb_gpu_rrf_fuse_device(device, nq, kd, dd.as<int64_t>(), ks, ds.as<int64_t>(), k, limit,
+                                              dout.as<int64_t>(), dsc.as<float>(), nullptr);
+        if (rc != LB_OK) return rc;
+        LB_HIP(hipMemcpy(out_ids, dout.p, (size_t)nq * limit * 8, hipMemcpyDeviceToHost));
+        LB_HIP(hipMemcpy(out_scores, dsc.p, (size_t)nq * limit * 4, hipMemcpyDeviceToHost));
+    } catch (const HipErr &e) {
+        return e.e == hipErrorOutOfMemory ? LB_ERR_OOM : LB_ERR_HIP;
     }
-    if (d_d) (void)hipFree(d_d);
-    if (d_s) (void)hipFree(d_s);
-    if (d_o) (void)hipFree(d_o);
-    if (d_sc) (void)hipFree(d_sc);
-    return rc;
+    return LB_OK;
 }
 
 int lb_gpu_fill_uniform_device(int device, float *d_dst, int64_t n, uint64_t seed, int64_t offset, void *stream)
@@ -1329,6 +1592,7 @@ int lb_gpu_fill_uniform_device(int device, float *d_dst, int64_t n, uint64_t see
     if (!device_ok(device)) return LB_ERR_NO_DEVICE;
     if (hipSetDevice(device) != hipSuccess) return LB_ERR_HIP;
     launch_fill_uniform(d_dst, n, seed, offset, (hipStream_t)stream);
+    if (hipGetLastError() != hipSuccess) return LB_ERR_HIP;
     return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? LB_OK : LB_ERR_HIP;
 }
 
@@ -1338,6 +1602,7 @@ int lb_gpu_fill_codes_device(int device, uint8_t *d_dst, int64_t n, uint64_t see
     if (!device_ok(device)) return LB_ERR_NO_DEVICE;
     if (hipSetDevice(device) != hipSuccess) return LB_ERR_HIP;
     launch_fill_codes(d_dst, n, seed, offset, (hipStream_t)stream);
+    if (hipGetLastError() != hipSuccess) return LB_ERR_HIP;
     return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? LB_OK : LB_ERR_HIP;
 }
 

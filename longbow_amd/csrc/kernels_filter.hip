@@ -279,7 +279,11 @@ void launch_rrf(int64_t nq, int kd, const int64_t *dense, int ks, const int64_t 
     if (nq <= 0 || limit <= 0) return;
     uint32_t P = 2;
     while ((int)P < kd + ks) P <<= 1;
-    hipLaunchKernelGGL(rrf_kernel, dim3((unsigned)nq), dim3(256), (size_t)P * 12, s, nq, kd, dense, ks, sparse, k, limit,
+    const size_t shmem = (size_t)P * 12; // 98,304 B at kd + ks = 8192: above the 64 KB default, opt in
+    if (shmem > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(rrf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)shmem);
+    hipLaunchKernelGGL(rrf_kernel, dim3((unsigned)nq), dim3(256), shmem, s, nq, kd, dense, ks, sparse, k, limit,
                        out_ids, out_scores);
 }
 

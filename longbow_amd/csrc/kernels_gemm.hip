@@ -493,8 +493,8 @@ int debug_gemm_occupancy()
     return nb;
 }
 
-int g_gemm_glds = 0;     // A/B switch (tools/ablate_gemm.py): -1 = register staging
-int g_gemm_ablation = 0; // profiling aid (tools/ablate_gemm.py); never set by the product path
+int g_gemm_glds = 0;     // A/B switch (tools/ablate_gemm.py, diagnostic build): -1 = register staging
+int g_gemm_ablation = 0; // profiling aid (diagnostic build only); always 0 in the product build
 
 void launch_gemm_filter(int metric, const float *X, const float *norm2, const float *rnorm,
                         int64_t row_begin, int64_t row_end, int D, const float *Q, int nq,
@@ -515,6 +515,7 @@ void launch_gemm_filter(int metric, const float *X, const float *norm2, const fl
     const bool aligned = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0) &&
                          ((reinterpret_cast<uintptr_t>(Q) & 15) == 0);
     const int mode = !aligned ? 0 : (D % BK == 0 ? 2 : 1);
+#ifdef LB_DIAG // timing-only ablations and the clock probe exist only in the diagnostic build
     if (split && g_gemm_ablation > 0 && metric == METRIC_COS) {
         switch (g_gemm_ablation) {
         case 1: hipLaunchKernelGGL((gemm_filter_kernel<METRIC_COS, 2, 1, true, true>), grid, dim3(GEMM_THREADS), 0, s, a); return;
@@ -524,7 +525,7 @@ void launch_gemm_filter(int metric, const float *X, const float *norm2, const fl
         default: break;
         }
     }
-    static const int env_abl = [] { const char *e = getenv("LB_GEMM_ABL"); return e ? atoi(e) : 0; }();
+    static const int env_abl = lb_tunable("LB_GEMM_ABL", 0);
     if (env_abl > 0 && g_gemm_ablation == 0) g_gemm_ablation = env_abl;
     if (!split && g_gemm_ablation == 8 && metric == METRIC_COS && mode == 2) { // A/B: default cache policy on the corpus stream
         hipLaunchKernelGGL((gemm_filter_kernel<METRIC_COS, 2, 8, true, false>), grid, dim3(GEMM_THREADS), 0, s, a);
@@ -539,7 +540,7 @@ void launch_gemm_filter(int metric, const float *X, const float *norm2, const fl
         case 5: {
             // LB_GEMM_1WG=1: pad the LDS request so that only ONE workgroup fits a CU (diagnostic: main-loop
             // cycles of a wave that has its SIMD to itself)
-            static const int one_wg = [] { const char *e = getenv("LB_GEMM_1WG"); return e ? atoi(e) : 0; }();
+            static const int one_wg = lb_tunable("LB_GEMM_1WG", 0);
             const size_t pad = one_wg ? 40 * 1024 : 0;
             if (pad) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_filter_kernel<METRIC_COS, 2, 5>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
@@ -551,9 +552,10 @@ void launch_gemm_filter(int metric, const float *X, const float *norm2, const fl
         default: break;
         }
     }
+#endif
     // direct-to-LDS staging is the default for the aligned, D % 32 == 0 case (LB_GEMM_GLDS=0 or
     // g_gemm_glds = -1 selects the register-staged pipeline for A/B runs)
-    static const bool env_noglds = [] { const char *e = getenv("LB_GEMM_GLDS"); return e && e[0] == '0'; }();
+    static const bool env_noglds = lb_tunable("LB_GEMM_GLDS", 1) == 0;
     if (split) {
         // X / Q are split-bf16 images (caller guarantees D % 32 == 0 and 16-B alignment)
         if (metric == METRIC_L2) hipLaunchKernelGGL((gemm_filter_kernel<METRIC_L2, 2, 0, true, true>), grid, dim3(GEMM_THREADS), 0, s, a);

@@ -63,6 +63,7 @@ struct AdcArgs {
     float *all_out; // indexed by absolute row - out_base
     int64_t out_base;
     int boot;
+    const int *skip_if_ok; // byte-table prefilter params {s_tau, ok}: ok != 0 -> nothing to do here
 };
 
 // ABL (profiling aid, wrong results): 1 = no LDS gathers, 2 = no global code loads
@@ -71,6 +72,7 @@ __global__ __launch_bounds__(ADC_THREADS) void adc_scan_kernel(AdcArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float tab[];
     const int M = a.M;
+    if (a.skip_if_ok && a.skip_if_ok[1] != 0) return;
     for (int i = threadIdx.x; i < M * 256; i += ADC_THREADS) tab[i] = a.table[i];
     __syncthreads();
     const uint64_t tau = a.all_out ? 0ull : a.cs.tau[a.slot];
@@ -134,6 +136,7 @@ __global__ __launch_bounds__(ADC_DMA_WAVES * 64) void adc_scan_dma_kernel(AdcArg
     unsigned char *stage_all = reinterpret_cast<unsigned char *>(smem_f + M * 256);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (a.skip_if_ok && a.skip_if_ok[1] != 0) return;
     for (int i = tid; i < M * 256; i += ADC_DMA_WAVES * 64) tab[i] = a.table[i];
     __syncthreads();
     unsigned char *stage = stage_all + wave * (ADC_DMA_SLOTS * 64 * M);
@@ -264,14 +267,15 @@ void launch_adc_sample(const float *table, int M, const uint8_t *codes, int64_t 
     hipLaunchKernelGGL(adc_sample_kernel, dim3(blocks), dim3(ADC_THREADS), shmem, s, table, M, codes, n, count, out, vec16);
 }
 
-int g_adc_ablation = 0; // profiling aid (tools/bench_pq.py)
+int g_adc_ablation = 0; // profiling aid (diagnostic build only; always 0 in the product build)
 
 void launch_adc_scan(const float *table, int M, const uint8_t *codes, int64_t row_begin, int64_t row_end,
                      int slot, const uint8_t *mask, CandState cs, bool boot, float *all_out,
-                     int64_t out_base, hipStream_t s)
+                     int64_t out_base, hipStream_t s, const int *skip_if_ok)
 {
     if (row_end <= row_begin) return;
     AdcArgs a;
+    a.skip_if_ok = skip_if_ok;
     a.boot = boot ? 1 : 0;
     a.table = table; a.M = M; a.codes = codes; a.row_begin = row_begin; a.row_end = row_end;
     a.slot = slot; a.mask = mask; a.cs = cs; a.all_out = all_out; a.out_base = out_base;
@@ -293,6 +297,7 @@ void launch_adc_scan(const float *table, int M, const uint8_t *codes, int64_t ro
         }
         if (ok) return;
     }
+#ifdef LB_DIAG
     if (vec && g_adc_ablation) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(adc_scan_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(adc_scan_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
@@ -300,6 +305,7 @@ void launch_adc_scan(const float *table, int M, const uint8_t *codes, int64_t ro
         else hipLaunchKernelGGL((adc_scan_kernel<true, 2>), dim3((unsigned)blocks), dim3(ADC_THREADS), shmem, s, a);
         return;
     }
+#endif
     if (vec) {
         if (shmem > 64 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(adc_scan_kernel<true>),

@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void scan_generic_kernel(ScanArgs a)
                 dist = a.raw_dot ? t : -t;
             }
             if (a.all_out) {
-                a.all_out[(int64_t)j * a.ld + row] = dist;
+                a.all_out[(int64_t)j * a.ld + pos] = dist; // indexed by position (== row without a row map)
             } else {
                 const uint64_t ent = pack_entry(dist, (uint32_t)row);
                 if (a.boot) {
@@ -626,7 +626,7 @@ void launch_sample_scores(int metric, int order, const float *X, int D, int64_t 
     a.X = X; a.D = D; a.span = span; a.count = count; a.rowmap = rowmap; a.mask = mask;
     a.Q = Q; a.qsel = qsel; a.nsel = nsel < SS_MAX_SLOTS ? nsel : SS_MAX_SLOTS; a.cs = cs;
     a.aligned = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && ((reinterpret_cast<uintptr_t>(Q) & 15) == 0);
-    static const int env_r = [] { const char *e = getenv("LB_SAMPLE_ROWS_PER_WAVE"); return e ? atoi(e) : 0; }();
+    static const int env_r = lb_tunable("LB_SAMPLE_ROWS_PER_WAVE", 0);
     const int R = (env_r == 1 || env_r == 2 || env_r == 4) ? env_r : (a.nsel > SS_MAXQ ? 4 : 1);
     a.nblocks = (count + 4 * R - 1) / (4 * R);
     dim3 grid(a.nblocks + (a.qna ? (unsigned)a.nsel : 0u)), block(256);
@@ -797,7 +797,7 @@ void launch_sample_tau(CandState cs, const int *qsel, int nsel, uint32_t count, 
                        m, (zero_stripes && cs.stripes != nullptr) ? 1 : 0, Q, D, qna, order);
 }
 
-int g_scan_nbuf = [] { const char *e = getenv("LB_SCAN_NBUF"); return e ? atoi(e) : 1; }();
+int g_scan_nbuf = lb_tunable("LB_SCAN_NBUF", 1);
 
 template <int METRIC, int ORDER, int NQ>
 static void launch_scan_variant(dim3 grid, hipStream_t s, const ScanArgs &a)
@@ -853,7 +853,7 @@ void launch_scan(int metric, int order, bool raw_dot, const float *X, int64_t ro
     }
     const int64_t ntiles = (row_end - row_begin + SC_ROWS - 1) / SC_ROWS;
     // 69.6 KB (2 stages) / 34.8 KB (1 stage) LDS per workgroup -> 2 / 4 workgroups per CU; 256 CUs.
-    static const int waves_mult = [] { const char *e = getenv("LB_SCAN_GRIDMULT"); return e ? atoi(e) : 4; }();
+    static const int waves_mult = lb_tunable("LB_SCAN_GRIDMULT", 4);
     const int64_t maxgrid = 256 * (g_scan_nbuf == 1 ? 4 : 2) * waves_mult;
     dim3 grid((unsigned)(ntiles < maxgrid ? ntiles : maxgrid));
     int nq_t = nsel <= 1 ? 1 : nsel <= 2 ? 2 : nsel <= 4 ? 4 : 8;

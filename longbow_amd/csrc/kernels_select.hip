@@ -347,7 +347,7 @@ void launch_select(CandState cs, const int *qsel, int nsel, int kc, uint32_t boo
     if (nsel <= 0) return;
     const size_t shmem = (size_t)next_pow2_host(cs.cap) * sizeof(uint64_t) + (256 + 4 + 8) * sizeof(uint32_t);
     // lists up to this size are simply sorted (one 1024-thread workgroup); larger ones take the radix select
-    static const uint32_t sort_max_big = [] { const char *e = getenv("LB_SELECT_SORT_MAX"); return e ? (uint32_t)atoi(e) : 0u; }();
+    static const uint32_t sort_max_big = (uint32_t)lb_tunable("LB_SELECT_SORT_MAX", 0);
     const uint32_t sort_max = nsel <= 32 ? sort_max_big : 0u;
     if (nsel <= 32) { // few queries: one big workgroup each, latency matters
         allow_big_lds(select_kernel<1024>, shmem);
@@ -773,52 +773,69 @@ void launch_emit_lists(CandState cs, const int *qsel, int nsel, int k, const int
 
 // ---------------------------------------------------------------------------
 // Cross-shard merge: per query S*k (dist,label) pairs -> k smallest by (dist, label).
-// Labels are i64, compared as unsigned so the -1 padding sorts last.
+// The LDS sort runs on ONE u64 per entry, (canonical sortable distance << 32) | input index, so 16384
+// entries (k = 2048 on 8 shards) fit in 128 KB; labels stay in HBM and are fetched for the k winners.
+// Canonical order as in the single-shard lists: every NaN after +inf, padding (label < 0) last of all.
+// The index tie-break is (shard, position); entries with EQUAL distances are then re-ranked by label
+// (unsigned, so that padding stays last) in a fix-up pass that only touches runs of equal distance.
 __global__ __launch_bounds__(SEL_THREADS) void merge_topk_kernel(int nshards, int64_t nq, int k,
                                                                  const float *dist_in,
                                                                  const int64_t *lab_in,
                                                                  int64_t dist_stride, int64_t lab_stride,
                                                                  float *dist_out, int64_t *lab_out)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    extern __shared__ __attribute__((aligned(16))) uint64_t mkey[];
     const int64_t q = blockIdx.x;
     const int tid = threadIdx.x;
     const uint32_t n = (uint32_t)(nshards * k);
     const uint32_t P = next_pow2(n);
-    uint64_t *slab = reinterpret_cast<uint64_t *>(smem);
-    uint32_t *skey = reinterpret_cast<uint32_t *>(slab + P);
+    auto label_of = [&](uint32_t idx) -> uint64_t {
+        const uint32_t s = idx / (uint32_t)k, r = idx % (uint32_t)k;
+        return (uint64_t)lab_in[(int64_t)s * lab_stride + q * k + r];
+    };
     for (uint32_t i = tid; i < P; i += SEL_THREADS) {
+        uint64_t e = kEntryMax;
         if (i < n) {
-            const int s = i / k, r = i % k;
+            const uint32_t s = i / (uint32_t)k, r = i % (uint32_t)k;
             const int64_t off = q * k + r; // within one shard's [nq][k] block
-            skey[i] = f32_sortable(dist_in[(int64_t)s * dist_stride + off] + 0.0f);
-            slab[i] = (uint64_t)lab_in[(int64_t)s * lab_stride + off];
-        } else {
-            skey[i] = 0xffffffffu;
-            slab[i] = ~0ull;
+            const float d = dist_in[(int64_t)s * dist_stride + off] + 0.0f; // -0 -> +0
+            const int64_t lab = lab_in[(int64_t)s * lab_stride + off];
+            uint32_t sk = (d != d) ? 0xffc00000u : f32_sortable(d);
+            if (lab < 0) sk = 0xffffffffu; // padding sorts after every real row, non-finite ones included
+            e = ((uint64_t)sk << 32) | i;
         }
+        mkey[i] = e;
     }
     __syncthreads();
-    for (uint32_t kk = 2; kk <= P; kk <<= 1) {
-        for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = tid; t < (P >> 1); t += SEL_THREADS) {
-                const uint32_t i = 2 * t - (t & (j - 1));
-                const uint32_t l = i + j;
-                const uint32_t ka = skey[i], kb = skey[l];
-                const uint64_t la = slab[i], lb2 = slab[l];
-                const bool gt = ka > kb || (ka == kb && la > lb2);
-                const bool up = (i & kk) == 0;
-                if (gt == up) {
-                    skey[i] = kb; skey[l] = ka;
-                    slab[i] = lb2; slab[l] = la;
-                }
+    bitonic_sort_u64(mkey, P, tid, SEL_THREADS);
+    // fix-up + output: an entry inside a run of equal distances moves to its label rank within the run
+    for (uint32_t i = tid; i < n; i += SEL_THREADS) {
+        const uint64_t e = mkey[i];
+        const uint32_t sk = (uint32_t)(e >> 32);
+        uint32_t lo = i, hi = i + 1;
+        while (lo > 0 && (uint32_t)(mkey[lo - 1] >> 32) == sk) lo--;
+        if (lo >= (uint32_t)k) continue; // the whole run lies beyond the output
+        while (hi < n && (uint32_t)(mkey[hi] >> 32) == sk) hi++;
+        uint32_t pos = i;
+        const uint64_t mylab = label_of((uint32_t)e);
+        if (hi - lo > 1) {
+            pos = lo;
+            for (uint32_t j = lo; j < hi; j++) {
+                if (j == i) continue;
+                const uint64_t lj = label_of((uint32_t)mkey[j]);
+                pos += (lj < mylab || (lj == mylab && j < i)) ? 1u : 0u;
             }
-            __syncthreads();
+        }
+        if (pos < (uint32_t)k) {
+            const bool pad = sk == 0xffffffffu;
+            dist_out[q * k + pos] = pad ? FLT_MAX : sortable_f32(sk);
+            lab_out[q * k + pos] = pad ? (int64_t)-1 : (int64_t)mylab;
         }
     }
-    for (int r = tid; r < k; r += SEL_THREADS) {
-        dist_out[q * k + r] = sortable_f32(skey[r]);
-        lab_out[q * k + r] = (int64_t)slab[r];
+    // fewer than k inputs in total (never with nshards >= 1, kept for safety)
+    for (uint32_t r = n + tid; r < (uint32_t)k; r += SEL_THREADS) {
+        dist_out[q * k + r] = FLT_MAX;
+        lab_out[q * k + r] = -1;
     }
 }
 
@@ -827,7 +844,7 @@ void launch_merge_topk(int nshards, int64_t nq, int k, const float *dist_in, con
 {
     if (nq <= 0 || k <= 0) return;
     const size_t P = next_pow2_host((uint32_t)(nshards * k));
-    const size_t shmem = P * 12;
+    const size_t shmem = P * sizeof(uint64_t);
     allow_big_lds(merge_topk_kernel, shmem);
     hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)nq), dim3(SEL_THREADS), shmem, s, nshards, nq,
                        k, dist_in, lab_in, dist_stride, lab_stride, dist_out, lab_out);

@@ -2,8 +2,23 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace lb {
+
+// A/B tunables.  In the product build every tunable IS its compiled-in default (the measured winner);
+// only a -DLB_DIAG build (python -m longbow_amd.build --diag -> liblongbow_gpu_diag.so, used by tools/)
+// reads the LB_* environment variables and carries the timing-only ablation kernels.
+inline int lb_tunable(const char *name, int dflt)
+{
+#ifdef LB_DIAG
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
 
 // ---------------------------------------------------------------------------
 // Candidate entries: (key f32, row u32) packed into one u64 so that unsigned
@@ -183,15 +198,34 @@ void launch_build_adc_table(const float *codebooks, int M, int K, int sub, const
                             float *tables, hipStream_t s);
 // one query per launch: `table` is that query's [M*256] table; entries go to cs slot `slot`,
 // or (all_out != nullptr) every distance is written to all_out[row - out_base].
+// skip_if_ok (nullable): {s_tau, ok} of the byte-table prefilter; the launch returns at once when ok != 0
+// (the prefilter + exact-candidates kernels did the work)
 void launch_adc_scan(const float *table, int M, const uint8_t *codes, int64_t row_begin, int64_t row_end,
                      int slot, const uint8_t *mask, CandState cs, bool boot, float *all_out,
-                     int64_t out_base, hipStream_t s);
+                     int64_t out_base, hipStream_t s, const int *skip_if_ok = nullptr);
 
 // sampled threshold for the ADC scan: exact ADC entries of `count` evenly spaced rows -> out[count];
 // launch_sample_topm reduces them to groups*m entries at lists[slot] (returns groups, 0 = does not fit)
 void launch_adc_sample(const float *table, int M, const uint8_t *codes, int64_t n, uint32_t count, uint64_t *out,
                        hipStream_t s);
 uint32_t launch_sample_topm(const uint64_t *in, uint32_t count_total, int m, CandState cs, int slot, hipStream_t s);
+
+// PQ codec + two-stage ADC search (kernels_pq2.hip)
+void launch_pq_encode(const float *codebooks, int M, int K, int sub, const float *X, int64_t n, uint8_t *codes,
+                      hipStream_t s);
+void launch_pq_decode(const float *codebooks, int M, int K, int sub, const uint8_t *codes, int64_t n, float *out,
+                      hipStream_t s);
+// byte table + integer admission bound per query slot: params[slot*4] = {s_tau, ok, -, -}
+void launch_adc_quantise(const float *tables, int M, CandState cs, const int *slots, int nslots, uint8_t *qtabs,
+                         int *params, hipStream_t s);
+// rows whose lower bound can still pass the slot's threshold -> cand[0..*cand_cnt) (false: M too large for LDS)
+bool launch_adc_prefilter(const uint8_t *qtab, const int *params, int M, const uint8_t *codes, int64_t n,
+                          uint32_t *cand, uint32_t cand_cap, uint32_t *cand_cnt, hipStream_t s);
+void launch_adc_exact_candidates(const float *table, int M, const uint8_t *codes, const uint32_t *cand,
+                                 const uint32_t *cand_cnt, uint32_t cand_cap, const int *params, int slot, CandState cs,
+                                 hipStream_t s);
+void launch_adc_rerank(const float *table, int M, const uint8_t *codes, int64_t n, const int64_t *rows, int64_t nrows,
+                       float *out_dist, float *out_score, hipStream_t s);
 
 // predicate masks (kernels_filter.hip): op = simd.CompareOp value; validity = Arrow LSB bitmap or null
 void launch_match_int64(const int64_t *src, int64_t n, int64_t val, int op, const uint8_t *validity,

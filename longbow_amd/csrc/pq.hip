@@ -7,12 +7,15 @@
 // stride K (internal/pq/adc_table.go:46); they agree only at K = 256.
 #include "../../include/longbow_gpu.h"
 #include "lb_device.h"
+#include "lb_host.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cmath>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <shared_mutex>
 #include <string>
@@ -21,20 +24,14 @@
 using namespace lb;
 
 namespace {
-struct HipErrP {
-    hipError_t e;
-    const char *what;
-};
-#define LBP_HIP(call)                                       \
-    do {                                                    \
-        hipError_t _e = (call);                             \
-        if (_e != hipSuccess) throw HipErrP{_e, #call};     \
-    } while (0)
+using HipErrP = lb::HipErr;
+#define LBP_HIP(call) LB_HIP(call)
 
 uint32_t rd_u32le(const uint8_t *p)
 {
     return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
 }
+struct PqScratch;
 } // namespace
 
 struct lb_gpu_pq {
@@ -44,9 +41,10 @@ struct lb_gpu_pq {
     uint8_t *d_codes = nullptr;
     int64_t n = 0, capacity = 0;
     hipStream_t stream = nullptr;
-    // sample buffers (sampled admission threshold) are pooled: a 3 MB hipMalloc per search costs 0.25 ms
-    std::mutex samp_mu;
-    std::vector<std::pair<uint64_t *, size_t>> samp_free;
+    // per-search scratch (lists, tables, sample and candidate buffers) is pooled on the handle: a search
+    // must not hipMalloc/hipFree (the latter synchronises the device under every concurrent search)
+    std::mutex sc_mu;
+    std::vector<std::unique_ptr<PqScratch>> sc_free;
     mutable std::mutex err_mu;
     std::string last_error;
     void set_error(const char *fmt, ...)
@@ -68,53 +66,120 @@ int pq_fail(lb_gpu_pq *p, const HipErrP &e)
     return e.e == hipErrorOutOfMemory ? LB_ERR_OOM : LB_ERR_HIP;
 }
 
-bool pq_device_ok(int device)
-{
-    int cnt = 0;
-    if (hipGetDeviceCount(&cnt) != hipSuccess) return false;
-    return device >= 0 && device < cnt;
-}
-
+// Geometric growth without a transient second copy of a large code buffer: beyond 1 GiB the buffer grows
+// by at most 25 % + the request, and the copy runs in 256 MiB pieces (the peak is still old + new; a
+// caller that knows the final size avoids it with lb_gpu_pq_reserve).
 void pq_grow(lb_gpu_pq *p, int64_t need)
 {
     if (need <= p->capacity) return;
     int64_t cap = std::max<int64_t>(std::max<int64_t>(need, p->capacity * 2), 4096);
+    if ((size_t)p->capacity * p->M > ((size_t)1 << 30)) cap = std::max<int64_t>(need, p->capacity + p->capacity / 4);
     uint8_t *nc = nullptr;
     LBP_HIP(hipMalloc(&nc, (size_t)cap * p->M));
-    if (p->n > 0) LBP_HIP(hipMemcpy(nc, p->d_codes, (size_t)p->n * p->M, hipMemcpyDeviceToDevice));
+    if (p->n > 0) {
+        hipError_t e = hipMemcpy(nc, p->d_codes, (size_t)p->n * p->M, hipMemcpyDeviceToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(nc);
+            throw HipErrP{e, "hipMemcpy (pq_grow)"};
+        }
+    }
     if (p->d_codes) (void)hipFree(p->d_codes);
     p->d_codes = nc;
     p->capacity = cap;
 }
 
+constexpr uint32_t kCandCap = 65536; // prefilter survivors per query (expected: a few thousand)
+
 struct PqScratch {
+    int device = 0;
+    int nq_cap = 0;
+    uint32_t cap = 0;
+    int M = 0;
     CandState cs{};
-    float *d_tables = nullptr;
-    int *d_slots = nullptr;
-    uint64_t *d_samp = nullptr; // ADC entries of the sampled rows (borrowed from the handle's pool)
+    float *d_tables = nullptr;   // [nq][M*256] f32
+    uint8_t *d_qtabs = nullptr;  // [nq][M*256] u8
+    int *d_params = nullptr;     // [nq][4]
+    uint32_t *d_cand = nullptr;  // [kCandCap] survivors of the query in flight
+    uint32_t *d_cand_cnt = nullptr; // [nq]
+    int *d_slots = nullptr;      // 0..nq-1
+    uint64_t *d_samp = nullptr;  // ADC entries of the sampled rows
     size_t samp_entries = 0;
-    lb_gpu_pq *owner = nullptr;
+    uint32_t *h_flags = nullptr; // pinned
     ~PqScratch()
     {
-        if (d_slots) (void)hipFree(d_slots);
-        if (d_samp && owner) {
-            std::lock_guard<std::mutex> g(owner->samp_mu);
-            if (owner->samp_free.size() < 4) {
-                owner->samp_free.emplace_back(d_samp, samp_entries);
-                d_samp = nullptr;
-            }
-        }
-        if (d_samp) (void)hipFree(d_samp);
+        (void)hipSetDevice(device);
         if (cs.lists) (void)hipFree(cs.lists);
         if (cs.cnt) (void)hipFree(cs.cnt);
         if (cs.tau) (void)hipFree(cs.tau);
         if (cs.flags) (void)hipFree(cs.flags);
         if (d_tables) (void)hipFree(d_tables);
+        if (d_qtabs) (void)hipFree(d_qtabs);
+        if (d_params) (void)hipFree(d_params);
+        if (d_cand) (void)hipFree(d_cand);
+        if (d_cand_cnt) (void)hipFree(d_cand_cnt);
+        if (d_slots) (void)hipFree(d_slots);
+        if (d_samp) (void)hipFree(d_samp);
+        if (h_flags) (void)hipHostFree(h_flags);
     }
 };
+
+std::unique_ptr<PqScratch> acquire_scratch(lb_gpu_pq *p, int nq, uint32_t cap, size_t samp_entries)
+{
+    std::unique_ptr<PqScratch> sc;
+    {
+        std::lock_guard<std::mutex> g(p->sc_mu);
+        for (size_t i = 0; i < p->sc_free.size(); i++)
+            if (p->sc_free[i]->nq_cap >= nq && p->sc_free[i]->cap == cap) {
+                sc = std::move(p->sc_free[i]);
+                p->sc_free.erase(p->sc_free.begin() + (long)i);
+                break;
+            }
+    }
+    if (!sc) {
+        sc = std::make_unique<PqScratch>();
+        sc->device = p->device;
+        sc->nq_cap = std::max(nq, 4);
+        sc->cap = cap;
+        sc->M = p->M;
+        sc->cs.cap = cap;
+        const size_t nqc = (size_t)sc->nq_cap;
+        LBP_HIP(hipMalloc(&sc->cs.lists, nqc * cap * 8));
+        LBP_HIP(hipMalloc(&sc->cs.cnt, nqc * 4));
+        LBP_HIP(hipMalloc(&sc->cs.tau, nqc * 8));
+        LBP_HIP(hipMalloc(&sc->cs.flags, nqc * 4));
+        LBP_HIP(hipMalloc(&sc->d_tables, nqc * p->M * 256 * 4));
+        LBP_HIP(hipMalloc(&sc->d_qtabs, nqc * p->M * 256));
+        LBP_HIP(hipMalloc(&sc->d_params, nqc * 4 * sizeof(int)));
+        LBP_HIP(hipMalloc(&sc->d_cand, (size_t)kCandCap * 4));
+        LBP_HIP(hipMalloc(&sc->d_cand_cnt, nqc * 4));
+        LBP_HIP(hipMalloc(&sc->d_slots, nqc * sizeof(int)));
+        LBP_HIP(hipHostMalloc(&sc->h_flags, nqc * 4, hipHostMallocDefault));
+        std::vector<int> slots(nqc);
+        for (size_t q = 0; q < nqc; q++) slots[q] = (int)q;
+        LBP_HIP(hipMemcpy(sc->d_slots, slots.data(), nqc * sizeof(int), hipMemcpyHostToDevice));
+    }
+    if (sc->samp_entries < samp_entries) {
+        if (sc->d_samp) (void)hipFree(sc->d_samp);
+        sc->d_samp = nullptr;
+        sc->samp_entries = 0;
+        LBP_HIP(hipMalloc(&sc->d_samp, samp_entries * sizeof(uint64_t)));
+        sc->samp_entries = samp_entries;
+    }
+    return sc;
+}
+
+void release_scratch(lb_gpu_pq *p, std::unique_ptr<PqScratch> sc)
+{
+    std::lock_guard<std::mutex> g(p->sc_mu);
+    if (p->sc_free.size() < 4) p->sc_free.push_back(std::move(sc));
+}
+
+std::atomic<int> g_adc_prefilter{1}; // test hook: 0 = exact f32 pass only (both are exact)
 } // namespace
 
 extern "C" {
+
+void lb_debug_set_adc_prefilter(int v) { g_adc_prefilter.store(v); }
 
 lb_gpu_pq *lb_gpu_pq_new(int device, const uint8_t *blob, size_t len, int *out_status)
 {
@@ -126,7 +191,7 @@ lb_gpu_pq *lb_gpu_pq_new(int device, const uint8_t *blob, size_t len, int *out_s
     if (len != 12 + (size_t)M * K * sub * 4) { st(LB_ERR_INVALID_ARG); return nullptr; } // "size mismatch"
     if (K != 256) { st(LB_ERR_UNSUPPORTED); return nullptr; }
     if ((size_t)M * 256 * 4 > 160 * 1024 - 1024) { st(LB_ERR_UNSUPPORTED); return nullptr; } // table must fit LDS
-    if (!pq_device_ok(device)) { st(LB_ERR_NO_DEVICE); return nullptr; }
+    if (!device_ok(device)) { st(LB_ERR_NO_DEVICE); return nullptr; }
     auto *p = new (std::nothrow) lb_gpu_pq();
     if (!p) { st(LB_ERR_OOM); return nullptr; }
     p->device = device; p->dims = (int)dims; p->M = (int)M; p->K = (int)K; p->sub = (int)sub;
@@ -152,10 +217,12 @@ void lb_gpu_pq_free(lb_gpu_pq *p)
         std::unique_lock<std::shared_mutex> g(p->mu);
         (void)hipSetDevice(p->device);
         (void)hipDeviceSynchronize();
+        {
+            std::lock_guard<std::mutex> g2(p->sc_mu);
+            p->sc_free.clear();
+        }
         if (p->d_codebooks) (void)hipFree(p->d_codebooks);
         if (p->d_codes) (void)hipFree(p->d_codes);
-        for (auto &b : p->samp_free) (void)hipFree(b.first);
-        p->samp_free.clear();
         if (p->stream) (void)hipStreamDestroy(p->stream);
     }
     delete p;
@@ -171,6 +238,19 @@ const char *lb_gpu_pq_last_error(const lb_gpu_pq *p)
 int lb_gpu_pq_m(const lb_gpu_pq *p) { return p ? p->M : 0; }
 int lb_gpu_pq_dims(const lb_gpu_pq *p) { return p ? p->dims : 0; }
 int64_t lb_gpu_pq_ntotal(const lb_gpu_pq *p) { return p ? p->n : 0; }
+
+int lb_gpu_pq_reserve(lb_gpu_pq *p, int64_t n_total)
+{
+    if (!p || n_total < 0) return LB_ERR_INVALID_ARG;
+    std::unique_lock<std::shared_mutex> g(p->mu);
+    try {
+        LBP_HIP(hipSetDevice(p->device));
+        pq_grow(p, n_total);
+    } catch (const HipErrP &e) {
+        return pq_fail(p, e);
+    }
+    return LB_OK;
+}
 
 static int add_codes_impl(lb_gpu_pq *p, int64_t n, const uint8_t *codes, bool on_device)
 {
@@ -193,25 +273,135 @@ static int add_codes_impl(lb_gpu_pq *p, int64_t n, const uint8_t *codes, bool on
 int lb_gpu_pq_add_codes(lb_gpu_pq *p, int64_t n, const uint8_t *codes) { return add_codes_impl(p, n, codes, false); }
 int lb_gpu_pq_add_codes_device(lb_gpu_pq *p, int64_t n, const uint8_t *d_codes) { return add_codes_impl(p, n, d_codes, true); }
 
+int lb_gpu_pq_get_codes(lb_gpu_pq *p, int64_t row0, int64_t n, uint8_t *codes)
+{
+    if (!p || row0 < 0 || n < 0 || (n > 0 && !codes)) return LB_ERR_INVALID_ARG;
+    if (n == 0) return LB_OK;
+    std::shared_lock<std::shared_mutex> g(p->mu);
+    if (row0 + n > p->n) { p->set_error("rows [%lld, %lld) outside the %lld stored codes", (long long)row0, (long long)(row0 + n), (long long)p->n); return LB_ERR_INVALID_ARG; }
+    try {
+        LBP_HIP(hipSetDevice(p->device));
+        LBP_HIP(hipMemcpy(codes, p->d_codes + (size_t)row0 * p->M, (size_t)n * p->M, hipMemcpyDeviceToHost));
+    } catch (const HipErrP &e) {
+        return pq_fail(p, e);
+    }
+    return LB_OK;
+}
+
+// ---- Encode / Decode -------------------------------------------------------------------
+int lb_gpu_pq_encode_device(lb_gpu_pq *p, int64_t n, const float *d_vectors, uint8_t *d_codes, void *stream)
+{
+    if (!p || n < 0 || (n > 0 && (!d_vectors || !d_codes))) return LB_ERR_INVALID_ARG;
+    if (n == 0) return LB_OK;
+    std::shared_lock<std::shared_mutex> g(p->mu);
+    try {
+        LBP_HIP(hipSetDevice(p->device));
+        hipStream_t s = stream ? (hipStream_t)stream : p->stream;
+        launch_pq_encode(p->d_codebooks, p->M, p->K, p->sub, d_vectors, n, d_codes, s);
+        LB_LAUNCH_CHECK();
+        LBP_HIP(hipStreamSynchronize(s));
+    } catch (const HipErrP &e) {
+        return pq_fail(p, e);
+    }
+    return LB_OK;
+}
+
+int lb_gpu_pq_encode(lb_gpu_pq *p, int64_t n, const float *vectors, uint8_t *codes)
+{
+    if (!p || n < 0 || (n > 0 && (!vectors || !codes))) return LB_ERR_INVALID_ARG;
+    if (n == 0) return LB_OK;
+    try {
+        LBP_HIP(hipSetDevice(p->device));
+        // in pieces of <= 64 Mi floats so that the staging buffers stay small and reusable
+        const int64_t piece = std::max<int64_t>(1, ((int64_t)64 << 20) / p->dims);
+        Lease dv(p->device, (size_t)std::min(n, piece) * p->dims * 4), dc(p->device, (size_t)std::min(n, piece) * p->M);
+        for (int64_t r0 = 0; r0 < n; r0 += piece) {
+            const int64_t cnt = std::min(piece, n - r0);
+            LBP_HIP(hipMemcpy(dv.p, vectors + (size_t)r0 * p->dims, (size_t)cnt * p->dims * 4, hipMemcpyHostToDevice));
+            const int rc = lb_gpu_pq_encode_device(p, cnt, dv.as<float>(), dc.as<uint8_t>(), nullptr);
+            if (rc != LB_OK) return rc;
+            LBP_HIP(hipMemcpy(codes + (size_t)r0 * p->M, dc.p, (size_t)cnt * p->M, hipMemcpyDeviceToHost));
+        }
+    } catch (const HipErrP &e) {
+        return pq_fail(p, e);
+    }
+    return LB_OK;
+}
+
+int lb_gpu_pq_add_vectors_device(lb_gpu_pq *p, int64_t n, const float *d_vectors)
+{
+    if (!p || n < 0 || (n > 0 && !d_vectors)) return LB_ERR_INVALID_ARG;
+    if (n == 0) return LB_OK;
+    std::unique_lock<std::shared_mutex> g(p->mu);
+    if (p->n + n > (int64_t)0xffffffffll) { p->set_error("more than 2^32 codes per device"); return LB_ERR_UNSUPPORTED; }
+    try {
+        LBP_HIP(hipSetDevice(p->device));
+        pq_grow(p, p->n + n);
+        launch_pq_encode(p->d_codebooks, p->M, p->K, p->sub, d_vectors, n, p->d_codes + (size_t)p->n * p->M, p->stream);
+        LB_LAUNCH_CHECK();
+        LBP_HIP(hipStreamSynchronize(p->stream));
+        p->n += n;
+    } catch (const HipErrP &e) {
+        return pq_fail(p, e);
+    }
+    return LB_OK;
+}
+
+int lb_gpu_pq_decode_device(lb_gpu_pq *p, int64_t n, const uint8_t *d_codes, float *d_vectors, void *stream)
+{
+    if (!p || n < 0 || (n > 0 && (!d_vectors || !d_codes))) return LB_ERR_INVALID_ARG;
+    if (n == 0) return LB_OK;
+    std::shared_lock<std::shared_mutex> g(p->mu);
+    try {
+        LBP_HIP(hipSetDevice(p->device));
+        hipStream_t s = stream ? (hipStream_t)stream : p->stream;
+        launch_pq_decode(p->d_codebooks, p->M, p->K, p->sub, d_codes, n, d_vectors, s);
+        LB_LAUNCH_CHECK();
+        LBP_HIP(hipStreamSynchronize(s));
+    } catch (const HipErrP &e) {
+        return pq_fail(p, e);
+    }
+    return LB_OK;
+}
+
+int lb_gpu_pq_decode(lb_gpu_pq *p, int64_t n, const uint8_t *codes, float *vectors)
+{
+    if (!p || n < 0 || (n > 0 && (!vectors || !codes))) return LB_ERR_INVALID_ARG;
+    if (n == 0) return LB_OK;
+    try {
+        LBP_HIP(hipSetDevice(p->device));
+        const int64_t piece = std::max<int64_t>(1, ((int64_t)64 << 20) / p->dims);
+        Lease dv(p->device, (size_t)std::min(n, piece) * p->dims * 4), dc(p->device, (size_t)std::min(n, piece) * p->M);
+        for (int64_t r0 = 0; r0 < n; r0 += piece) {
+            const int64_t cnt = std::min(piece, n - r0);
+            LBP_HIP(hipMemcpy(dc.p, codes + (size_t)r0 * p->M, (size_t)cnt * p->M, hipMemcpyHostToDevice));
+            const int rc = lb_gpu_pq_decode_device(p, cnt, dc.as<uint8_t>(), dv.as<float>(), nullptr);
+            if (rc != LB_OK) return rc;
+            LBP_HIP(hipMemcpy(vectors + (size_t)r0 * p->dims, dv.p, (size_t)cnt * p->dims * 4, hipMemcpyDeviceToHost));
+        }
+    } catch (const HipErrP &e) {
+        return pq_fail(p, e);
+    }
+    return LB_OK;
+}
+
+// ---- ADC table / batch ----------------------------------------------------------------
 int lb_gpu_pq_build_adc_table(lb_gpu_pq *p, const float *query, float *table)
 {
     if (!p || !query || !table) return LB_ERR_INVALID_ARG;
     std::shared_lock<std::shared_mutex> g(p->mu);
-    float *d_q = nullptr, *d_t = nullptr;
-    int rc = LB_OK;
     try {
         LBP_HIP(hipSetDevice(p->device));
-        LBP_HIP(hipMalloc(&d_q, (size_t)p->dims * 4));
-        LBP_HIP(hipMalloc(&d_t, (size_t)p->M * p->K * 4));
-        LBP_HIP(hipMemcpy(d_q, query, (size_t)p->dims * 4, hipMemcpyHostToDevice));
-        launch_build_adc_table(p->d_codebooks, p->M, p->K, p->sub, d_q, 1, d_t, nullptr);
-        LBP_HIP(hipMemcpy(table, d_t, (size_t)p->M * p->K * 4, hipMemcpyDeviceToHost));
+        Lease dq(p->device, (size_t)p->dims * 4), dt(p->device, (size_t)p->M * p->K * 4);
+        LBP_HIP(hipMemcpyAsync(dq.p, query, (size_t)p->dims * 4, hipMemcpyHostToDevice, p->stream));
+        launch_build_adc_table(p->d_codebooks, p->M, p->K, p->sub, dq.as<float>(), 1, dt.as<float>(), p->stream);
+        LB_LAUNCH_CHECK();
+        LBP_HIP(hipMemcpyAsync(table, dt.p, (size_t)p->M * p->K * 4, hipMemcpyDeviceToHost, p->stream));
+        LBP_HIP(hipStreamSynchronize(p->stream));
     } catch (const HipErrP &e) {
-        rc = pq_fail(p, e);
+        return pq_fail(p, e);
     }
-    if (d_q) (void)hipFree(d_q);
-    if (d_t) (void)hipFree(d_t);
-    return rc;
+    return LB_OK;
 }
 
 int lb_gpu_pq_adc_distance_batch(lb_gpu_pq *p, const float *table, int64_t row0, int64_t n, float *results)
@@ -221,55 +411,86 @@ int lb_gpu_pq_adc_distance_batch(lb_gpu_pq *p, const float *table, int64_t row0,
     if (!table || !results) return LB_ERR_INVALID_ARG;
     std::shared_lock<std::shared_mutex> g(p->mu);
     if (row0 + n > p->n) { p->set_error("flatCodes buffer too small"); return LB_ERR_INVALID_ARG; } // adc_table.go:61-63
-    float *d_t = nullptr, *d_r = nullptr;
-    int rc = LB_OK;
     try {
         LBP_HIP(hipSetDevice(p->device));
-        LBP_HIP(hipMalloc(&d_t, (size_t)p->M * 256 * 4));
-        LBP_HIP(hipMalloc(&d_r, (size_t)n * 4));
-        LBP_HIP(hipMemcpy(d_t, table, (size_t)p->M * 256 * 4, hipMemcpyHostToDevice));
+        Lease dt(p->device, (size_t)p->M * 256 * 4), dr(p->device, (size_t)n * 4);
+        LBP_HIP(hipMemcpyAsync(dt.p, table, (size_t)p->M * 256 * 4, hipMemcpyHostToDevice, p->stream));
         CandState cs{};
-        launch_adc_scan(d_t, p->M, p->d_codes, row0, row0 + n, 0, nullptr, cs, false, d_r, row0, nullptr);
-        LBP_HIP(hipMemcpy(results, d_r, (size_t)n * 4, hipMemcpyDeviceToHost));
+        launch_adc_scan(dt.as<float>(), p->M, p->d_codes, row0, row0 + n, 0, nullptr, cs, false, dr.as<float>(), row0,
+                        p->stream);
+        LB_LAUNCH_CHECK();
+        LBP_HIP(hipMemcpyAsync(results, dr.p, (size_t)n * 4, hipMemcpyDeviceToHost, p->stream));
+        LBP_HIP(hipStreamSynchronize(p->stream));
     } catch (const HipErrP &e) {
-        rc = pq_fail(p, e);
+        return pq_fail(p, e);
     }
-    if (d_t) (void)hipFree(d_t);
-    if (d_r) (void)hipFree(d_r);
-    return rc;
+    return LB_OK;
 }
 
+// ---- candidate re-rank (processChunkInternal, PQ branch) ----------------------------------
+int lb_gpu_pq_rerank_device(lb_gpu_pq *p, const float *d_query, const int64_t *d_rows, int64_t n, float *d_dist,
+                            float *d_score, void *stream)
+{
+    if (!p || n < 0) return LB_ERR_INVALID_ARG;
+    if (n == 0) return LB_OK;
+    if (!d_query || !d_rows || !d_dist) return LB_ERR_INVALID_ARG;
+    std::shared_lock<std::shared_mutex> g(p->mu);
+    try {
+        LBP_HIP(hipSetDevice(p->device));
+        hipStream_t s = stream ? (hipStream_t)stream : p->stream;
+        Lease dt(p->device, (size_t)p->M * 256 * 4);
+        launch_build_adc_table(p->d_codebooks, p->M, p->K, p->sub, d_query, 1, dt.as<float>(), s);
+        launch_adc_rerank(dt.as<float>(), p->M, p->d_codes, p->n, d_rows, n, d_dist, d_score, s);
+        LB_LAUNCH_CHECK();
+        LBP_HIP(hipStreamSynchronize(s));
+    } catch (const HipErrP &e) {
+        return pq_fail(p, e);
+    }
+    return LB_OK;
+}
+
+int lb_gpu_pq_rerank(lb_gpu_pq *p, const float *query, const int64_t *rows, int64_t n, float *dist, float *score)
+{
+    if (!p || n < 0) return LB_ERR_INVALID_ARG;
+    if (n == 0) return LB_OK;
+    if (!query || !rows || !dist) return LB_ERR_INVALID_ARG;
+    try {
+        LBP_HIP(hipSetDevice(p->device));
+        Lease dq(p->device, (size_t)p->dims * 4), drw(p->device, (size_t)n * 8), dd(p->device, (size_t)n * 4),
+            ds(p->device, (size_t)n * 4);
+        LBP_HIP(hipMemcpy(dq.p, query, (size_t)p->dims * 4, hipMemcpyHostToDevice));
+        LBP_HIP(hipMemcpy(drw.p, rows, (size_t)n * 8, hipMemcpyHostToDevice));
+        const int rc = lb_gpu_pq_rerank_device(p, dq.as<float>(), drw.as<int64_t>(), n, dd.as<float>(), ds.as<float>(), nullptr);
+        if (rc != LB_OK) return rc;
+        LBP_HIP(hipMemcpy(dist, dd.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+        if (score) LBP_HIP(hipMemcpy(score, ds.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    } catch (const HipErrP &e) {
+        return pq_fail(p, e);
+    }
+    return LB_OK;
+}
+
+// ---- search ----------------------------------------------------------------------------
 int lb_gpu_pq_search_device(lb_gpu_pq *p, int64_t nq, const float *d_queries, int k, float *d_dist,
                             int64_t *d_labels, void *stream)
 {
     if (!p || nq < 0 || k <= 0 || (nq > 0 && (!d_queries || !d_dist || !d_labels))) return LB_ERR_INVALID_ARG;
     if (nq == 0) return LB_OK;
     if (k > 4096) { p->set_error("k=%d exceeds the supported maximum 4096", k); return LB_ERR_UNSUPPORTED; }
+    if (nq > 65536) { p->set_error("nq=%lld exceeds 65536 queries per call", (long long)nq); return LB_ERR_UNSUPPORTED; }
     std::shared_lock<std::shared_mutex> g(p->mu);
-    PqScratch sc;
+    std::unique_ptr<PqScratch> scp;
     try {
         LBP_HIP(hipSetDevice(p->device));
         hipStream_t s = stream ? (hipStream_t)stream : p->stream;
         const uint32_t cap = std::max<uint32_t>(8192u, 4u * next_pow2_host((uint32_t)k));
-        sc.cs.cap = cap;
         const int nqi = (int)nq;
-        LBP_HIP(hipMalloc(&sc.cs.lists, (size_t)nqi * cap * 8));
-        LBP_HIP(hipMalloc(&sc.cs.cnt, (size_t)nqi * 4));
-        LBP_HIP(hipMalloc(&sc.cs.tau, (size_t)nqi * 8));
-        LBP_HIP(hipMalloc(&sc.cs.flags, (size_t)nqi * 4));
-        LBP_HIP(hipMalloc(&sc.d_tables, (size_t)nqi * p->M * 256 * 4));
-        launch_build_adc_table(p->d_codebooks, p->M, p->K, p->sub, d_queries, nqi, sc.d_tables, s);
-        // device list 0..nq-1 so one slot can be addressed as a 1-element selection
-        std::vector<int> slots(nqi);
-        for (int q = 0; q < nqi; q++) slots[q] = q;
-        LBP_HIP(hipMalloc(&sc.d_slots, (size_t)nqi * sizeof(int)));
-        LBP_HIP(hipMemcpyAsync(sc.d_slots, slots.data(), (size_t)nqi * sizeof(int), hipMemcpyHostToDevice, s));
         // Sampled admission threshold (same reasoning as index.hip: sample_plan): one row in `stride` is scored
         // exactly, the m-th best sample entry becomes tau, and the codes are walked once.  About m*stride rows
         // pass (2048 at 100M rows); fewer than k or more than the list holds is detected by the select and
         // the query is redone by the bootstrap schedule.  Two-level m-th minimum: the sample (390k entries at
         // 100M rows) is larger than one list.
-        static const int sample_on = [] { const char *e = getenv("LB_SAMPLE_TAU"); return e ? atoi(e) : 1; }();
+        static const int sample_on = lb_tunable("LB_SAMPLE_TAU", 1);
         uint32_t samp_count = 0;
         int samp_m = 0;
         if (sample_on && p->n >= 65536 && p->n < ((int64_t)1 << 32)) {
@@ -280,24 +501,14 @@ int lb_gpu_pq_search_device(lb_gpu_pq *p, int64_t nq, const float *d_queries, in
             if (m <= 32 && loose <= (double)(cap - (uint32_t)k) && cnt <= (int64_t)8192 * (8192 / m)) {
                 samp_count = (uint32_t)cnt;
                 samp_m = m;
-                sc.owner = p;
-                {
-                    std::lock_guard<std::mutex> g2(p->samp_mu);
-                    for (size_t i = 0; i < p->samp_free.size(); i++)
-                        if (p->samp_free[i].second >= samp_count) {
-                            sc.d_samp = p->samp_free[i].first;
-                            sc.samp_entries = p->samp_free[i].second;
-                            p->samp_free.erase(p->samp_free.begin() + (long)i);
-                            break;
-                        }
-                }
-                if (!sc.d_samp) {
-                    LBP_HIP(hipMalloc(&sc.d_samp, (size_t)samp_count * sizeof(uint64_t)));
-                    sc.samp_entries = samp_count;
-                }
             }
         }
-        // mode 0: sampled threshold, 1: bootstrap chunks, 2: chunks that cannot overflow the list
+        scp = acquire_scratch(p, nqi, cap, samp_count);
+        PqScratch &sc = *scp;
+        launch_build_adc_table(p->d_codebooks, p->M, p->K, p->sub, d_queries, nqi, sc.d_tables, s);
+        const bool prefilter = samp_count != 0 && g_adc_prefilter.load() != 0;
+        if (prefilter) LBP_HIP(hipMemsetAsync(sc.d_cand_cnt, 0, (size_t)nqi * 4, s));
+        // mode 0: sampled threshold (+ byte-table prefilter), 1: bootstrap chunks, 2: chunks that cannot overflow
         auto scan_query = [&](int q, int mode) {
             const float *tab = sc.d_tables + (size_t)q * p->M * 256;
             launch_init_cand(sc.cs, sc.d_slots + q, 1, s);
@@ -306,7 +517,20 @@ int lb_gpu_pq_search_device(lb_gpu_pq *p, int64_t nq, const float *d_queries, in
                 const uint32_t groups = launch_sample_topm(sc.d_samp, samp_count, samp_m, sc.cs, q, s);
                 if (groups) {
                     launch_sample_tau(sc.cs, sc.d_slots + q, 1, groups * (uint32_t)samp_m, samp_m, false, s);
-                    launch_adc_scan(tab, p->M, p->d_codes, 0, p->n, q, nullptr, sc.cs, false, nullptr, 0, s);
+                    const int *skip = nullptr;
+                    if (prefilter) {
+                        // rows whose byte-table lower bound cannot pass tau are dropped; the survivors are scored
+                        // exactly.  params.ok == 0 (decided on the device): neither kernel does anything and the
+                        // exact full pass below runs instead.
+                        const int *prm = sc.d_params + q * 4;
+                        launch_adc_quantise(sc.d_tables, p->M, sc.cs, sc.d_slots + q, 1, sc.d_qtabs, sc.d_params, s);
+                        launch_adc_prefilter(sc.d_qtabs + (size_t)q * p->M * 256, prm, p->M, p->d_codes, p->n, sc.d_cand,
+                                             kCandCap, sc.d_cand_cnt + q, s);
+                        launch_adc_exact_candidates(tab, p->M, p->d_codes, sc.d_cand, sc.d_cand_cnt + q, kCandCap, prm, q,
+                                                    sc.cs, s);
+                        skip = prm;
+                    }
+                    launch_adc_scan(tab, p->M, p->d_codes, 0, p->n, q, nullptr, sc.cs, false, nullptr, 0, s, skip);
                     launch_select(sc.cs, sc.d_slots + q, 1, k, 0u, s, false, (uint32_t)std::min<int64_t>(k, p->n));
                     return;
                 }
@@ -323,22 +547,23 @@ int lb_gpu_pq_search_device(lb_gpu_pq *p, int64_t nq, const float *d_queries, in
             }
         };
         for (int q = 0; q < nqi; q++) scan_query(q, 0);
-        std::vector<uint32_t> flags(nqi);
         auto read_flags = [&]() {
-            LBP_HIP(hipMemcpyAsync(flags.data(), sc.cs.flags, (size_t)nqi * 4, hipMemcpyDeviceToHost, s));
+            LBP_HIP(hipMemcpyAsync(sc.h_flags, sc.cs.flags, (size_t)nqi * 4, hipMemcpyDeviceToHost, s));
             LBP_HIP(hipStreamSynchronize(s));
         };
         read_flags();
         if (samp_count) {
             bool any = false;
             for (int q = 0; q < nqi; q++)
-                if (flags[q] & (1u | 4u)) { scan_query(q, 1); any = true; } // the sampled threshold missed
+                if (sc.h_flags[q] & (1u | 4u)) { scan_query(q, 1); any = true; } // the sampled threshold missed
             if (any) read_flags();
         }
         for (int q = 0; q < nqi; q++)
-            if (flags[q] & 1u) scan_query(q, 2); // chunks that cannot overflow the list
+            if (sc.h_flags[q] & 1u) scan_query(q, 2); // chunks that cannot overflow the list
         launch_emit_lists(sc.cs, nullptr, nqi, k, nullptr, d_dist, d_labels, nullptr, s);
+        LB_LAUNCH_CHECK();
         LBP_HIP(hipStreamSynchronize(s));
+        release_scratch(p, std::move(scp));
     } catch (const HipErrP &e) {
         return pq_fail(p, e);
     }
@@ -349,26 +574,19 @@ int lb_gpu_pq_search(lb_gpu_pq *p, int64_t nq, const float *queries, int k, floa
 {
     if (!p || nq < 0 || k <= 0 || (nq > 0 && (!queries || !dist || !labels))) return LB_ERR_INVALID_ARG;
     if (nq == 0) return LB_OK;
-    float *d_q = nullptr, *d_d = nullptr;
-    int64_t *d_l = nullptr;
     int rc = LB_OK;
     try {
         LBP_HIP(hipSetDevice(p->device));
-        LBP_HIP(hipMalloc(&d_q, (size_t)nq * p->dims * 4));
-        LBP_HIP(hipMalloc(&d_d, (size_t)nq * k * 4));
-        LBP_HIP(hipMalloc(&d_l, (size_t)nq * k * 8));
-        LBP_HIP(hipMemcpy(d_q, queries, (size_t)nq * p->dims * 4, hipMemcpyHostToDevice));
-        rc = lb_gpu_pq_search_device(p, nq, d_q, k, d_d, d_l, nullptr);
+        Lease dq(p->device, (size_t)nq * p->dims * 4), dd(p->device, (size_t)nq * k * 4), dl(p->device, (size_t)nq * k * 8);
+        LBP_HIP(hipMemcpy(dq.p, queries, (size_t)nq * p->dims * 4, hipMemcpyHostToDevice));
+        rc = lb_gpu_pq_search_device(p, nq, dq.as<float>(), k, dd.as<float>(), dl.as<int64_t>(), nullptr);
         if (rc == LB_OK) {
-            LBP_HIP(hipMemcpy(dist, d_d, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
-            LBP_HIP(hipMemcpy(labels, d_l, (size_t)nq * k * 8, hipMemcpyDeviceToHost));
+            LBP_HIP(hipMemcpy(dist, dd.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
+            LBP_HIP(hipMemcpy(labels, dl.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost));
         }
     } catch (const HipErrP &e) {
         rc = pq_fail(p, e);
     }
-    if (d_q) (void)hipFree(d_q);
-    if (d_d) (void)hipFree(d_d);
-    if (d_l) (void)hipFree(d_l);
     return rc;
 }
 

@@ -89,6 +89,27 @@ class Index:
                                                  labels.ctypes.data), self._h)
         return labels, dist
 
+    def Rerank(self, query, rows, order=Order.Unroll4, want_score=True):
+        """The distance step of processChunkInternal (internal/store/parallel_search.go:274-364): distances of
+        the resident rows `rows` (positions) to `query` + Score = 1/(1+d).  The reference runs
+        simd.EuclideanDistanceBatchFlat here (4-accumulator order), hence the default order."""
+        self._live()
+        query = np.ascontiguousarray(query, np.float32).reshape(-1)
+        if query.size != self.dim:
+            raise ValueError(f"query vector dimension {query.size} does not match index dimension {self.dim}")
+        rows = np.ascontiguousarray(rows, np.int64).reshape(-1)
+        dist = np.empty(rows.size, np.float32)
+        score = np.empty(rows.size, np.float32) if want_score else None
+        _lib.check(self._lib.lb_gpu_index_rerank(self._h, query.ctypes.data, rows.ctypes.data, rows.size,
+                                                 -1 if order is None else int(Order(order)), dist.ctypes.data,
+                                                 score.ctypes.data if want_score else None), self._h)
+        return (dist, score) if want_score else dist
+
+    def rerank_device(self, d_query, d_rows, n, d_dist, d_score=None, order=Order.Unroll4, stream=None):
+        self._live()
+        _lib.check(self._lib.lb_gpu_index_rerank_device(self._h, d_query, d_rows, n, -1 if order is None else int(Order(order)),
+                                                        d_dist, d_score, stream), self._h)
+
     def add_device(self, n, d_vectors, d_ids=None):
         self._live()
         _lib.check(self._lib.lb_gpu_index_add_device(self._h, n, d_vectors, d_ids), self._h)

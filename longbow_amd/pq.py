@@ -1,8 +1,9 @@
 """Mirror of internal/pq's query-side interface (the ADC path), computed by HIP kernels.
 
 PQEncoder.{BuildADCTable, ADCDistanceBatch, Serialize/Deserialize blob}
-(internal/pq/adc_table.go:15-72, persistence.go:9-73).  Training (k-means) and Encode are
-offline steps in the reference and stay out of the GPU path: codebooks and codes are inputs.
+(internal/pq/adc_table.go:15-72, persistence.go:9-73) and Encode / Decode (encoder.go:76-158).
+Training (k-means, unseeded) is an offline step in the reference and stays out of the GPU path:
+codebooks are an input.
 """
 import ctypes as C
 import struct
@@ -50,6 +51,58 @@ class PQEncoder:
     @property
     def ntotal(self):
         return int(self._lib.lb_gpu_pq_ntotal(self._h))
+
+    def reserve(self, n_total):
+        _lib.check(self._lib.lb_gpu_pq_reserve(self._h, n_total), self._h, pq=True)
+
+    def get_codes(self, row0=0, n=None):
+        """stored codes rows [row0, row0+n) -> uint8 [n, M]"""
+        n = self.ntotal - row0 if n is None else n
+        out = np.empty((n, self.M), np.uint8)
+        _lib.check(self._lib.lb_gpu_pq_get_codes(self._h, row0, n, out.ctypes.data), self._h, pq=True)
+        return out
+
+    def Encode(self, vector):
+        """PQEncoder.Encode (encoder.go:76-89): one vector -> M bytes; a 2-D array encodes row by row."""
+        v = np.ascontiguousarray(vector, np.float32)
+        single = v.ndim == 1
+        v = v.reshape(-1, v.shape[-1])
+        if v.shape[1] != self.Dims:
+            raise ValueError("vector dimension mismatch")  # encoder.go:77-79
+        codes = np.empty((v.shape[0], self.M), np.uint8)
+        _lib.check(self._lib.lb_gpu_pq_encode(self._h, v.shape[0], v.ctypes.data, codes.ctypes.data), self._h, pq=True)
+        return codes[0] if single else codes
+
+    def Decode(self, codes):
+        """PQEncoder.Decode (encoder.go:139-158)"""
+        c = np.ascontiguousarray(codes, np.uint8)
+        single = c.ndim == 1
+        c = c.reshape(-1, c.shape[-1])
+        if c.shape[1] != self.M:
+            raise ValueError("code length mismatch")  # encoder.go:140-142
+        out = np.empty((c.shape[0], self.Dims), np.float32)
+        _lib.check(self._lib.lb_gpu_pq_decode(self._h, c.shape[0], c.ctypes.data, out.ctypes.data), self._h, pq=True)
+        return out[0] if single else out
+
+    def encode_device(self, n, d_vectors, d_codes, stream=None):
+        _lib.check(self._lib.lb_gpu_pq_encode_device(self._h, n, d_vectors, d_codes, stream), self._h, pq=True)
+
+    def add_vectors_device(self, n, d_vectors):
+        """encode n device-resident vectors and append their codes"""
+        _lib.check(self._lib.lb_gpu_pq_add_vectors_device(self._h, n, d_vectors), self._h, pq=True)
+
+    def Rerank(self, query, rows):
+        """processChunkInternal's PQ branch (parallel_search.go:292-345): ADC distance of the stored code rows
+        + Score = 1/(1+d)"""
+        query = np.ascontiguousarray(query, np.float32).reshape(-1)
+        if query.size != self.Dims:
+            raise ValueError("query dimension mismatch")
+        rows = np.ascontiguousarray(rows, np.int64).reshape(-1)
+        dist = np.empty(rows.size, np.float32)
+        score = np.empty(rows.size, np.float32)
+        _lib.check(self._lib.lb_gpu_pq_rerank(self._h, query.ctypes.data, rows.ctypes.data, rows.size, dist.ctypes.data,
+                                              score.ctypes.data), self._h, pq=True)
+        return dist, score
 
     def BuildADCTable(self, query):
         query = np.ascontiguousarray(query, np.float32).reshape(-1)

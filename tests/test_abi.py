@@ -74,3 +74,16 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 for tok in banned:
                     assert tok not in text, (f, tok)
+
+
+def test_dimension_cap_is_reported_not_silently_wrong():
+    """dims above LB_MAX_DIM would need more LDS than a workgroup may declare: rejected at construction
+    (argument checks come before the device check, so this runs on a CPU box too)"""
+    from longbow_amd import _lib
+    lib = _lib.load()
+    st = ctypes.c_int(0)
+    assert not lib.lb_gpu_index_new(0, 8193, 0, ctypes.byref(st)) and st.value == 6
+    assert lib.lb_simd_distance_batch_flat(0, 0, 0, 1, 1, 1, 8193, 1) in (3, 6)  # no device, or unsupported
+    # RRF list and merge size limits are argument errors
+    assert lib.lb_gpu_rrf_fuse(0, 1, 8000, 1, 200, 1, 60, 10, 1, 1) == 1
+    assert lib.lb_gpu_merge_topk_device(0, 9, 1, 2048, 1, 1, 1, 1, None) == 1

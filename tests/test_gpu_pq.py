@@ -109,3 +109,118 @@ def test_blob_validation():
         pq.PQEncoder(struct.pack("<III", 32, 4, 256) + bytes(100))
     with pytest.raises(_lib.LongbowGPUError):
         pq.PQEncoder(struct.pack("<III", 32, 4, 16) + bytes(4 * 16 * 8 * 4))  # K != 256
+
+
+@pytest.mark.parametrize("dims,M", [(768, 96), (64, 16), (96, 8), (60, 12), (35, 5), (32, 32)])
+def test_encode_decode_match_the_oracle(oracle, dims, M):
+    """pq.Encode (encoder.go:76-136 -> simd.FindNearestCentroid, simd.go:305-326: sqrt'd 4-accumulator
+    distances, FIRST strict minimum) and pq.Decode (encoder.go:139-158), SubDim 8 / 4 / 12 / 5 / 7 / 1"""
+    gpu_or_skip()
+    from longbow_amd import pq
+    rng = np.random.default_rng(dims * 3 + M)
+    sub = dims // M
+    cb = rng.random((M, 256, sub), dtype=F)
+    enc = pq.PQEncoder(pq.serialize_codebooks(cb))
+    n = 700
+    V = rng.random((n, dims), dtype=F)
+    codes = enc.Encode(V)
+    assert codes.shape == (n, M) and codes.dtype == np.uint8
+    want = np.stack([oracle.pq_encode(cb, V[i]) for i in range(n)])
+    assert np.array_equal(codes, want)
+    assert np.array_equal(enc.Encode(V[3]), want[3])
+    dec = enc.Decode(codes[:50])
+    assert np.array_equal(dec, np.stack([oracle.pq_decode(cb, want[i]) for i in range(50)]))
+    assert np.array_equal(enc.Decode(codes[7]), dec[7])
+    with pytest.raises(ValueError):
+        enc.Encode(V[0][:-1])     # vector dimension mismatch
+    with pytest.raises(ValueError):
+        enc.Decode(codes[0][:-1])  # code length mismatch
+    enc.Close()
+
+
+def test_encode_ties_first_centroid_wins(oracle):
+    """duplicate and near-duplicate centroids on a coarse grid: exact ties and sums that differ in the last
+    bits but round to the same float32 sqrt -- the reference keeps the FIRST minimum of the sqrt'd values"""
+    gpu_or_skip()
+    from longbow_amd import pq
+    rng = np.random.default_rng(1234)
+    M, sub = 6, 8
+    base = (rng.integers(0, 9, (M, 64, sub)) / 8.0).astype(F)
+    cb = np.concatenate([base, base, base + F(2.0 ** -20), base[:, ::-1]], axis=1)  # 256 centroids, many ties
+    assert cb.shape == (M, 256, sub)
+    enc = pq.PQEncoder(pq.serialize_codebooks(cb))
+    V = (rng.integers(0, 17, (3000, M * sub)) / 16.0).astype(F)
+    codes = enc.Encode(V)
+    want = np.stack([oracle.pq_encode(cb, v) for v in V])
+    assert np.array_equal(codes, want)
+    assert (codes < 64).mean() > 0.5  # the first copy wins the exact ties
+    enc.Close()
+
+
+def test_search_on_encoded_vectors_and_prefilter_equivalence(oracle):
+    """codes produced by Encode on the device (add_vectors_device), searched with and without the byte-table
+    prefilter: identical results, equal to the oracle's ADC over the oracle's own codes"""
+    gpu_or_skip()
+    torch = pytest.importorskip("torch")
+    import ctypes as C
+    from longbow_amd import _lib, pq
+    lib = _lib.load()
+    rng = np.random.default_rng(77)
+    M, dims, n, k = 96, 768, 120_000, 100
+    cb = rng.random((M, 256, dims // M), dtype=F)
+    enc = pq.PQEncoder(pq.serialize_codebooks(cb))
+    V = torch.empty((n, dims), device="cuda")
+    assert lib.lb_gpu_fill_uniform_device(0, V.data_ptr(), V.numel(), 99, 0, None) == 0
+    enc.add_vectors_device(n, V.data_ptr())
+    assert enc.ntotal == n
+    Vh = V.cpu().numpy()
+    sub = rng.integers(0, n, 200)
+    codes_sub = np.stack([oracle.pq_encode(cb, Vh[i]) for i in sub])
+    codes_all = enc.Encode(Vh)  # host-pointer entry, in pieces
+    assert np.array_equal(codes_all[sub], codes_sub)
+    assert np.array_equal(enc.get_codes(), codes_all) and np.array_equal(enc.get_codes(5000, 10), codes_all[5000:5010])
+    Q = rng.random((3, dims), dtype=F)
+    lib.lb_debug_set_adc_prefilter.argtypes = [C.c_int]
+    try:
+        lib.lb_debug_set_adc_prefilter(1)
+        lab1, dist1 = enc.Search(Q, k)
+        lib.lb_debug_set_adc_prefilter(0)
+        lab0, dist0 = enc.Search(Q, k)
+    finally:
+        lib.lb_debug_set_adc_prefilter(1)
+    assert np.array_equal(lab0, lab1) and np.array_equal(dist0, dist1)
+    for b in range(3):
+        d = oracle.adc_batch(oracle.build_adc_table(cb, Q[b]), codes_all)
+        oi, od, cnt = oracle.topk_canonical(d, k)
+        assert np.array_equal(lab1[b], oi) and np.array_equal(dist1[b], od)
+    enc.Close()
+
+
+def test_prefilter_degenerate_tables(oracle):
+    """constant sub-tables (scale 0), heavy duplication (candidate buffer overflow -> exact path) and a
+    non-finite query (prefilter refused on the device) all return the exact kernel's results"""
+    gpu_or_skip()
+    from longbow_amd import pq
+    rng = np.random.default_rng(5)
+    M, dims, n, k = 16, 64, 200_000, 10
+    cb = np.zeros((M, 256, dims // M), F)          # every centroid identical: all ADC distances tie
+    enc = pq.PQEncoder(pq.serialize_codebooks(cb))
+    codes = rng.integers(0, 256, (n, M), dtype=np.uint8)
+    enc.add_codes(codes)
+    q = rng.random(dims, dtype=F)
+    lab, dist = enc.Search(q, k)
+    assert np.array_equal(lab[0], np.arange(k)) and len(np.unique(dist)) == 1
+    enc.Close()
+    cb = rng.random((M, 256, dims // M), dtype=F)
+    enc = pq.PQEncoder(pq.serialize_codebooks(cb))
+    enc.add_codes(codes)
+    qbad = q.copy()
+    qbad[3] = np.inf
+    lab, dist = enc.Search(np.stack([q, qbad]), k)
+    d = oracle.adc_batch(oracle.build_adc_table(cb, q), codes)
+    oi, od, cnt = oracle.topk_canonical(d, k)
+    assert np.array_equal(lab[0], oi) and np.array_equal(dist[0], od)
+    d = oracle.adc_batch(oracle.build_adc_table(cb, qbad), codes)
+    oi, od, cnt = oracle.topk_canonical(d, k)
+    assert np.array_equal(lab[1], oi)
+    enc.Close()

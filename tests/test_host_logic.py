@@ -2,6 +2,7 @@
 import struct
 
 import numpy as np
+import pytest
 
 from longbow_amd import pq as lpq
 from longbow_amd.sharded import RingSharder, fnv1a32_bytes, partition_rows
@@ -61,7 +62,10 @@ def test_sample_plan_invariants():
     import ctypes as C
     import math
     from longbow_amd import _lib
-    lib = _lib.load()
+    try:
+        lib = _lib.load()
+    except (RuntimeError, OSError) as e:  # CPU-only checkout without the built library / ROCm runtime
+        pytest.skip(f"liblongbow_gpu.so not loadable here: {e}")
     lib.lb_debug_sample_plan.argtypes = [C.c_longlong, C.c_int, C.c_uint, C.c_uint, C.POINTER(C.c_longlong)]
     lib.lb_debug_sample_plan.restype = None
     out = (C.c_longlong * 4)()
