@@ -16,10 +16,12 @@ namespace lb {
 constexpr int ADC_THREADS = 1024;
 
 __global__ __launch_bounds__(256) void build_adc_table_kernel(const float *codebooks, int M, int K, int sub,
-                                                              const float *Q, float *tables)
+                                                              const float *Q, float *tables, float *minrng)
 {
     const int q = blockIdx.y;
     const int i = blockIdx.x;
+    float mn = __builtin_huge_valf(), mx = -__builtin_huge_valf();
+    int bad = 0;
     const float *qs = Q + ((int64_t)q * M + i) * sub;
     const float *cb = codebooks + (int64_t)i * K * sub;
     for (int j = threadIdx.x; j < K; j += blockDim.x) {
@@ -42,14 +44,38 @@ __global__ __launch_bounds__(256) void build_adc_table_kernel(const float *codeb
         r = r + s2;
         r = r + s3;
         tables[((int64_t)q * M + i) * K + j] = r;
+        mn = fminf(mn, r);
+        mx = fmaxf(mx, r);
+        if (!(r >= 0.f) || r > 3.0e38f) bad = 1;
+    }
+    if (minrng) { // subtable minimum / range for the byte-table prefilter (kernels_pq2.hip)
+        __shared__ float s_mn[4], s_mx[4];
+        __shared__ int s_bad[4];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mn = fminf(mn, __shfl_xor(mn, off));
+            mx = fmaxf(mx, __shfl_xor(mx, off));
+            bad |= __shfl_xor(bad, off);
+        }
+        if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6] = mn; s_mx[threadIdx.x >> 6] = mx; s_bad[threadIdx.x >> 6] = bad; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float a = fminf(fminf(s_mn[0], s_mn[1]), fminf(s_mn[2], s_mn[3]));
+            const float b = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
+            float *o = minrng + ((int64_t)q * M + i) * 4;
+            o[0] = a;
+            o[1] = b - a;
+            o[2] = (s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3]) ? 1.0f : 0.0f;
+            o[3] = 0.f;
+        }
     }
 }
 
 void launch_build_adc_table(const float *codebooks, int M, int K, int sub, const float *Q, int nq,
-                            float *tables, hipStream_t s)
+                            float *tables, hipStream_t s, float *minrng)
 {
     if (nq <= 0) return;
-    hipLaunchKernelGGL(build_adc_table_kernel, dim3(M, nq), dim3(256), 0, s, codebooks, M, K, sub, Q, tables);
+    hipLaunchKernelGGL(build_adc_table_kernel, dim3(M, nq), dim3(256), 0, s, codebooks, M, K, sub, Q, tables, minrng);
 }
 
 struct AdcArgs {

@@ -23,6 +23,8 @@
 
 namespace lb {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 // ---------------------------------------------------------------------------
 // Encode
 // ---------------------------------------------------------------------------
@@ -194,65 +196,59 @@ void launch_pq_decode(const float *codebooks, int M, int K, int sub, const uint8
 // ---------------------------------------------------------------------------
 // Two-stage ADC search
 // ---------------------------------------------------------------------------
-// One workgroup per query slot: quantise the query's f32 table to the byte table and derive the integer
-// admission bound from the slot's threshold.  params[slot] = {s_tau (int), ok, -, -}; ok = 0 when the
-// prefilter cannot be used for this query (non-finite table entries, no threshold yet): the caller then
-// runs the exact kernel.
+// Quantise one query's f32 table to the byte table (one workgroup per subtable) and derive the integer
+// admission bound from the slot's threshold.  minrng[j] = {min_j, max_j - min_j, bad} comes from the table
+// builder (build_adc_table_kernel reduces each subtable as it writes it).  params = {s_tau, ok}; ok = 0 when
+// the prefilter cannot be used for this query (non-finite table entries, no threshold yet): the caller's
+// exact kernel then runs instead.
 //   U    = nextafter(tau_dist)^2                  (every admitted row has f32 sum <= U)
 //   real sum <= f32 sum * (1 + 2*gamma), gamma = 1.05 * M * 2^-24   (sequential f32 sum of M terms >= 0)
-//   real sum >= base + s * S - eps                 (floor quantisation; eps covers the f64 roundings)
+//   real sum >= base + s * S - eps                 (floor quantisation; eps covers the roundings)
 //   => admitted rows satisfy S <= (U*(1+2 gamma) - base) / s + 2
-__global__ __launch_bounds__(256) void adc_quantise_kernel(const float *tables, int M, const CandState cs, const int *slots,
-                                                           uint8_t *qtabs, int *params)
+__global__ __launch_bounds__(256) void adc_quantise_kernel(const float *table, const float *minrng, int M, const uint64_t *tau_p,
+                                                           uint8_t *qt, int *params)
 {
-    __shared__ float s_min[256], s_rng[256];
+    __shared__ float s_inv, s_scale, s_mn;
     __shared__ double s_base;
-    __shared__ float s_scale;
     __shared__ int s_bad;
-    const int slot = slots ? slots[blockIdx.x] : (int)blockIdx.x;
-    const float *tab = tables + (size_t)slot * M * 256;
-    uint8_t *qt = qtabs + (size_t)slot * M * 256;
-    const int tid = threadIdx.x;
-    if (tid == 0) s_bad = 0;
-    __syncthreads();
-    // per-subtable min / max (one wave-free loop per thread; M <= 256)
-    if (tid < M) {
-        float mn = __builtin_huge_valf(), mx = -__builtin_huge_valf();
-        int bad = 0;
-        for (int c = 0; c < 256; c++) {
-            const float t = tab[tid * 256 + c];
-            if (!(t >= 0.f) || t > 3.0e38f) bad = 1; // NaN, negative or infinite entries: no prefilter
-            mn = t < mn ? t : mn;
-            mx = t > mx ? t : mx;
-        }
-        s_min[tid] = mn;
-        s_rng[tid] = mx - mn;
-        if (bad) atomicOr(&s_bad, 1);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        double base = 0.0;
+    const int j = blockIdx.x, tid = threadIdx.x;
+    if (tid < 64) { // one wave: max range, sum of minima, any bad entry
         float rmax = 0.f;
-        for (int j = 0; j < M; j++) {
-            base += (double)s_min[j];
-            rmax = s_rng[j] > rmax ? s_rng[j] : rmax;
+        double base = 0.0;
+        int bad = 0;
+        for (int i = tid; i < M; i += 64) {
+            rmax = fmaxf(rmax, minrng[i * 4 + 1]);
+            base += (double)minrng[i * 4 + 0];
+            bad |= minrng[i * 4 + 2] != 0.f ? 1 : 0;
         }
-        s_base = base;
-        s_scale = rmax > 0.f ? rmax / 255.0f : 1.0f;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            rmax = fmaxf(rmax, __shfl_xor(rmax, off));
+            base += __shfl_xor(base, off);
+            bad |= __shfl_xor(bad, off);
+        }
+        if (tid == 0) {
+            s_scale = rmax > 0.f ? rmax / 255.0f : 1.0f;
+            s_inv = rmax > 0.f ? 255.0f / rmax : 0.f;
+            s_base = base;
+            s_bad = bad;
+            s_mn = minrng[j * 4 + 0];
+        }
     }
     __syncthreads();
-    const double sc = (double)s_scale;
-    for (int i = tid; i < M * 256; i += 256) {
-        const int j = i >> 8;
-        const double rel = ((double)tab[i] - (double)s_min[j]) / sc;
-        int q = (int)floor(rel);
-        q = q < 0 ? 0 : (q > 255 ? 255 : q);
-        qt[i] = (uint8_t)q;
+    // q = floor((t - min) / s) in f32: the roundings can lift q by one only when (t - min)/s is within
+    // ~5e-5 of an integer, i.e. s*q exceeds t - min by < 5e-5 s per entry, < 0.01 s over M <= 155 entries:
+    // covered by the +2 units of slack in s_tau below.
+    {
+        const float r = (table[j * 256 + tid] - s_mn) * s_inv;
+        int qi = (int)floorf(r);
+        qi = qi < 0 ? 0 : (qi > 255 ? 255 : qi);
+        qt[j * 256 + tid] = (uint8_t)qi;
     }
-    if (tid == 0) {
+    if (j == 0 && tid == 0) {
         int ok = s_bad ? 0 : 1;
         int s_tau = 0;
-        const uint64_t tau = cs.tau[slot];
+        const uint64_t tau = *tau_p;
         if (tau == kEntryMax) {
             ok = 0; // no threshold: every row would be admitted
         } else {
@@ -263,22 +259,21 @@ __global__ __launch_bounds__(256) void adc_quantise_kernel(const float *tables, 
                 const float tn = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, td + 0.0f) + 1u); // next f32 above td (td >= 0, finite)
                 const double U = (double)tn * (double)tn;
                 const double gamma = 1.05 * (double)M * 5.9604644775390625e-8;
-                const double lim = (U * (1.0 + 2.0 * gamma) - s_base) / sc + 2.0;
+                const double lim = (U * (1.0 + 2.0 * gamma) - s_base) / (double)s_scale + 2.0;
                 if (lim < 0.0) s_tau = -1;                 // nothing can pass
                 else if (lim > 2.0e9) ok = 0;
                 else s_tau = (int)lim;
             }
         }
-        params[slot * 4 + 0] = s_tau;
-        params[slot * 4 + 1] = ok;
+        params[0] = s_tau;
+        params[1] = ok;
     }
 }
 
-void launch_adc_quantise(const float *tables, int M, CandState cs, const int *slots, int nslots, uint8_t *qtabs,
-                         int *params, hipStream_t s)
+void launch_adc_quantise(const float *table, const float *minrng, int M, const uint64_t *tau, uint8_t *qtab, int *params,
+                         hipStream_t s)
 {
-    if (nslots <= 0) return;
-    hipLaunchKernelGGL(adc_quantise_kernel, dim3(nslots), dim3(256), 0, s, tables, M, cs, slots, qtabs, params);
+    hipLaunchKernelGGL(adc_quantise_kernel, dim3(M), dim3(256), 0, s, table, minrng, M, tau, qtab, params);
 }
 
 struct AdcPreArgs {
@@ -295,10 +290,8 @@ struct AdcPreArgs {
 // a private LDS slot with M/16 direct-to-LDS loads of 1 KiB, reads its own row back, re-issues the DMA for
 // its next tile and then does the M byte gathers.  The byte table is 24 KB at M = 96, which leaves room
 // for 16 waves per CU (96 KB of code bytes in flight) instead of 8.
-constexpr int PRE_WAVES = 16;
-
-template <int MCH>
-__global__ __launch_bounds__(PRE_WAVES * 64) void adc_prefilter_kernel(AdcPreArgs a)
+template <int MCH, bool QW, int WAVES, int SLOTS, bool HYB = false>
+__global__ __launch_bounds__(WAVES * 64) void adc_prefilter_kernel(AdcPreArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_u8[];
     constexpr int M = MCH * 16;
@@ -311,36 +304,59 @@ __global__ __launch_bounds__(PRE_WAVES * 64) void adc_prefilter_kernel(AdcPreArg
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(a.qtab);
         uint4 *dst = reinterpret_cast<uint4 *>(tab);
-        for (int i = tid; i < M * 16; i += PRE_WAVES * 64) dst[i] = src[i];
+        for (int i = tid; i < M * 16; i += WAVES * 64) dst[i] = src[i];
     }
     __syncthreads();
-    unsigned char *stage = stage_all + wave * (64 * M);
+    unsigned char *stage = stage_all + wave * (SLOTS * 64 * M);
     const int64_t ntiles = (a.n + 63) / 64;
-    const int64_t tstride = (int64_t)gridDim.x * PRE_WAVES;
+    const int64_t tstride = (int64_t)gridDim.x * WAVES;
     const unsigned char *last16 = a.codes + a.n * (int64_t)M - 16;
 
-    auto issue = [&](int64_t tile) {
+    auto issue = [&](int64_t tile, int slot) {
         const unsigned char *src0 = a.codes + tile * 64 * (int64_t)M + lane * 16;
 #pragma unroll
         for (int i = 0; i < MCH; i++) {
             const unsigned char *src = src0 + i * 1024;
             if (src > last16) src = last16; // tail tile: stay inside the buffer (rows past the end are discarded)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(stage + i * 1024), 16, 0,
-                                             2 /* nt: the codes stream through once */);
+                                             (__attribute__((address_space(3))) void *)(stage + slot * (64 * M) + i * 1024), 16,
+                                             0, 2 /* nt: the codes stream through once */);
         }
     };
 
-    int64_t tile = (int64_t)blockIdx.x * PRE_WAVES + wave;
-    if (tile < ntiles) issue(tile);
-    for (; tile < ntiles; tile += tstride) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int64_t tile = (int64_t)blockIdx.x * WAVES + wave;
+    if (tile < ntiles) issue(tile, 0);
+    if (SLOTS == 2 && tile + tstride < ntiles) issue(tile + tstride, 1);
+    int slot = 0;
+    for (; tile < ntiles; tile += tstride, slot = (SLOTS == 2) ? (slot ^ 1) : 0) {
+        // two slots: the older of the (up to) two tiles in flight has landed once at most MCH DMAs remain
+        if (SLOTS == 2 && tile + tstride < ntiles) {
+            if (MCH == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else if (MCH == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (MCH == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else if (MCH == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (MCH == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const unsigned char *sl = stage + slot * (64 * M);
         uint4 c[MCH];
 #pragma unroll
-        for (int i = 0; i < MCH; i++) c[i] = *reinterpret_cast<const uint4 *>(stage + lane * M + i * 16);
+        for (int i = 0; i < MCH; i++) c[i] = *reinterpret_cast<const uint4 *>(sl + lane * M + i * 16);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // slot fully read before it is refilled
-        if (tile + tstride < ntiles) issue(tile + tstride);
+        if (tile + SLOTS * tstride < ntiles) issue(tile + SLOTS * tstride, slot);
 
+        // Gather.  A byte gather (ds_read_u8) spreads a subtable's 64 dwords over the 32 banks of the 4-byte
+        // LDS path, two per bank: random codes collide 2-way on every instruction (measured:
+        // SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE, 4.2 LDS cycles per instruction).  The QW variant
+        // reads the qword holding the entry instead (ds_read_b64 is banked 64 wide: the subtable's 32 qwords
+        // own one bank pair each and lanes that meet on a pair read the SAME qword, a broadcast) and picks
+        // the byte with v_perm_b32: conflict-free (2.35 cycles per instruction) but 3.3x the VALU
+        // instructions, which costs more than the conflicts did (2.03 vs 1.78 ms at 100M x 96); HYB does that
+        // for every third sub-quantiser only (1.78 vs 1.80 ms: inside the noise, not the default).  Also
+        // tried and slower: two DMA slots per wave (11 x 2: 1.87 ms), 16 gathers issued ahead of their adds
+        // (1.91 ms), a third of the gathers through the vector cache instead of LDS (1.87-2.7 ms).
         uint32_t S = 0;
 #pragma unroll
         for (int g = 0; g < MCH; g++) {
@@ -348,8 +364,16 @@ __global__ __launch_bounds__(PRE_WAVES * 64) void adc_prefilter_kernel(AdcPreArg
 #pragma unroll
             for (int t = 0; t < 4; t++)
 #pragma unroll
-                for (int b = 0; b < 4; b++)
-                    S += tab[(g * 16 + t * 4 + b) * 256 + ((w[t] >> (8 * b)) & 0xffu)];
+                for (int b = 0; b < 4; b++) {
+                    const int j = g * 16 + t * 4 + b;
+                    const uint32_t code = (w[t] >> (8 * b)) & 0xffu;
+                    if (QW || (HYB && (j % 3) == 0)) {
+                        const uint2 qw = *reinterpret_cast<const uint2 *>(tab + j * 256 + (code & 0xf8u));
+                        S += __builtin_amdgcn_perm(qw.y, qw.x, code & 7u) & 0xffu;
+                    } else {
+                        S += tab[j * 256 + code];
+                    }
+                }
         }
         const int64_t row = tile * 64 + lane;
         if (row < a.n && (int)S <= s_tau) {
@@ -378,6 +402,20 @@ __global__ __launch_bounds__(1024) void adc_prefilter_generic_kernel(AdcPreArgs 
     }
 }
 
+template <int MCH, bool QW, int WAVES, int SLOTS, bool HYB = false>
+static bool try_prefilter(const AdcPreArgs &a, hipStream_t s)
+{
+    const size_t shmem = (size_t)(MCH * 16) * 256 + (size_t)WAVES * SLOTS * 64 * (MCH * 16);
+    if (shmem > 160 * 1024) return false;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(adc_prefilter_kernel<MCH, QW, WAVES, SLOTS, HYB>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    const int64_t ntiles = (a.n + 63) / 64;
+    int64_t blocks = (ntiles + WAVES - 1) / WAVES;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL((adc_prefilter_kernel<MCH, QW, WAVES, SLOTS, HYB>), dim3((unsigned)blocks), dim3(WAVES * 64), shmem, s, a);
+    return true;
+}
+
 bool launch_adc_prefilter(const uint8_t *qtab, const int *params, int M, const uint8_t *codes, int64_t n,
                           uint32_t *cand, uint32_t cand_cap, uint32_t *cand_cnt, hipStream_t s)
 {
@@ -385,30 +423,33 @@ bool launch_adc_prefilter(const uint8_t *qtab, const int *params, int M, const u
     AdcPreArgs a{qtab, params, codes, n, cand, cand_cap, cand_cnt};
     const bool vec = (M % 16 == 0) && ((reinterpret_cast<uintptr_t>(codes) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(qtab) & 15) == 0);
-    const int64_t ntiles = (n + 63) / 64;
-    int64_t blocks = (ntiles + PRE_WAVES - 1) / PRE_WAVES;
-    if (blocks > 256) blocks = 256;
-#define LB_PRE(MCH)                                                                                                 \
-    do {                                                                                                            \
-        const size_t shmem = (size_t)(MCH * 16) * 256 + (size_t)PRE_WAVES * 64 * (MCH * 16);                        \
-        if (shmem > 160 * 1024) break;                                                                              \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(adc_prefilter_kernel<MCH>),                       \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                         \
-        hipLaunchKernelGGL((adc_prefilter_kernel<MCH>), dim3((unsigned)blocks), dim3(PRE_WAVES * 64), shmem, s, a); \
-        return true;                                                                                                \
-    } while (0)
+    // A/B (diagnostic build): 0 = 16 waves x 1 slot, byte gathers (default); 1 = 11 x 2; 2 = 8 x 2; 3 = 12 x 1;
+    // 4 = 16 x 1 with qword gathers; 5 = 16 x 1, every third gather a qword gather
+    static const int cfg = lb_tunable("LB_ADC_PRE_CFG", 0);
     if (vec && n >= 4096) {
+        bool ok = false;
         switch (M / 16) {
-        case 1: LB_PRE(1); break;
-        case 2: LB_PRE(2); break;
-        case 3: LB_PRE(3); break;
-        case 4: LB_PRE(4); break;
-        case 6: LB_PRE(6); break;
-        case 8: LB_PRE(8); break;
+        case 1: ok = try_prefilter<1, false, 16, 1>(a, s); break;
+        case 2: ok = try_prefilter<2, false, 16, 1>(a, s); break;
+        case 3: ok = try_prefilter<3, false, 16, 1>(a, s); break;
+        case 4: ok = try_prefilter<4, false, 16, 1>(a, s); break;
+        case 6:
+#ifdef LB_DIAG
+            if (cfg == 1) ok = try_prefilter<6, false, 11, 2>(a, s);
+            else if (cfg == 2) ok = try_prefilter<6, false, 8, 2>(a, s);
+            else if (cfg == 3) ok = try_prefilter<6, false, 12, 1>(a, s);
+            else if (cfg == 4) ok = try_prefilter<6, true, 16, 1>(a, s);
+            else if (cfg == 5) ok = try_prefilter<6, false, 16, 1, true>(a, s);
+            else
+#endif
+                ok = try_prefilter<6, false, 16, 1>(a, s);
+            break;
+        case 8: ok = try_prefilter<8, false, 10, 1>(a, s); break;
         default: break;
         }
+        (void)cfg;
+        if (ok) return true;
     }
-#undef LB_PRE
     const size_t shmem = (size_t)M * 256;
     if (shmem > 160 * 1024) return false;
     if (shmem > 64 * 1024)
@@ -445,11 +486,26 @@ __global__ __launch_bounds__(256) void adc_exact_candidates_kernel(AdcExactArgs 
         return;
     }
     const uint64_t tau = a.cs.tau[a.slot];
+    const bool vec = (a.M % 16 == 0) && ((reinterpret_cast<uintptr_t>(a.codes) & 15) == 0);
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < raw; i += gridDim.x * 256u) {
         const uint32_t row = a.cand[i];
         const uint8_t *c = a.codes + (int64_t)row * a.M;
         float sum = 0.f;
-        for (int j = 0; j < a.M; j++) sum = sum + a.table[j * 256 + c[j]];
+        if (vec) {
+            // the row's code bytes first (M/16 independent 16-B loads), then 16 independent table reads per
+            // group; only the adds are ordered
+            for (int g = 0; g < a.M / 16; g++) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(c + g * 16);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                float t[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) t[u] = a.table[(g * 16 + u) * 256 + ((w[u >> 2] >> (8 * (u & 3))) & 0xffu)];
+#pragma unroll
+                for (int u = 0; u < 16; u++) sum = sum + t[u];
+            }
+        } else {
+            for (int j = 0; j < a.M; j++) sum = sum + a.table[j * 256 + c[j]];
+        }
         const uint64_t ent = pack_entry((float)sqrt((double)sum), row);
         if (ent < tau) {
             const uint32_t pos = atomicAdd(&a.cs.cnt[a.slot], 1u);
@@ -463,7 +519,7 @@ void launch_adc_exact_candidates(const float *table, int M, const uint8_t *codes
                                  hipStream_t s)
 {
     AdcExactArgs a{table, M, codes, cand, cand_cnt, cand_cap, params, slot, cs};
-    hipLaunchKernelGGL(adc_exact_candidates_kernel, dim3(64), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(adc_exact_candidates_kernel, dim3(256), dim3(256), 0, s, a);
 }
 
 // processChunkInternal's PQ branch (internal/store/parallel_search.go:292-345): ADC distance of the

@@ -194,8 +194,9 @@ void launch_fill_uniform(float *dst, int64_t n, uint64_t seed, int64_t offset, h
 void launch_fill_codes(uint8_t *dst, int64_t n, uint64_t seed, int64_t offset, hipStream_t s);
 
 // PQ
+// minrng (nullable): [nq][M][4] = {min, max - min, 1.0 if the subtable holds a NaN / negative / infinite entry, 0}
 void launch_build_adc_table(const float *codebooks, int M, int K, int sub, const float *Q, int nq,
-                            float *tables, hipStream_t s);
+                            float *tables, hipStream_t s, float *minrng = nullptr);
 // one query per launch: `table` is that query's [M*256] table; entries go to cs slot `slot`,
 // or (all_out != nullptr) every distance is written to all_out[row - out_base].
 // skip_if_ok (nullable): {s_tau, ok} of the byte-table prefilter; the launch returns at once when ok != 0
@@ -215,9 +216,9 @@ void launch_pq_encode(const float *codebooks, int M, int K, int sub, const float
                       hipStream_t s);
 void launch_pq_decode(const float *codebooks, int M, int K, int sub, const uint8_t *codes, int64_t n, float *out,
                       hipStream_t s);
-// byte table + integer admission bound per query slot: params[slot*4] = {s_tau, ok, -, -}
-void launch_adc_quantise(const float *tables, int M, CandState cs, const int *slots, int nslots, uint8_t *qtabs,
-                         int *params, hipStream_t s);
+// byte table + integer admission bound of one query: params = {s_tau, ok}; minrng from launch_build_adc_table
+void launch_adc_quantise(const float *table, const float *minrng, int M, const uint64_t *tau, uint8_t *qtab, int *params,
+                         hipStream_t s);
 // rows whose lower bound can still pass the slot's threshold -> cand[0..*cand_cnt) (false: M too large for LDS)
 bool launch_adc_prefilter(const uint8_t *qtab, const int *params, int M, const uint8_t *codes, int64_t n,
                           uint32_t *cand, uint32_t cand_cap, uint32_t *cand_cnt, hipStream_t s);

@@ -98,6 +98,7 @@ struct PqScratch {
     CandState cs{};
     float *d_tables = nullptr;   // [nq][M*256] f32
     uint8_t *d_qtabs = nullptr;  // [nq][M*256] u8
+    float *d_minrng = nullptr;   // [nq][M][4]: subtable minimum, range, bad flag
     int *d_params = nullptr;     // [nq][4]
     uint32_t *d_cand = nullptr;  // [kCandCap] survivors of the query in flight
     uint32_t *d_cand_cnt = nullptr; // [nq]
@@ -114,6 +115,7 @@ struct PqScratch {
         if (cs.flags) (void)hipFree(cs.flags);
         if (d_tables) (void)hipFree(d_tables);
         if (d_qtabs) (void)hipFree(d_qtabs);
+        if (d_minrng) (void)hipFree(d_minrng);
         if (d_params) (void)hipFree(d_params);
         if (d_cand) (void)hipFree(d_cand);
         if (d_cand_cnt) (void)hipFree(d_cand_cnt);
@@ -149,6 +151,7 @@ std::unique_ptr<PqScratch> acquire_scratch(lb_gpu_pq *p, int nq, uint32_t cap, s
         LBP_HIP(hipMalloc(&sc->cs.flags, nqc * 4));
         LBP_HIP(hipMalloc(&sc->d_tables, nqc * p->M * 256 * 4));
         LBP_HIP(hipMalloc(&sc->d_qtabs, nqc * p->M * 256));
+        LBP_HIP(hipMalloc(&sc->d_minrng, nqc * p->M * 4 * sizeof(float)));
         LBP_HIP(hipMalloc(&sc->d_params, nqc * 4 * sizeof(int)));
         LBP_HIP(hipMalloc(&sc->d_cand, (size_t)kCandCap * 4));
         LBP_HIP(hipMalloc(&sc->d_cand_cnt, nqc * 4));
@@ -483,68 +486,77 @@ int lb_gpu_pq_search_device(lb_gpu_pq *p, int64_t nq, const float *d_queries, in
     try {
         LBP_HIP(hipSetDevice(p->device));
         hipStream_t s = stream ? (hipStream_t)stream : p->stream;
-        const uint32_t cap = std::max<uint32_t>(8192u, 4u * next_pow2_host((uint32_t)k));
         const int nqi = (int)nq;
         // Sampled admission threshold (same reasoning as index.hip: sample_plan): one row in `stride` is scored
         // exactly, the m-th best sample entry becomes tau, and the codes are walked once.  About m*stride rows
-        // pass (2048 at 100M rows); fewer than k or more than the list holds is detected by the select and
-        // the query is redone by the bootstrap schedule.  Two-level m-th minimum: the sample (390k entries at
-        // 100M rows) is larger than one list.
+        // pass (4096 at stride 512); fewer than k or more than the list holds is detected by the select and
+        // the query is redone by the bootstrap schedule.  Two-level m-th minimum: the sample (195k entries at
+        // 100M rows) is larger than one list.  Stride 512 with a 16384-entry list (mean + 5 sigma = 11.3k
+        // admitted rows) instead of stride 256 / 8192 halves the sampling pass (49 -> 25 us at 100M rows).
         static const int sample_on = lb_tunable("LB_SAMPLE_TAU", 1);
         uint32_t samp_count = 0;
         int samp_m = 0;
+        uint32_t cap = std::max<uint32_t>(8192u, 4u * next_pow2_host((uint32_t)k));
         if (sample_on && p->n >= 65536 && p->n < ((int64_t)1 << 32)) {
-            const int64_t cnt = std::max<int64_t>(8192, (p->n + 255) / 256);
+            const uint32_t cap_s = std::max<uint32_t>(16384u, cap);
+            const int64_t stride = p->n >= ((int64_t)8192 * 512) ? 512 : 256;
+            const int64_t cnt = std::max<int64_t>(8192, (p->n + stride - 1) / stride);
             const double lambda = (double)k * (double)cnt / (double)p->n;
             const int m = std::max(8, (int)std::ceil(lambda + 5.0 * std::sqrt(lambda) + 4.0));
             const double loose = (double)m * ((double)p->n / (double)cnt) * (1.0 + 5.0 / std::sqrt((double)m));
-            if (m <= 32 && loose <= (double)(cap - (uint32_t)k) && cnt <= (int64_t)8192 * (8192 / m)) {
+            if (m <= 32 && loose <= (double)(cap_s - (uint32_t)k) && cnt <= (int64_t)8192 * (8192 / m)) {
                 samp_count = (uint32_t)cnt;
                 samp_m = m;
+                cap = cap_s;
             }
         }
         scp = acquire_scratch(p, nqi, cap, samp_count);
         PqScratch &sc = *scp;
-        launch_build_adc_table(p->d_codebooks, p->M, p->K, p->sub, d_queries, nqi, sc.d_tables, s);
         const bool prefilter = samp_count != 0 && g_adc_prefilter.load() != 0;
+        launch_build_adc_table(p->d_codebooks, p->M, p->K, p->sub, d_queries, nqi, sc.d_tables, s, prefilter ? sc.d_minrng : nullptr);
+        LBP_HIP(hipMemsetAsync(sc.cs.flags, 0, (size_t)nqi * 4, s));
         if (prefilter) LBP_HIP(hipMemsetAsync(sc.d_cand_cnt, 0, (size_t)nqi * 4, s));
+        const EmitArgs em{k, nullptr, d_dist, d_labels, nullptr};
         // mode 0: sampled threshold (+ byte-table prefilter), 1: bootstrap chunks, 2: chunks that cannot overflow
         auto scan_query = [&](int q, int mode) {
             const float *tab = sc.d_tables + (size_t)q * p->M * 256;
-            launch_init_cand(sc.cs, sc.d_slots + q, 1, s);
             if (mode == 0 && samp_count) {
                 launch_adc_sample(tab, p->M, p->d_codes, p->n, samp_count, sc.d_samp, s);
                 const uint32_t groups = launch_sample_topm(sc.d_samp, samp_count, samp_m, sc.cs, q, s);
                 if (groups) {
-                    launch_sample_tau(sc.cs, sc.d_slots + q, 1, groups * (uint32_t)samp_m, samp_m, false, s);
+                    launch_sample_tau(sc.cs, sc.d_slots + q, 1, groups * (uint32_t)samp_m, samp_m, false, s); // sets tau, cnt = 0
                     const int *skip = nullptr;
                     if (prefilter) {
                         // rows whose byte-table lower bound cannot pass tau are dropped; the survivors are scored
                         // exactly.  params.ok == 0 (decided on the device): neither kernel does anything and the
                         // exact full pass below runs instead.
-                        const int *prm = sc.d_params + q * 4;
-                        launch_adc_quantise(sc.d_tables, p->M, sc.cs, sc.d_slots + q, 1, sc.d_qtabs, sc.d_params, s);
-                        launch_adc_prefilter(sc.d_qtabs + (size_t)q * p->M * 256, prm, p->M, p->d_codes, p->n, sc.d_cand,
-                                             kCandCap, sc.d_cand_cnt + q, s);
+                        int *prm = sc.d_params + q * 4;
+                        uint8_t *qtab = sc.d_qtabs + (size_t)q * p->M * 256;
+                        launch_adc_quantise(tab, sc.d_minrng + (size_t)q * p->M * 4, p->M, sc.cs.tau + q, qtab, prm, s);
+                        launch_adc_prefilter(qtab, prm, p->M, p->d_codes, p->n, sc.d_cand, kCandCap, sc.d_cand_cnt + q, s);
                         launch_adc_exact_candidates(tab, p->M, p->d_codes, sc.d_cand, sc.d_cand_cnt + q, kCandCap, prm, q,
                                                     sc.cs, s);
                         skip = prm;
                     }
                     launch_adc_scan(tab, p->M, p->d_codes, 0, p->n, q, nullptr, sc.cs, false, nullptr, 0, s, skip);
-                    launch_select(sc.cs, sc.d_slots + q, 1, k, 0u, s, false, (uint32_t)std::min<int64_t>(k, p->n));
+                    // the search's last select also writes the k results (redone queries overwrite them below)
+                    launch_select(sc.cs, sc.d_slots + q, 1, k, 0u, s, false, (uint32_t)std::min<int64_t>(k, p->n), &em);
                     return;
                 }
             }
+            launch_init_cand(sc.cs, sc.d_slots + q, 1, s);
             int64_t pos = 0;
             int step = 0;
             while (pos < p->n) {
                 const int64_t end = chunk_end_host(step, pos, p->n, k, cap, mode == 2, /*big_boot=*/true);
                 const bool boot = step == 0;
                 launch_adc_scan(tab, p->M, p->d_codes, pos, end, q, nullptr, sc.cs, boot, nullptr, 0, s);
-                launch_select(sc.cs, sc.d_slots + q, 1, k, boot ? (uint32_t)(end - pos) : 0u, s);
+                launch_select(sc.cs, sc.d_slots + q, 1, k, boot ? (uint32_t)(end - pos) : 0u, s, false, 0u,
+                              end >= p->n ? &em : nullptr);
                 pos = end;
                 step++;
             }
+            if (p->n == 0) launch_emit_lists(sc.cs, sc.d_slots + q, 1, k, nullptr, d_dist, d_labels, nullptr, s);
         };
         for (int q = 0; q < nqi; q++) scan_query(q, 0);
         auto read_flags = [&]() {
@@ -560,7 +572,6 @@ int lb_gpu_pq_search_device(lb_gpu_pq *p, int64_t nq, const float *d_queries, in
         }
         for (int q = 0; q < nqi; q++)
             if (sc.h_flags[q] & 1u) scan_query(q, 2); // chunks that cannot overflow the list
-        launch_emit_lists(sc.cs, nullptr, nqi, k, nullptr, d_dist, d_labels, nullptr, s);
         LB_LAUNCH_CHECK();
         LBP_HIP(hipStreamSynchronize(s));
         release_scratch(p, std::move(scp));
