@@ -537,8 +537,8 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     ProfScope whole(w, s, prof, 4);
 
     // Path selection (measured at 1M x 768 on MI355X, tools/bench_sweep.py): <= 4 queries exact scan
-    // (0.65-0.77 ms); 5..384 queries narrow MFMA tile (0.78 ms at 5-8, 0.87 ms at 32, 3.7 ms at 256);
-    // beyond that the 128-query tile.
+    // (0.50-0.55 ms); 5..384 queries narrow MFMA tiles on the split-bf16 contraction (0.59 ms at 8, 0.62 at 32,
+    // 0.66 at 64, 1.1 at 128, 1.95 at 256); beyond that the 128-query f32 tile.
     const bool narrow_ok = h->dim % 32 == 0 && ((reinterpret_cast<uintptr_t>(d_q) & 15) == 0);
     static const int narrow_min = lb_tunable("LB_NARROW_MINQ", 5);
     static const int narrow_max = lb_tunable("LB_NARROW_MAXQ", 384);
@@ -580,25 +580,29 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         // 3D/16 MFMA accumulations + <=16-term block sums, plus the dropped lo*lo / residual terms
         gamma = 1.05f * ((float)(3 * h->dim / 16 + 24) * u24 + 3.0f * 3.8146973e-6f);
     }
-    // Tile choice by padded work (measured at 1M x 768: one 32-query tile pass 0.43 ms, one 128-query tile
-    // pass 1.49 ms; beyond ~10 query tiles the narrow kernel degrades): e.g. 128 and 256 queries take the
-    // wide tile, 160-192 and 320 the narrow one.
-    // Costs per corpus pass in ms at 1M x 768 (only their ratios matter): 32-query tile 0.43, 64-query tile
-    // 0.80 (MFMA-bound: 0.63 ms of f32 MFMA per pass), 128-query tile 1.49.
+    // Tile choice by padded work.  The 32- and 64-query tiles run the contraction as 3 x bf16 MFMA on operands
+    // split in registers (kernels_gemm_narrow.hip, SPLIT): both are HBM streams (one corpus pass each), so a
+    // batch takes ceil(nq / 64) passes of the 64-query tile or one pass of the 32-query tile; the 128-query
+    // f32 tile (1.49 ms per pass at 1M x 768, MFMA-bound) takes over where its padded cost is lower.
+    // Costs in ms per corpus pass at 1M x 768 (only their ratios matter).
     static const int force64 = lb_tunable("LB_NARROW_TILE64", -1);
-    const double kCost64 = 0.80; // measured: 64 queries 0.97 ms, 192 queries 2.48 ms per search
+    static const bool nsplit_on = lb_tunable("LB_NARROW_SPLIT", 1) != 0;
+    static const double kCost32 = lb_tunable("LB_COST32_US", nsplit_on ? 500 : 430) * 1e-3;
+    static const double kCost64 = lb_tunable("LB_COST64_US", nsplit_on ? 560 : 800) * 1e-3;
     const int tiles_n = (nq + 31) / 32, tiles_64 = (nq + 63) / 64, tiles_w = (nq + 127) / 128;
-    const double c32 = (nq <= 32 || tiles_n <= 10) ? 0.43 * tiles_n : 1e9, c64 = kCost64 * tiles_64, cw = 1.49 * tiles_w;
+    const double c32 = (nq <= 32 || tiles_n <= 10) ? kCost32 * tiles_n : 1e9, c64 = kCost64 * tiles_64, cw = 1.49 * tiles_w;
     const bool narrow_allowed = !split && narrow_ok && nq <= narrow_max;
     bool use_narrow = narrow_allowed && (nq <= 32 || std::min(c32, c64) < cw);
     bool tile64 = use_narrow && nq > 32 && c64 <= c32;
     if (force64 == 0) { tile64 = false; use_narrow = narrow_allowed && (nq <= 32 || c32 < cw); }
     if (force64 == 1 && narrow_allowed && nq > 32) { use_narrow = true; tile64 = true; }
+    const bool nsplit = use_narrow && nsplit_on;
+    if (nsplit) gamma = 1.05f * ((float)(3 * h->dim / 16 + 24) * u24 + 3.0f * 3.8146973e-6f); // as the split image mode
     auto candidates = [&](int64_t b, int64_t e, const uint32_t *rowmap, bool boot) {
         ProfScope p(w, s, prof, 0);
         if (use_narrow)
             launch_gemm_filter_narrow(metric, gx, h->d_norm2, h->d_rnorm, b, e, h->dim, gq, nq, mask, rowmap,
-                                      w->cs, boot, s, tile64);
+                                      w->cs, boot, s, tile64, nsplit);
         else
             launch_gemm_filter(metric, gx, h->d_norm2, h->d_rnorm, b, e, h->dim, gq, nq, mask, rowmap, w->cs,
                                boot, split, s);

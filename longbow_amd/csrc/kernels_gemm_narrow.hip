@@ -21,6 +21,20 @@ namespace lb {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// x (8 consecutive f32 of one row) -> hi = bf16(x) (round to nearest even), lo = bf16(x - hi):
+// x = hi + lo + O(2^-18 |x|).  Same split as split_bf16_kernel (kernels_gemm.hip), done in registers.
+__device__ __forceinline__ void split8(const f32x4 x0, const f32x4 x1, bf16x8 &hi, bf16x8 &lo)
+{
+    const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const __bf16 h = (__bf16)x[i];
+        hi[i] = h;
+        lo[i] = (__bf16)(x[i] - (float)h);
+    }
+}
 
 constexpr int NBK = 32;
 constexpr int NTHREADS = 256;
@@ -42,7 +56,13 @@ struct NarrowArgs {
 
 __device__ __forceinline__ int nswz(int row, int chunk) { return row * NBK + ((chunk ^ ((row >> 1) & 7)) << 2); }
 
-template <int METRIC, int NBM, int NBN> // NBM corpus rows x NBN queries per tile: <256, 32> or <128, 64>
+// SPLIT: the inner products are computed as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with both
+// operands split into bf16 pairs IN REGISTERS after the (unchanged) f32 LDS staging -- no second copy of
+// the corpus.  3/16 of the f32 MFMA cycles: at 32-64 queries the f32 contraction keeps the MFMA pipe 70 %
+// busy under the corpus stream (0.31 of 0.45 ms per pass at 1M x 768), which is what held this kernel at
+// 5.1 TB/s; split, the pipe is ~13 % busy and the kernel is a pure HBM stream.  Candidate keys carry the
+// split contraction's error bound (index.hip: gamma); reported results come from the exact re-rank.
+template <int METRIC, int NBM, int NBN, bool SPLIT> // NBM corpus rows x NBN queries per tile: <256, 32> or <128, 64>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowArgs a)
 {
     constexpr int WROWS = NBM / 4;   // corpus rows per wave
@@ -148,6 +168,35 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
         if (kt + 1 < nk) stage_in(cur ^ 1, (kt + 1) * NBK);
         const float *As = lds_all + cur * STAGE_F;
         const float *Bs = As + NBM * NBK;
+        if (SPLIT) {
+            // MFMA k-step ks covers floats [16 ks, 16 ks + 16) of the 32-float K-step; lane half h supplies
+            // k = 8h .. 8h+7 of it: two 16-B chunks (4 ks + 2h, 4 ks + 2h + 1) of the row's 128-B piece
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                const int ch = 4 * ks + 2 * h;
+                bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                for (int t = 0; t < TM; t++) {
+                    const int r = wave * WROWS + t * 32 + l31;
+                    split8(*reinterpret_cast<const f32x4 *>(&As[nswz(r, ch)]), *reinterpret_cast<const f32x4 *>(&As[nswz(r, ch + 1)]),
+                           ah[t], al[t]);
+                }
+#pragma unroll
+                for (int t = 0; t < TN; t++) {
+                    const int r = t * 32 + l31;
+                    split8(*reinterpret_cast<const f32x4 *>(&Bs[nswz(r, ch)]), *reinterpret_cast<const f32x4 *>(&Bs[nswz(r, ch + 1)]),
+                           bh[t], bl[t]);
+                }
+#pragma unroll
+                for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+                    for (int tn = 0; tn < TN; tn++) {
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+                    }
+            }
+        } else {
         f32x4 fa[2][TM], fb[2][TN];
 #pragma unroll
         for (int t = 0; t < TM; t++) fa[0][t] = *reinterpret_cast<const f32x4 *>(&As[nswz(wave * WROWS + t * 32 + l31, h)]);
@@ -171,6 +220,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
 #pragma unroll
                     for (int tn = 0; tn < TN; tn++)
                         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb][tm][e], fb[cb][tn][e], acc[tm][tn], 0, 0, 0);
+        }
         }
         __syncthreads();
     }
@@ -254,7 +304,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
 void launch_gemm_filter_narrow(int metric, const float *X, const float *norm2, const float *rnorm,
                                int64_t row_begin, int64_t row_end, int D, const float *Q, int nq,
                                const uint8_t *mask, const uint32_t *rowmap, CandState cs, bool boot,
-                               hipStream_t s, bool tile64)
+                               hipStream_t s, bool tile64, bool split)
 {
     if (row_end <= row_begin || nq <= 0) return;
     NarrowArgs a;
@@ -266,15 +316,21 @@ void launch_gemm_filter_narrow(int metric, const float *X, const float *norm2, c
     a.n_q_tiles = (nq + bn - 1) / bn;
     const int groups = (a.n_row_tiles + 7) / 8;
     dim3 grid((unsigned)(groups * 8 * a.n_q_tiles));
-#define LB_NARROW(M)                                                                                          \
-    do {                                                                                                      \
-        if (tile64) hipLaunchKernelGGL((gemm_filter_narrow_kernel<M, 128, 64>), grid, dim3(NTHREADS), 0, s, a); \
-        else hipLaunchKernelGGL((gemm_filter_narrow_kernel<M, 256, 32>), grid, dim3(NTHREADS), 0, s, a);        \
+#define LB_NARROW_S(M, SP)                                                                                          \
+    do {                                                                                                            \
+        if (tile64) hipLaunchKernelGGL((gemm_filter_narrow_kernel<M, 128, 64, SP>), grid, dim3(NTHREADS), 0, s, a); \
+        else hipLaunchKernelGGL((gemm_filter_narrow_kernel<M, 256, 32, SP>), grid, dim3(NTHREADS), 0, s, a);        \
+    } while (0)
+#define LB_NARROW(M)                        \
+    do {                                    \
+        if (split) LB_NARROW_S(M, true);    \
+        else LB_NARROW_S(M, false);         \
     } while (0)
     if (metric == METRIC_L2) LB_NARROW(METRIC_L2);
     else if (metric == METRIC_COS) LB_NARROW(METRIC_COS);
     else LB_NARROW(METRIC_DOT);
 #undef LB_NARROW
+#undef LB_NARROW_S
 }
 
 } // namespace lb

@@ -125,7 +125,8 @@ void launch_gemm_filter(int metric, const float *X, const float *norm2, const fl
 void launch_gemm_filter_narrow(int metric, const float *X, const float *norm2, const float *rnorm,
                                int64_t row_begin, int64_t row_end, int D, const float *Q, int nq,
                                const uint8_t *mask, const uint32_t *rowmap, CandState cs, bool boot,
-                               hipStream_t s, bool tile64 = false); // tile64: 128 rows x 64 queries per workgroup
+                               hipStream_t s, bool tile64 = false, // tile64: 128 rows x 64 queries per workgroup
+                               bool split = false);                // split: 3 x bf16 MFMA on operands split in registers
 // f32 [rows][D] -> split-bf16 image (same byte shape; D % 32 == 0) consumed by the split GEMM
 void launch_split_bf16(const float *src, float *dst, int64_t rows, int D, hipStream_t s);
 

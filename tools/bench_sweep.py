@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Batch-size sweep on one MI355X: queries/s and effective corpus-read rate vs batch size
-(1M x 768 f32 cosine, k = 100).  usage: python tools/bench_sweep.py [rows]"""
+(1M x 768 f32 cosine, k = 100), with the library's own per-class device timing.
+usage: python tools/bench_sweep.py [rows]   (SWEEP=1,2,4,... selects the batch sizes)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -17,9 +18,14 @@ for B in [int(x) for x in os.environ.get('SWEEP', '1,2,4,8,9,16,24,32,48,64,96,9
     od = torch.empty((B, K), device="cuda"); ol = torch.empty((B, K), dtype=torch.int64, device="cuda")
     q = Q[:B].contiguous()
     ts = []
-    for i in range(8):
+    for i in range(10):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         idx.search_device(B, q.data_ptr(), K, od.data_ptr(), ol.data_ptr())
         ts.append(time.perf_counter() - t0)
     t = sorted(ts[2:])[len(ts[2:]) // 2]
-    print(f"B={B:5d}  {t*1e3:8.3f} ms/batch  {B/t:10.0f} q/s  corpus-read-equivalent {4.0*rows*D/t/1e12:5.2f} TB/s  fallbacks {idx.last_fallbacks}", flush=True)
+    idx.set_profiling(True)
+    idx.search_device(B, q.data_ptr(), K, od.data_ptr(), ol.data_ptr())
+    tm = idx.last_timing()
+    idx.set_profiling(False)
+    cls = " ".join(f"{c}={tm[c][0]*1e3:.0f}us/{tm[c][1]}" for c in ("gemm", "scan", "select", "rerank", "total"))
+    print(f"B={B:5d}  {t*1e3:8.3f} ms/batch  {B/t:10.0f} q/s  corpus-read-equivalent {4.0*rows*D/t/1e12:5.2f} TB/s  fallbacks {idx.last_fallbacks}  [{cls}]", flush=True)
