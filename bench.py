@@ -1,15 +1,23 @@
 #!/usr/bin/env python3
 """bench.py -- the reference's headline metric on MI355X.
 
-Metric (BASELINE.json): k-NN queries/sec at batch = 1024, k = 100 on 1M x 768 f32 (cosine,
-brute force), plus p50 single-query latency.  One "step" = one batch of 1024 queries searched
-over the rank's 1M x 768 shard, inputs resident in HBM.  With N > 1 (launched by
-torch.distributed.run, one rank per GPU) the corpus is N shards of 1M rows partitioned by the
-reference's RingSharder; every step ends with the RCCL all-gather of the per-shard top-k and the
-device merge.  A unit of `value` is one query searched over one 1M x 768 shard, so the whole-job
-rate is N * 1024 / step_time (weak scaling: per-GPU work fixed).
+Metric (BASELINE.json): k-NN queries/sec at batch = 1024, k = 100 on 1M x 768 f32 (cosine, brute force),
+plus p50 single-query latency.  One "step" = one batch of 1024 queries searched over the whole job's corpus,
+inputs resident in HBM.
 
-Prints ONE JSON line on rank 0.
+  N = 1 (default)      BASELINE config 2: 1M x 768 cosine on one GPU.  Secondary legs on the same line:
+                       split-bf16 candidates, p50 latency + scan roofline, batch sweep, PQ/ADC (config 4,
+                       100M x m=96), filtered hybrid (config 5, one GPU's share), oracle parity, CPU baseline.
+  N > 1, weak          (default) the corpus grows with N: N x 1M rows with ids 0 .. N*1M-1, partitioned by the
+                       reference's RingSharder run with 8 ring shards per GPU packed onto the GPUs by size
+                       (longbow_amd.sharded.GpuPartition); every rank searches the same 1024 queries over ITS
+                       rows, one RCCL all-gather moves the per-shard top-k, every rank merges.  A unit of
+                       `value` is one query searched over 1M rows: value = 1024 * N / step_time (per-GPU work
+                       fixed up to the ring's residual skew, which is reported, not hidden).
+  N > 1, --scaling strong   BASELINE config 3: a FIXED 10M x 768 dot corpus partitioned the same way;
+                       value = global queries/s = 1024 / step_time; N = 1 holds all 10M rows.
+
+Launched for N > 1 by torch.distributed.run, one rank per GPU.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -23,7 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N_ROWS, DIM, BATCH, K = 1_000_000, 768, 1024, 100
-METRIC_COSINE = 1
+METRIC_COSINE, METRIC_DOT = 1, 2
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X dense f32 MFMA (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_HBM_GBS = 8000.0          # HBM3E spec
 
@@ -44,21 +52,163 @@ def host_cores():
     return cores
 
 
-def shard_ids(rank, world, rows):
-    """first `rows` vector ids (ascending) that Longbow's ring assigns to shard `rank`"""
-    from longbow_amd.sharded import RingSharder
-    ring = RingSharder(world, 40)
+def median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2]
+
+
+def timed_ms(fn, torch, dev, n=8, skip=2):
+    ts = []
+    for _ in range(n):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize(dev)
+        ts.append(1e3 * (time.perf_counter() - t0))
+    return median(ts[skip:])
+
+
+def rank_ids(part, rank, global_rows):
+    """ascending ids of [0, global_rows) that the partition gives to GPU `rank`"""
     out = []
-    have = 0
-    start = 0
-    step = 4 * rows
-    while have < rows:
-        ids = np.arange(start, start + step, dtype=np.uint64)
-        mine = ids[ring.GetShards(ids) == rank]
-        out.append(mine)
-        have += mine.size
-        start += step
-    return np.concatenate(out)[:rows].astype(np.int64)
+    step = 4_000_000
+    for a in range(0, global_rows, step):
+        ids = np.arange(a, min(global_rows, a + step), dtype=np.uint64)
+        out.append(ids[part.GetGpus(ids) == rank])
+    return np.concatenate(out).astype(np.int64)
+
+
+# ---------------------------------------------------------------------------------------------------
+# secondary legs (N = 1 only)
+# ---------------------------------------------------------------------------------------------------
+def leg_batch_sweep(torch, dev, idx, Q, rows):
+    """HBM-bound regime: whole-search time vs batch size (the reference's live multi-query path issues small
+    batches sequentially, internal/store/vector_search_action.go:73)"""
+    out = []
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    for B in (1, 2, 4, 8, 16, 32, 64, 128, 256):
+        od = torch.empty((B, K), device=dev)
+        ol = torch.empty((B, K), dtype=torch.int64, device=dev)
+        q = Q[:B].contiguous()
+        ms = timed_ms(lambda: idx.search_device(B, q.data_ptr(), K, od.data_ptr(), ol.data_ptr(), stream), torch, dev, n=9, skip=3)
+        out.append({"batch": B, "ms": round(ms, 4), "queries_per_s": round(B / ms * 1e3, 1),
+                    "corpus_read_equiv_TBs": round(4.0 * rows * DIM / (ms * 1e-3) / 1e12, 3),
+                    "frac_of_8TBs": round(4.0 * rows * DIM / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)})
+    return out
+
+
+def leg_pq_adc(torch, dev, lib, _lib, cores, check=True):
+    """BASELINE config 4: 100M x 768 -> PQ (m = 96, 8-bit) codes encoded ON THE GPU from synthetic vectors,
+    ADC k-NN, k = 100, B = 1."""
+    import ctypes as C
+    from longbow_amd import pq
+    from oracle import oracle_c as oc
+    n, dims, M = 100_000_000, 768, 96
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    if free_b < 24 * 2**30:
+        return {"skipped": "needs ~16 GB of free HBM"}
+    cb = oc.fill_uniform(M * 256 * (dims // M), 7).reshape(M, 256, dims // M)
+    enc = pq.PQEncoder(pq.serialize_codebooks(cb), device=dev.index or 0)
+    enc.reserve(n)
+    CH = 2_000_000
+    buf = torch.empty((CH, dims), device=dev)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for r0 in range(0, n, CH):
+        _lib.check(lib.lb_gpu_fill_uniform_device(dev.index or 0, buf.data_ptr(), CH * dims, 12345, r0 * dims, None))
+        enc.add_vectors_device(CH, buf.data_ptr())
+    enc_s = time.perf_counter() - t0
+    del buf
+    Q = torch.empty((4, dims), device=dev)
+    _lib.check(lib.lb_gpu_fill_uniform_device(dev.index or 0, Q.data_ptr(), Q.numel(), 42, 0, None))
+    od = torch.empty((4, K), device=dev)
+    ol = torch.empty((4, K), dtype=torch.int64, device=dev)
+    ms1 = timed_ms(lambda: enc.search_device(1, Q.data_ptr(), K, od.data_ptr(), ol.data_ptr()), torch, dev, n=12, skip=4)
+    ms4 = timed_ms(lambda: enc.search_device(4, Q.data_ptr(), K, od.data_ptr(), ol.data_ptr()), torch, dev, n=8, skip=3)
+    lab, dist = ol.cpu().numpy().copy(), od.cpu().numpy().copy()
+    lib.lb_debug_set_adc_prefilter.argtypes = [C.c_int]
+    lib.lb_debug_set_adc_prefilter(0)
+    try:
+        ms_exact = timed_ms(lambda: enc.search_device(1, Q.data_ptr(), K, od.data_ptr(), ol.data_ptr()), torch, dev, n=8, skip=3)
+        same = bool(np.array_equal(ol.cpu().numpy()[:1], lab[:1]) and np.array_equal(od.cpu().numpy()[:1], dist[:1]))
+    finally:
+        lib.lb_debug_set_adc_prefilter(1)
+    res = {
+        "workload": "100M x 768 f32 -> PQ m=96 K=256 codes (9.6 GB), asymmetric distance, k=100, B=1",
+        "ms_per_query": round(ms1, 4), "queries_per_s": round(1e3 / ms1, 1),
+        "ms_per_query_at_B4": round(ms4 / 4, 4),
+        "roofline": {"bound": "hbm", "kernel": "adc_prefilter_kernel (+ exact survivors)", "achieved": round(n * M / (ms1 * 1e-3) / 1e9, 1),
+                     "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(n * M / (ms1 * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                     "algorithmic_bytes_per_query": n * M + 4 * M * 256 + 12 * K},
+        "exact_f32_table_pass_ms": round(ms_exact, 4), "prefilter_equals_exact_pass": same,
+        "encode": {"vectors": n, "seconds_incl_generation": round(enc_s, 2), "vectors_per_s": round(n / enc_s, 0)},
+    }
+    if check:  # oracle over ALL codes for one query (threaded restatement of simd.ADCDistanceBatch on the GPU's codes)
+        from concurrent.futures import ThreadPoolExecutor
+        codes = enc.get_codes()
+        table = oc.build_adc_table(cb, Q[0].cpu().numpy())
+        step = (n + cores - 1) // cores
+        with ThreadPoolExecutor(max_workers=cores) as ex:
+            d = np.concatenate(list(ex.map(lambda a: oc.adc_batch(table, codes[a:a + step]), range(0, n, step))))
+        oi, odist, _ = oc.topk_canonical(d, K)
+        sub = np.random.default_rng(1).integers(0, n, 16)
+        enc_ok = all(np.array_equal(codes[r], oc.pq_encode(cb, oc.fill_uniform(dims, 12345, int(r) * dims))) for r in sub)
+        res["parity"] = {"query_vs_oracle_ids_equal": bool(np.array_equal(lab[0], oi)),
+                         "query_vs_oracle_dist_bit_equal": bool(np.array_equal(dist[0], odist)),
+                         "encode_vs_oracle_rows_checked": int(len(sub)), "encode_ok": bool(enc_ok),
+                         "ok": bool(np.array_equal(lab[0], oi) and np.array_equal(dist[0], odist) and enc_ok and same)}
+        del codes
+    enc.Close()
+    return res
+
+
+def leg_filtered_hybrid(torch, dev, lib, _lib, cores):
+    """BASELINE config 5 on ONE GPU's share: 1.25M x 1536 f32 dot, int64 metadata `< 10` (10 % of the rows),
+    batch 256, dense side asks for 2k = 200 (internal/store/hybrid_search.go:62), RRF k = 60 with a synthetic
+    sparse ranking (BM25 stays on the CPU in the reference)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from longbow_amd import gpu
+    from oracle import oracle_c as oc
+    rows, D5, B5 = 1_250_000, 1536, 256
+    di = dev.index or 0
+    X = torch.empty((rows, D5), device=dev)
+    Q = torch.empty((B5, D5), device=dev)
+    _lib.check(lib.lb_gpu_fill_uniform_device(di, X.data_ptr(), X.numel(), 12345, 0, None))
+    _lib.check(lib.lb_gpu_fill_uniform_device(di, Q.data_ptr(), Q.numel(), 42, 0, None))
+    idx = gpu.NewIndexWithConfig(gpu.GPUConfig(DeviceID=di, Dimension=D5, Metric=METRIC_DOT))
+    idx.add_device(rows, X.data_ptr())
+    meta = np.random.default_rng(5).integers(0, 100, rows).astype(np.int64)
+    visible = np.flatnonzero(meta < 10)
+    # synthetic sparse ranking: 2k distinct visible ids per query (ids are unique within a ranked list)
+    rs6 = np.random.default_rng(6)
+    sparse = torch.from_numpy(np.stack([visible[rs6.choice(len(visible), 2 * K, replace=False)] for _ in range(B5)])).to(dev)
+    dd = torch.empty((B5, 2 * K), device=dev)
+    dl = torch.empty((B5, 2 * K), dtype=torch.int64, device=dev)
+    oi = torch.empty((B5, K), dtype=torch.int64, device=dev)
+    osc = torch.empty((B5, K), device=dev)
+    t_filter = timed_ms(lambda: idx.filter_column(meta, "<", 10), torch, dev)
+    t_dense = timed_ms(lambda: idx.search_device(B5, Q.data_ptr(), 2 * K, dd.data_ptr(), dl.data_ptr()), torch, dev)
+    t_fuse = timed_ms(lambda: _lib.check(lib.lb_gpu_rrf_fuse_device(di, B5, 2 * K, dl.data_ptr(), 2 * K, sparse.data_ptr(), 60, K,
+                                                                     oi.data_ptr(), osc.data_ptr(), None)), torch, dev)
+    lab, dist = dl.cpu().numpy(), dd.cpu().numpy()
+    Xv = X[torch.from_numpy(visible).to(dev)].cpu().numpy()  # the oracle only needs the visible rows
+    Qh = Q.cpu().numpy()
+    ok = bool(np.all(meta[lab] < 10))
+    for qi in (0, B5 - 1):
+        step = (len(visible) + cores - 1) // cores
+        with ThreadPoolExecutor(max_workers=cores) as ex:
+            d = np.concatenate(list(ex.map(lambda a: oc.batch_flat(METRIC_DOT, Qh[qi], Xv[a:a + step]), range(0, len(visible), step))))
+        ti, td, _ = oc.topk_canonical(d, 2 * K)
+        ok = ok and bool(np.array_equal(lab[qi], visible[ti]) and np.array_equal(dist[qi], td))
+        ri, rs = oc.rrf(lab[qi], sparse[qi].cpu().numpy(), 60, K)
+        ok = ok and bool(np.array_equal(oi[qi].cpu().numpy(), ri) and np.array_equal(osc[qi].cpu().numpy(), rs))
+    idx.Close()
+    per = t_dense + t_fuse
+    return {"workload": "1.25M x 1536 f32 dot (one GPU's share of 10M), int64 predicate < 10 (10 % visible), batch 256, dense 2k=200, RRF k=60",
+            "predicate_to_mask_ms": round(t_filter, 4), "dense_filtered_search_ms": round(t_dense, 4), "rrf_fusion_ms": round(t_fuse, 4),
+            "ms_per_batch": round(per, 4), "queries_per_s": round(B5 / per * 1e3, 1),
+            "visible_rows_read_equiv_TBs": round(4.0 * len(visible) * D5 / (t_dense * 1e-3) / 1e12, 3),
+            "parity": {"checked_queries": 2, "ok": ok}}
 
 
 def main():
@@ -66,17 +216,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rows", type=int, default=N_ROWS)
+    ap.add_argument("--rows", type=int, default=N_ROWS, help="rows per GPU (weak) / global rows (strong: default 10M)")
     ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast", action="store_true", help="skip the split-bf16 candidate-mode leg")
-    ap.add_argument("--cpu-queries", type=int, default=0, help="CPU baseline sample size (0 = 4 per core)")
+    ap.add_argument("--no-legs", action="store_true", help="skip the secondary legs (sweep, PQ, filtered hybrid)")
+    ap.add_argument("--cpu-queries", type=int, default=0, help="CPU baseline sample size (0 = 16 per core)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from longbow_amd import _lib, gpu
-    from longbow_amd.sharded import ShardedSearcher
+    from longbow_amd.sharded import CommSearcher, GpuPartition, ShardedSearcher
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -86,7 +238,7 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # LB_BENCH_FORCE_DIST=1 exercises the RCCL path (process group, all-gather, merge) even with one
+    # LB_BENCH_FORCE_DIST=1 exercises the collective path (process group, all-gather, merge) even with one
     # rank, so the multi-GPU code can be rehearsed on a single-GPU box.
     use_dist = world > 1 or os.environ.get("LB_BENCH_FORCE_DIST") == "1"
     if use_dist:
@@ -95,21 +247,53 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     lib = _lib.require_gpu(local_rank)
-    rows, B = args.rows, args.batch
+    strong = args.scaling == "strong"
+    metric = METRIC_DOT if strong else METRIC_COSINE
+    B = args.batch
+    global_rows = (10_000_000 if args.rows == N_ROWS else args.rows) if strong else args.rows * world
 
-    # ---- synthetic inputs, generated in HBM (uniform [0,1), corpus seed 12345, queries 42)
-    X = torch.empty((rows, DIM), device=dev)
+    # ---- synthetic inputs, generated in HBM (uniform [0,1), corpus seed 12345, queries 42) ----
+    shards_per_gpu = 8
+    part = GpuPartition(world, shards_per_gpu, 40)
+    if world > 1 or use_dist:
+        my_ids = rank_ids(part, rank, global_rows)
+    else:
+        my_ids = None
+    rows = int(my_ids.size) if my_ids is not None else global_rows
     Q = torch.empty((B, DIM), device=dev)
-    _lib.check(lib.lb_gpu_fill_uniform_device(local_rank, X.data_ptr(), X.numel(), 12345, rank * rows * DIM, None))
     _lib.check(lib.lb_gpu_fill_uniform_device(local_rank, Q.data_ptr(), Q.numel(), 42, 0, None))
-    idx = gpu.NewIndexWithConfig(gpu.GPUConfig(DeviceID=local_rank, Dimension=DIM, Metric=METRIC_COSINE))
+    idx = gpu.NewIndexWithConfig(gpu.GPUConfig(DeviceID=local_rank, Dimension=DIM, Metric=metric))
     idx.reserve(rows)
-    d_ids = None
+    X = None
+    if my_ids is None:
+        CH = 1_000_000
+        if rows <= 2 * CH:
+            X = torch.empty((rows, DIM), device=dev)
+            _lib.check(lib.lb_gpu_fill_uniform_device(local_rank, X.data_ptr(), X.numel(), 12345, 0, None))
+            idx.add_device(rows, X.data_ptr())
+        else:
+            buf = torch.empty((CH, DIM), device=dev)
+            for r0 in range(0, rows, CH):
+                c = min(CH, rows - r0)
+                _lib.check(lib.lb_gpu_fill_uniform_device(local_rank, buf.data_ptr(), c * DIM, 12345, r0 * DIM, None))
+                idx.add_device(c, buf.data_ptr())
+            del buf
+    else:
+        CH = 1_000_000
+        buf = torch.empty((min(CH, max(rows, 1)), DIM), device=dev)
+        ids_t = torch.from_numpy(my_ids).to(dev)
+        for r0 in range(0, rows, CH):
+            c = min(CH, rows - r0)
+            _lib.check(lib.lb_gpu_fill_uniform_rows_device(local_rank, buf.data_ptr(), ids_t[r0:r0 + c].data_ptr(), c, DIM, 12345, None))
+            idx.add_device(c, buf.data_ptr(), ids_t[r0:r0 + c].data_ptr())
+        del buf
+    comm_kind = os.environ.get("LB_BENCH_COMM", "torch")  # "lib": RCCL inside liblongbow_gpu.so (lb_gpu_comm_*)
+    searcher = None
     if use_dist:
-        ids = torch.from_numpy(shard_ids(rank, world, rows)).to(dev)
-        d_ids = ids.data_ptr()
-    idx.add_device(rows, X.data_ptr(), d_ids)
-    searcher = ShardedSearcher(idx, rank, world, device=dev, force_collective=use_dist) if use_dist else None
+        if comm_kind == "lib":
+            searcher = CommSearcher(idx, rank, world, device_index=local_rank, transport="rccl")
+        else:
+            searcher = ShardedSearcher(idx, rank, world, device=dev, force_collective=True)
     out_d = torch.empty((B, K), device=dev)
     out_l = torch.empty((B, K), dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -143,46 +327,64 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     idx.set_profiling(False)
+    shard_rows = [rows]
     if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        cnt = torch.tensor([rows], device=dev, dtype=torch.int64)
+        allc = [torch.zeros_like(cnt) for _ in range(world)]
+        dist.all_gather(allc, cnt)
+        shard_rows = [int(c.item()) for c in allc]
     lab, dd = step()
     lab_h, dist_h = lab.cpu().numpy(), dd.cpu().numpy()
 
     ms_per_step = 1e3 * elapsed / args.steps
-    value = world * B * args.steps / elapsed
+    if strong:
+        value = B * args.steps / elapsed                     # global queries/s over the fixed corpus
+        metric_name = "k-NN queries/sec (batch=1024, k=100), 10Mx768 f32 dot, corpus sharded over the GPUs"
+        workload = "10Mx768 float32 dot-product, corpus sharded across the GPUs, RCCL top-k merge"
+    else:
+        value = B * (global_rows / float(N_ROWS)) * args.steps / elapsed  # unit: one query over 1M rows
+        metric_name = "k-NN queries/sec (batch=1024, k=100), 1Mx768 f32"
+        workload = "1Mx768 float32 cosine, batch=1024 queries, k=100, brute-force"
 
     flops_per_step = 2.0 * B * rows * DIM
+    bytes_per_step = 4.0 * rows * DIM + 4.0 * B * DIM + 12.0 * B * K
     result = {
-        "metric": "k-NN queries/sec (batch=1024, k=100), 1Mx768 f32", "value": round(value, 1),
+        "metric": metric_name, "value": round(value, 1),
         "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "1Mx768 float32 cosine, batch=1024 queries, k=100, brute-force",
-                   "shard_rows": rows, "dim": DIM, "batch": B, "k": K, "metric": "cosine",
-                   "global_rows": rows * world,
-                   "sharding": "RingSharder(n_gpus, 40) + RCCL all-gather merge" if use_dist else "single shard",
-                   "unit_of_value": "one query searched over one 1Mx768 shard"},
+        "config": {"workload": workload, "dim": DIM, "batch": B, "k": K, "metric": "dot" if strong else "cosine",
+                   "global_rows": global_rows,
+                   "shard_rows": {"per_rank": shard_rows, "max": max(shard_rows), "mean": round(sum(shard_rows) / len(shard_rows), 1),
+                                  "max_over_mean": round(max(shard_rows) * len(shard_rows) / max(sum(shard_rows), 1), 4)},
+                   "sharding": (f"RingSharder({world * shards_per_gpu}, 40): {shards_per_gpu} ring shards per GPU packed by size "
+                                f"(one ring shard per GPU would be {GpuPartition(world, 1, 40).skew():.2f}x skewed) + "
+                                f"{'lb_gpu_comm (RCCL in the library)' if comm_kind == 'lib' else 'torch.distributed'} all-gather + device merge")
+                   if use_dist else "single shard",
+                   "unit_of_value": "global queries/s" if strong else "one query searched over 1M x 768 rows"},
         "fallback_queries": int(fallbacks),
         "device_ms_per_step": {c: round(v / args.steps, 4) for c, v in cls_ms.items()},
     }
 
-    flops_per_step = 2.0 * B * rows * DIM
-    bytes_per_step = 4.0 * rows * DIM + 4.0 * B * DIM + 12.0 * B * K
     if gemm_ms > 0:
         achieved = flops_per_step * args.steps / (gemm_ms * 1e-3) / 1e12
         traffic = None
+        traffic_src = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get("gemm_filter_kernel_hbm_bytes_per_launch")
+                tj = json.load(open(tp))
+                traffic = tj.get("gemm_filter_kernel_hbm_bytes_per_launch")
+                traffic_src = "profiles/traffic.json (rocprofv3 PMC passes of an earlier run of this command; not measured in this run)"
             except Exception:
                 traffic = None
         result["roofline"] = {
             "bound": "mfma", "kernel": "gemm_filter_kernel", "achieved": round(achieved, 2),
             "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-            "traffic": traffic,
+            "traffic": traffic, "traffic_source": traffic_src,
             "launches_per_step": gemm_launches / args.steps,
             "avg_launch_ms": round(gemm_ms / max(gemm_launches, 1), 4),
             "kernel_ms_per_step": round(gemm_ms / args.steps, 4),
@@ -191,8 +393,9 @@ def main():
             "hbm_frac_of_8TBs_at_step_rate": round(bytes_per_step / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
         }
 
+    single = rank == 0 and world == 1 and not strong and X is not None
     # ---- secondary leg: split-bf16 candidate contraction (3 x bf16 MFMA), same exact results ----------
-    if not args.no_fast and not use_dist:
+    if not args.no_fast and single:
         try:
             idx.set_candidate_mode(1)
             for _ in range(2):
@@ -229,7 +432,7 @@ def main():
             except Exception:
                 pass
 
-    if rank == 0 and world == 1:
+    if single:
         # ---- p50 single-query latency (the DoExchange path is single-query) ------------------------
         lat = []
         d1 = torch.empty((1, K), device=dev)
@@ -247,15 +450,20 @@ def main():
             idx.search_device(1, q1.data_ptr(), K, d1.data_ptr(), l1.data_ptr(), stream)
             scan_ms.append(idx.last_timing()["scan"][0])
         idx.set_profiling(False)
-        lat = sorted(lat[4:])
-        p50 = lat[len(lat) // 2]
-        scan_p50 = sorted(scan_ms[4:])[len(scan_ms[4:]) // 2]
+        p50 = median(lat[4:])
+        scan_p50 = median(scan_ms[4:])
         result["p50_latency_ms"] = round(p50, 4)
         result["latency_roofline"] = {
             "bound": "hbm", "kernel": "scan_kernel", "achieved": round(4.0 * rows * DIM / (scan_p50 * 1e-3) / 1e9, 1),
             "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": round(4.0 * rows * DIM / (scan_p50 * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-            "scan_kernels_ms": round(scan_p50, 4)}
+            "scan_kernels_ms": round(scan_p50, 4),
+            "whole_search_frac_of_8TBs": round(4.0 * rows * DIM / (p50 * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+        if not args.no_legs:
+            try:
+                result["batch_sweep"] = leg_batch_sweep(torch, dev, idx, Q, rows)
+            except Exception as e:
+                result["batch_sweep"] = {"error": str(e)}
 
         # ---- parity gate + CPU baseline (oracle = test/bench infrastructure, never the product) -----
         from oracle import oracle_c as oc
@@ -277,11 +485,29 @@ def main():
                 "sample": f"{nqc} of the {B} queries, each scanned over the full {rows}x{DIM} corpus "
                           f"(reference idiom: queries partitioned over {cores} threads, SIMD C port of internal/simd)",
                 "seconds": round(secs, 2), "label_agreement_with_gpu": round(agree, 5)}
+        del Xh
+        # ---- configs 4 and 5 (own corpora; the 1M x 768 index is released first) ----------------------
+        if not args.no_legs:
+            idx.Close()
+            idx = None
+            del X
+            X = None
+            torch.cuda.empty_cache()
+            for name, fn in (("pq_adc", lambda: leg_pq_adc(torch, dev, lib, _lib, cores)),
+                             ("filtered_hybrid", lambda: leg_filtered_hybrid(torch, dev, lib, _lib, cores))):
+                try:
+                    result[name] = fn()
+                except Exception as e:
+                    result[name] = {"error": f"{type(e).__name__}: {e}"}
+                torch.cuda.empty_cache()
 
     if rank == 0:
         print(json.dumps(result), flush=True)
-    idx.Close()
+    if idx is not None:
+        idx.Close()
     if use_dist:
+        if hasattr(searcher, "close"):
+            searcher.close()
         dist.destroy_process_group()
 
 

@@ -234,6 +234,35 @@ int lb_gpu_merge_topk_device(int device, int nshards, int64_t nq, int k, const f
 int lb_gpu_merge_topk_packed_device(int device, int nshards, int64_t nq, int k, const void *d_packed,
                                     float *d_dist_out, int64_t *d_labels_out, void *stream);
 
+/* ---- multi-GPU search -------------------------------------------------------------------
+ * One GPU per shard; per batch: shard search -> ONE all-gather of the packed per-shard top-k (RCCL over xGMI,
+ * nq*k*12 bytes per rank) -> device merge.  Semantics of ShardedHNSW.SearchVectors' fan-out + concat + sort
+ * (internal/store/sharded_hnsw.go:414-503) / MergeSortedStreams (result_merger.go:34-101); which rows a
+ * shard holds is the host's business (store.RingSharder, sharding_strategy.go:40-127).  SURVEY 8(b)'s
+ * lb_gpu_comm_init(ndev) is lb_gpu_comm_init_all.  ranks * k <= 16384. */
+typedef struct lb_gpu_comm lb_gpu_comm;
+/* host-supplied all-gather between HOST buffers: recv holds nranks blocks of `bytes` in rank order; 0 = ok */
+typedef int (*lb_allgather_fn)(void *ctx, const void *send, void *recv, size_t bytes);
+#define LB_COMM_UNIQUE_ID_BYTES 128
+/* ONE process drives ndev GPUs (the Go server): devices NULL = 0..ndev-1.  RCCL (ncclCommInitAll). */
+lb_gpu_comm *lb_gpu_comm_init_all(int ndev, const int *devices, int *out_status);
+/* one process (or thread) per GPU: rank 0 calls get_unique_id and ships the 128 bytes to the others */
+int lb_gpu_comm_get_unique_id(void *out128);
+lb_gpu_comm *lb_gpu_comm_init_rank(int device, int nranks, int rank, const void *unique_id, int *out_status);
+/* one process per GPU with the exchange done by the host (gloo / MPI / gRPC), staged through pinned memory */
+lb_gpu_comm *lb_gpu_comm_init_host(int device, int nranks, int rank, lb_allgather_fn fn, void *ctx, int *out_status);
+void lb_gpu_comm_free(lb_gpu_comm *c);
+int lb_gpu_comm_nranks(const lb_gpu_comm *c);
+int lb_gpu_comm_rank(const lb_gpu_comm *c);
+const char *lb_gpu_comm_last_error(const lb_gpu_comm *c);
+/* init_rank / init_host communicators: this rank's shard h, the same nq queries on every rank (device
+ * pointer), global top-k on every rank.  Collective: every rank must call it with the same nq and k. */
+int lb_gpu_comm_search_device(lb_gpu_comm *c, lb_gpu_index *h, int64_t nq, const float *d_queries, int k, float *d_dist,
+                              int64_t *d_labels, void *stream);
+/* init_all communicators: shards[i] lives on the communicator's i-th device; host queries in, host results out */
+int lb_gpu_comm_search_all(lb_gpu_comm *c, lb_gpu_index *const *shards, int64_t nq, const float *queries, int k, float *dist,
+                           int64_t *labels);
+
 /* ---- hybrid fusion ---------------------------------------------------------------------
  * store.ReciprocalRankFusion (internal/store/rrf.go:10-51) for nq queries at once: per query a dense
  * ranking ids[kd] and a sparse ranking ids[ks] (best first, -1 = padding, ids unique within a list);
@@ -252,6 +281,10 @@ int lb_gpu_fill_uniform_device(int device, float *d_dst, int64_t n, uint64_t see
                                void *stream);
 int lb_gpu_fill_codes_device(int device, uint8_t *d_dst, int64_t n, uint64_t seed, int64_t offset,
                              void *stream);
+/* rows of a global synthetic corpus picked by id: dst[r][j] = uniform(seed, ids[r]*dim + j) -- what a shard of
+ * a ring-partitioned corpus holds (bench.py) */
+int lb_gpu_fill_uniform_rows_device(int device, float *d_dst, const int64_t *d_ids, int64_t nrows, int dim, uint64_t seed,
+                                    void *stream);
 
 /* ---- instrumentation (bench.py roofline leg) ----------------------------------------
  * HIP-event timing of the dominant kernels of the most recent search on this handle,

@@ -86,6 +86,17 @@ SIGNATURES = [
     ("lb_gpu_rrf_fuse", _i, [_i, _i64, _i, _vp, _i, _vp, _i, _i, _vp, _vp]),
     ("lb_gpu_fill_uniform_device", _i, [_i, _vp, _i64, _u64, _i64, _vp]),
     ("lb_gpu_fill_codes_device", _i, [_i, _vp, _i64, _u64, _i64, _vp]),
+    ("lb_gpu_fill_uniform_rows_device", _i, [_i, _vp, _vp, _i64, _i, _u64, _vp]),
+    ("lb_gpu_comm_init_all", _vp, [_i, _vp, _ip]),
+    ("lb_gpu_comm_get_unique_id", _i, [_vp]),
+    ("lb_gpu_comm_init_rank", _vp, [_i, _i, _i, _vp, _ip]),
+    ("lb_gpu_comm_init_host", _vp, [_i, _i, _i, _vp, _vp, _ip]),
+    ("lb_gpu_comm_free", None, [_vp]),
+    ("lb_gpu_comm_nranks", _i, [_vp]),
+    ("lb_gpu_comm_rank", _i, [_vp]),
+    ("lb_gpu_comm_last_error", C.c_char_p, [_vp]),
+    ("lb_gpu_comm_search_device", _i, [_vp, _vp, _i64, _vp, _i, _vp, _vp, _vp]),
+    ("lb_gpu_comm_search_all", _i, [_vp, _vp, _i64, _vp, _i, _vp, _vp]),
     ("lb_gpu_index_set_profiling", _i, [_vp, _i]),
     ("lb_gpu_index_last_timing", _i, [_vp, _vp, _vp]),
 ]

@@ -1600,6 +1600,17 @@ int lb_gpu_fill_uniform_device(int device, float *d_dst, int64_t n, uint64_t see
     return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? LB_OK : LB_ERR_HIP;
 }
 
+int lb_gpu_fill_uniform_rows_device(int device, float *d_dst, const int64_t *d_ids, int64_t nrows, int dim, uint64_t seed,
+                                    void *stream)
+{
+    if (nrows < 0 || dim <= 0 || (nrows > 0 && (!d_dst || !d_ids))) return LB_ERR_INVALID_ARG;
+    if (!device_ok(device)) return LB_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return LB_ERR_HIP;
+    launch_fill_uniform_rows(d_dst, d_ids, nrows, dim, seed, (hipStream_t)stream);
+    if (hipGetLastError() != hipSuccess) return LB_ERR_HIP;
+    return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? LB_OK : LB_ERR_HIP;
+}
+
 int lb_gpu_fill_codes_device(int device, uint8_t *d_dst, int64_t n, uint64_t seed, int64_t offset, void *stream)
 {
     if (n < 0 || (n > 0 && !d_dst)) return LB_ERR_INVALID_ARG;

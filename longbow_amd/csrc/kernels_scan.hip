@@ -936,6 +936,24 @@ __global__ void fill_codes_kernel(uint8_t *dst, int64_t n, uint64_t seed, int64_
         dst[i] = (uint8_t)(splitmix64_at(seed, (uint64_t)(offset + i)) >> 56);
 }
 
+__global__ void fill_uniform_rows_kernel(float *dst, const int64_t *ids, int64_t nrows, int dim, uint64_t seed)
+{
+    const int64_t total = nrows * (int64_t)dim;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / dim;
+        const int j = (int)(i - r * dim);
+        dst[i] = (float)(splitmix64_at(seed, (uint64_t)(ids[r] * (int64_t)dim + j)) >> 40) * (1.0f / 16777216.0f);
+    }
+}
+
+void launch_fill_uniform_rows(float *dst, const int64_t *ids, int64_t nrows, int dim, uint64_t seed, hipStream_t s)
+{
+    if (nrows <= 0 || dim <= 0) return;
+    int64_t blocks = (nrows * (int64_t)dim + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(fill_uniform_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dst, ids, nrows, dim, seed);
+}
+
 void launch_fill_uniform(float *dst, int64_t n, uint64_t seed, int64_t offset, hipStream_t s)
 {
     if (n <= 0) return;

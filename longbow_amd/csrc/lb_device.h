@@ -193,6 +193,7 @@ void launch_merge_topk(int nshards, int64_t nq, int k, const float *dist_in, con
 
 void launch_fill_uniform(float *dst, int64_t n, uint64_t seed, int64_t offset, hipStream_t s);
 void launch_fill_codes(uint8_t *dst, int64_t n, uint64_t seed, int64_t offset, hipStream_t s);
+void launch_fill_uniform_rows(float *dst, const int64_t *ids, int64_t nrows, int dim, uint64_t seed, hipStream_t s);
 
 // PQ
 // minrng (nullable): [nq][M][4] = {min, max - min, 1.0 if the subtable holds a NaN / negative / infinite entry, 0}

@@ -179,3 +179,139 @@ def partition_rows(ids, num_shards, vnodes=40):
     owner = ring.GetShards(ids)
     counts = np.bincount(owner, minlength=num_shards)
     return owner, counts
+
+
+# ---------------------------------------------------------------------------------------------------
+# Shards -> GPUs.  The reference's ring is badly skewed at one shard per GPU (FNV-1a-32 over the short keys
+# "<shard>:<vnode>" clusters: with 8 shards x 40 vnodes one shard owns 30 % of the hash space, max/mean 2.4),
+# and the largest shard sets the step time.  ShardedHNSW's NumShards is a free parameter
+# (internal/store/sharded_hnsw.go:150-165), so a node runs MORE ring shards than GPUs and packs them onto
+# the GPUs by size: same RingSharder, same id -> shard map, balanced devices.
+# ---------------------------------------------------------------------------------------------------
+class GpuPartition:
+    """RingSharder(num_gpus * shards_per_gpu, vnodes) + a largest-first packing of the shards onto the GPUs
+    by the fraction of the hash space each shard owns (exact, from the ring's arcs; no data needed)."""
+
+    def __init__(self, num_gpus, shards_per_gpu=8, vnodes=40):
+        self.num_gpus = num_gpus
+        self.ring = RingSharder(num_gpus * shards_per_gpu, vnodes)
+        h = self.ring.sorted_hashes.astype(np.uint64)
+        arcs = np.empty(h.size, np.float64)
+        arcs[1:] = (h[1:] - h[:-1]).astype(np.float64)
+        arcs[0] = float(h[0]) + float((1 << 32) - int(h[-1]))  # keys above the last point wrap to point 0
+        frac = np.bincount(self.ring.owners, weights=arcs, minlength=self.ring.num_shards) / float(1 << 32)
+        self.shard_fraction = frac
+        load = np.zeros(num_gpus)
+        self.shard_gpu = np.zeros(self.ring.num_shards, np.int32)
+        for s in np.argsort(-frac, kind="stable"):  # largest first onto the least loaded GPU
+            g = int(np.argmin(load))
+            self.shard_gpu[s] = g
+            load[g] += frac[s]
+        self.gpu_fraction = load
+
+    def GetGpus(self, ids):
+        return self.shard_gpu[self.ring.GetShards(ids)]
+
+    def skew(self):
+        """max / mean of the GPUs' expected shares"""
+        return float(self.gpu_fraction.max() / self.gpu_fraction.mean())
+
+
+class CommSearcher:
+    """Sharded search through the library's own communicator (lb_gpu_comm_*): no torch in the data path.
+    transport "rccl": ncclCommInitRank inside liblongbow_gpu.so, the unique id travels over `group`;
+    transport "host": the exchange is `group`'s all_gather between host buffers (gloo), staged by the library."""
+
+    def __init__(self, index, rank, world_size, device_index=0, transport="rccl", group=None):
+        import ctypes as C
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.C = torch, dist, C
+        self.index, self.rank, self.world, self.group = index, rank, world_size, group
+        self.device_index = device_index
+        lib = _lib.require_gpu(device_index)
+        self._lib = lib
+        st = C.c_int(0)
+        self._cb = None
+        if transport == "rccl":
+            uid = (C.c_char * 128)()
+            if rank == 0:
+                _lib.check(lib.lb_gpu_comm_get_unique_id(uid))
+            box = [bytes(uid)]
+            if world_size > 1:
+                dist.broadcast_object_list(box, src=0, group=group)
+            buf = C.create_string_buffer(box[0], 128)
+            h = lib.lb_gpu_comm_init_rank(device_index, world_size, rank, buf, C.byref(st))
+        elif transport == "host":
+            FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+
+            def allgather(ctx, send, recv, nbytes):
+                try:
+                    mine = torch.frombuffer((C.c_char * nbytes).from_address(send), dtype=torch.uint8).clone()
+                    parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world_size)]
+                    dist.all_gather(parts, mine, group=group)
+                    out = torch.frombuffer((C.c_char * (nbytes * world_size)).from_address(recv), dtype=torch.uint8)
+                    out.copy_(torch.cat(parts))
+                    return 0
+                except Exception:  # never let an exception cross the C boundary
+                    return 1
+            self._cb = FN(allgather)
+            h = lib.lb_gpu_comm_init_host(device_index, world_size, rank, self._cb, None, C.byref(st))
+        else:
+            raise ValueError(transport)
+        if not h:
+            _lib.check(st.value or 7)
+        self._h = C.c_void_p(h)
+
+    def search(self, queries, k):
+        """queries: [nq, dim] float32 CUDA tensor, identical on all ranks -> (labels, dist) CUDA tensors"""
+        t = self.torch
+        nq = queries.shape[0]
+        d = t.empty((nq, k), dtype=t.float32, device=queries.device)
+        lab = t.empty((nq, k), dtype=t.int64, device=queries.device)
+        stream = t.cuda.current_stream(queries.device).cuda_stream
+        rc = self._lib.lb_gpu_comm_search_device(self._h, self.index._h, nq, queries.data_ptr(), k, d.data_ptr(),
+                                                 lab.data_ptr(), stream)
+        if rc != 0:
+            raise _lib.LongbowGPUError(rc, (self._lib.lb_gpu_comm_last_error(self._h) or b"").decode())
+        return lab, d
+
+    def close(self):
+        if self._h:
+            self._lib.lb_gpu_comm_free(self._h)
+            self._h = None
+
+
+class NodeSearcher:
+    """ONE process driving every GPU of the node (what the Go server does): lb_gpu_comm_init_all + one index
+    per device; host queries in, host results out."""
+
+    def __init__(self, indexes, devices=None):
+        import ctypes as C
+        self.C = C
+        lib = _lib.require_gpu(0)
+        self._lib = lib
+        self.indexes = list(indexes)
+        n = len(self.indexes)
+        devs = (C.c_int * n)(*(devices if devices is not None else range(n)))
+        st = C.c_int(0)
+        h = lib.lb_gpu_comm_init_all(n, devs, C.byref(st))
+        if not h:
+            _lib.check(st.value or 7)
+        self._h = C.c_void_p(h)
+        self._shards = (C.c_void_p * n)(*[ix._h for ix in self.indexes])
+
+    def search(self, queries, k):
+        q = np.ascontiguousarray(queries, np.float32)
+        nq = q.shape[0]
+        dist = np.empty((nq, k), np.float32)
+        lab = np.empty((nq, k), np.int64)
+        rc = self._lib.lb_gpu_comm_search_all(self._h, self._shards, nq, q.ctypes.data, k, dist.ctypes.data, lab.ctypes.data)
+        if rc != 0:
+            raise _lib.LongbowGPUError(rc, (self._lib.lb_gpu_comm_last_error(self._h) or b"").decode())
+        return lab, dist
+
+    def close(self):
+        if self._h:
+            self._lib.lb_gpu_comm_free(self._h)
+            self._h = None

@@ -91,3 +91,36 @@ def test_sample_plan_invariants():
                     mean = m * span / count
                     assert mean * (1 + 5 / math.sqrt(m)) <= (cap - keep) * 1.0001, (n, keep, cap, m, mean)
     assert seen_on > 50
+
+
+def test_gpu_partition_packs_ring_shards_evenly():
+    """GpuPartition: the reference's RingSharder with 8 ring shards per GPU, shards packed onto GPUs by the
+    share of the hash space they own.  The id -> ring shard map stays the reference's; only shard -> GPU is
+    chosen; the expected shares (from the ring's arcs) match a count over real ids."""
+    from longbow_amd.sharded import GpuPartition
+    ids = np.arange(2_000_000, dtype=np.uint64)
+    for gpus in (1, 2, 4, 8):
+        p = GpuPartition(gpus, 8, 40)
+        assert p.ring.num_shards == gpus * 8
+        g = p.GetGpus(ids)
+        assert g.min() >= 0 and g.max() < gpus
+        assert np.array_equal(g, p.shard_gpu[RingSharder(gpus * 8, 40).GetShards(ids)])
+        cnt = np.bincount(g, minlength=gpus)
+        assert cnt.max() / cnt.mean() < 1.03, (gpus, cnt)
+        assert abs(p.skew() - cnt.max() / cnt.mean()) < 0.01
+        assert abs(p.shard_fraction.sum() - 1.0) < 1e-9
+    assert GpuPartition(8, 1, 40).skew() > 2.0  # one ring shard per GPU: the skew the packing removes
+
+
+def test_comm_entry_points_validate_arguments_without_a_gpu():
+    import ctypes as C
+    from longbow_amd import _lib
+    lib = _lib.load()
+    st = C.c_int(0)
+    assert not lib.lb_gpu_comm_init_all(0, None, C.byref(st)) and st.value == 1
+    assert not lib.lb_gpu_comm_init_host(0, 2, 5, None, None, C.byref(st)) and st.value == 1
+    assert not lib.lb_gpu_comm_init_rank(0, 2, 0, None, C.byref(st)) and st.value == 1
+    if lib.lb_gpu_device_count() == 0:
+        assert not lib.lb_gpu_comm_init_all(2, None, C.byref(st)) and st.value == 3
+    assert lib.lb_gpu_comm_nranks(None) == 0
+    assert lib.lb_gpu_comm_search_device(None, None, 1, None, 1, None, None, None) == 1
