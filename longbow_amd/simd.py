@@ -163,3 +163,111 @@ def AndBytes(dst, src, device=0):
     if src.size != dst.size:
         raise ValueError("simd: length mismatch")  # simd.go:120-122
     _lib.check(lib.lb_simd_and_bytes(device, dst.ctypes.data, src.ctypes.data, dst.size))
+
+
+# ---------------------------------------------------------------------------------------------------
+# internal/simd's dispatch surface (a13): SIMDDataType, KernelKey, KernelRegistry.Register/Get,
+# DispatchDistance, core.DistanceMetric strings -- with the HIP kernels registered the way
+# go/internal/simd/hip_kernels.go registers them in the Go tree.
+# ---------------------------------------------------------------------------------------------------
+class SIMDDataType(enum.IntEnum):
+    """simd.SIMDDataType (internal/simd/registry.go:32-47)"""
+    Float32 = 0
+    Float16 = 1
+    Int8 = 2
+    Uint8 = 3
+    Int16 = 4
+    Uint16 = 5
+    Int32 = 6
+    Uint32 = 7
+    Int64 = 8
+    Uint64 = 9
+    Float64 = 10
+    Complex64 = 11
+    Complex128 = 12
+
+    def __str__(self):  # SIMDDataType.String(), registry.go:49-79
+        return self.name.lower()
+
+
+BatchFlatDims = -1  # KernelKey.Dims of the batch-flat kernels (no vector has a negative length)
+
+
+class KernelRegistry:
+    """simd.KernelRegistry (internal/simd/registry.go:82-124): kernels keyed by (metric, data type, dims);
+    Get tries the exact dims first and then the generic dims = 0 entry."""
+
+    def __init__(self):
+        import threading
+        self._mu = threading.RLock()
+        self._kernels = {}
+
+    def Register(self, metric, dt, dims, kernel):
+        with self._mu:
+            self._kernels[(int(metric), int(dt), int(dims))] = kernel
+
+    def Get(self, metric, dt, dims):
+        with self._mu:
+            k = self._kernels.get((int(metric), int(dt), int(dims)))
+            if k is not None:
+                return k
+            return self._kernels.get((int(metric), int(dt), 0))
+
+
+Registry = KernelRegistry()
+# per-pair kernels at the generic key, as dispatch.go:221-234 registers the CPU ones
+Registry.Register(MetricType.Euclidean, SIMDDataType.Float32, 0, EuclideanDistance)
+Registry.Register(MetricType.Cosine, SIMDDataType.Float32, 0, CosineDistance)
+Registry.Register(MetricType.DotProduct, SIMDDataType.Float32, 0, DotProduct)
+
+
+def _hip_batch_flat(metric):
+    def kernel(query, flatVectors, numVectors, dims, results, order=Order.Unroll4, device=0):
+        _batch_flat(metric, query, flatVectors, numVectors, dims, results, order, device)
+    kernel.metric = metric
+    return kernel
+
+
+for _m in MetricType:  # go/internal/simd/hip_kernels.go: init()
+    Registry.Register(_m, SIMDDataType.Float32, BatchFlatDims, _hip_batch_flat(_m))
+
+
+def DispatchDistance(metric, a, b):
+    """simd.DispatchDistance (internal/simd/dispatch.go:264-302)"""
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    if a.size != b.size:
+        raise ValueError(f"simd: dimension mismatch: {a.size} != {b.size}")
+    if a.size == 0:
+        return np.float32(0)
+    kernel = Registry.Get(metric, SIMDDataType.Float32, a.size)
+    if kernel is None:
+        raise ValueError(f"simd: no kernel found for {MetricType(metric)}/{SIMDDataType.Float32} dims={a.size}")
+    return kernel(a, b)
+
+
+def DispatchBatchFlat(metric, query, flatVectors, numVectors, dims, results, **kw):
+    """one query x n rows through the registry: the HIP batch kernel when registered (exact key), else the
+    generic per-pair kernel row by row (go/internal/simd/hip_kernels.go: DispatchBatchFlat)"""
+    kernel = Registry.Get(metric, SIMDDataType.Float32, BatchFlatDims)
+    if kernel is None:
+        raise ValueError(f"simd: no kernel found for {MetricType(metric)}/{SIMDDataType.Float32}")
+    if getattr(kernel, "metric", None) is not None:
+        return kernel(query, flatVectors, numVectors, dims, results, **kw)
+    flat = np.ascontiguousarray(flatVectors, np.float32).reshape(-1)
+    for i in range(numVectors):
+        results[i] = kernel(query, flat[i * dims:(i + 1) * dims])
+
+
+_CORE_METRICS = {"euclidean": MetricType.Euclidean, "": MetricType.Euclidean, "cosine": MetricType.Cosine,
+                 "dot_product": MetricType.DotProduct, "dot": MetricType.DotProduct}
+
+
+def MetricFromCore(name):
+    """core.DistanceMetric strings (internal/core/enums.go:6-13) and MetricType.String()'s "dot" -> MetricType"""
+    if isinstance(name, MetricType):
+        return name
+    try:
+        return _CORE_METRICS[str(name)]
+    except KeyError:
+        raise ValueError(f"simd: unknown distance metric {name!r}") from None

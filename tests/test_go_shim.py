@@ -1,0 +1,57 @@
+"""The Go side of the boundary cannot be compiled here (no Go toolchain in the image), so the shim sources
+are checked mechanically: every C symbol they call is declared by include/longbow_gpu.h (so they cannot
+drift from the library), delimiters balance outside strings / comments, the build tags and package names are
+the reference's (internal/gpu/faiss_gpu.go:1, internal/simd/registry.go:1)."""
+import glob
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _strip_go(src):
+    """drop comments, string / rune literals and the cgo preamble (keeps delimiters of real code)"""
+    out, i, n = [], 0, len(src)
+    while i < n:
+        c = src[i]
+        if src.startswith("//", i):
+            i = src.find("\n", i) if "\n" in src[i:] else n
+        elif src.startswith("/*", i):
+            i = src.find("*/", i) + 2
+        elif c == '"':
+            i += 1
+            while src[i] != '"':
+                i += 2 if src[i] == "\\" else 1
+            i += 1
+        elif c == "`":
+            i = src.find("`", i + 1) + 1
+        elif c == "'":
+            i += 1
+            while src[i] != "'":
+                i += 2 if src[i] == "\\" else 1
+            i += 1
+        else:
+            out.append(c)
+            i += 1
+    return "".join(out)
+
+
+def test_go_shims_reference_only_declared_symbols_and_balance():
+    header = open(os.path.join(ROOT, "include", "longbow_gpu.h")).read()
+    declared = set(re.findall(r"\b(lb_[a-z0-9_]+)\s*\(", header)) | set(re.findall(r"\b(LB_[A-Z0-9_]+)\b", header))
+    declared |= set(re.findall(r"\b(lb_[a-z0-9_]+)\b", header))  # typedef'd names (lb_gpu_index, lb_status ...)
+    files = sorted(glob.glob(os.path.join(ROOT, "go", "internal", "*", "*.go")))
+    assert len(files) >= 2
+    for f in files:
+        src = open(f).read()
+        assert src.startswith("//go:build gpu && linux"), f
+        pkg = os.path.basename(os.path.dirname(f))
+        assert re.search(rf"^package {pkg}$", src, re.M), f
+        assert '#include "longbow_gpu.h"' in src and 'import "C"' in src, f
+        code = _strip_go(src)
+        for op, cl in ("()", "[]", "{}"):
+            assert code.count(op) == code.count(cl), (f, op)
+        used = set(re.findall(r"\bC\.(lb_[a-z0-9_]+|LB_[A-Z0-9_]+)\b", code))
+        assert used, f
+        missing = used - declared
+        assert not missing, (f, missing)

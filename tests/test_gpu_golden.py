@@ -177,3 +177,26 @@ def test_golden_merge_on_gpu(golden):
         assert rc == 0
         got = [int(x) for x in lo[0].cpu().numpy() if x >= 0][:c["k"]]
         assert got == c["expected_ids"], c["name"]
+
+
+def test_dispatch_through_the_registry_matches_the_oracle(oracle):
+    """simd.DispatchDistance / DispatchBatchFlat resolve to the HIP kernels through KernelRegistry.Get
+    (internal/simd/registry.go:94-124, dispatch.go:264-302) and return the reference's values"""
+    from tests.gpu_util import gpu_or_skip
+    gpu_or_skip()
+    from longbow_amd import simd
+    rng = np.random.default_rng(12)
+    for dims in (128, 384, 768, 7):
+        X = rng.random((50, dims), dtype=np.float32)
+        q = rng.random(dims, dtype=np.float32)
+        for name in ("euclidean", "cosine", "dot_product"):
+            m = simd.MetricFromCore(name)
+            want = oracle.batch_flat(int(m), q, X, 1)
+            if m == simd.MetricType.DotProduct:
+                want = -want  # the registry's dot kernels return the RAW dot product (simd.DotProduct)
+            res = np.empty(50, np.float32)
+            simd.DispatchBatchFlat(m, q, X.reshape(-1), 50, dims, res)
+            assert np.array_equal(res, want), (dims, name)
+            one = simd.DispatchDistance(m, q, X[3])
+            ref = {0: oracle.euclidean, 1: oracle.cosine, 2: oracle.dot}[int(m)](q, X[3], 0)
+            assert one == ref, (dims, name)

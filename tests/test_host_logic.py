@@ -124,3 +124,33 @@ def test_comm_entry_points_validate_arguments_without_a_gpu():
         assert not lib.lb_gpu_comm_init_all(2, None, C.byref(st)) and st.value == 3
     assert lib.lb_gpu_comm_nranks(None) == 0
     assert lib.lb_gpu_comm_search_device(None, None, 1, None, 1, None, None, None) == 1
+
+
+def test_kernel_registry_lookup_rule_and_metric_names():
+    """internal/simd/registry.go:94-124: exact (metric, type, dims) first, then dims = 0; nil when neither;
+    core.DistanceMetric strings (core/enums.go:6-13) map onto MetricType; the HIP batch kernels sit under
+    their own dims key and never shadow the per-pair kernels DispatchDistance looks up"""
+    from longbow_amd import simd
+    r = simd.KernelRegistry()
+    f0, f128 = object(), object()
+    r.Register(simd.MetricType.Euclidean, simd.SIMDDataType.Float32, 0, f0)
+    r.Register(simd.MetricType.Euclidean, simd.SIMDDataType.Float32, 128, f128)
+    assert r.Get(simd.MetricType.Euclidean, simd.SIMDDataType.Float32, 128) is f128
+    assert r.Get(simd.MetricType.Euclidean, simd.SIMDDataType.Float32, 384) is f0
+    assert r.Get(simd.MetricType.Cosine, simd.SIMDDataType.Float32, 128) is None
+    assert r.Get(simd.MetricType.Euclidean, simd.SIMDDataType.Float16, 128) is None
+    r.Register(simd.MetricType.Euclidean, simd.SIMDDataType.Float32, 128, f0)  # re-registering replaces
+    assert r.Get(simd.MetricType.Euclidean, simd.SIMDDataType.Float32, 128) is f0
+    for m in simd.MetricType:
+        batch = simd.Registry.Get(m, simd.SIMDDataType.Float32, simd.BatchFlatDims)
+        pair = simd.Registry.Get(m, simd.SIMDDataType.Float32, 768)
+        assert batch is not None and pair is not None and batch is not pair and batch.metric == m
+    assert [str(m) for m in simd.MetricType] == ["euclidean", "cosine", "dot"]
+    assert str(simd.SIMDDataType.Float32) == "float32" and int(simd.SIMDDataType.Complex128) == 12
+    assert simd.MetricFromCore("euclidean") == 0 and simd.MetricFromCore("cosine") == 1
+    assert simd.MetricFromCore("dot_product") == 2 and simd.MetricFromCore("dot") == 2
+    with pytest.raises(ValueError):
+        simd.MetricFromCore("manhattan")
+    with pytest.raises(ValueError):
+        simd.DispatchDistance(0, np.zeros(3, np.float32), np.zeros(4, np.float32))  # dimension mismatch
+    assert simd.DispatchDistance(1, np.zeros(0, np.float32), np.zeros(0, np.float32)) == 0  # len 0 -> 0, nil
