@@ -189,3 +189,112 @@ func (idx *HIPIndex) Close() error {
 	idx.closed = true
 	return nil
 }
+
+// Rerank is the distance step of processChunkInternal (internal/store/parallel_search.go:274-364) for
+// candidates that are already resident on the GPU: rows are row positions (the labels Search returns when
+// Add got no ids), dist[i] is what simd.EuclideanDistanceBatchFlat would give for the gathered vectors
+// (4-accumulator order), score[i] = 1/(1+dist[i]).  No vectors cross PCIe.
+func (idx *HIPIndex) Rerank(query []float32, rows []int64) (dist, score []float32, err error) {
+	idx.mu.RLock()
+	defer idx.mu.RUnlock()
+	if idx.closed {
+		return nil, nil, fmt.Errorf("index is closed")
+	}
+	if len(query) != idx.dim {
+		return nil, nil, fmt.Errorf("query vector dimension %d does not match index dimension %d", len(query), idx.dim)
+	}
+	if len(rows) == 0 {
+		return nil, nil, nil
+	}
+	dist = make([]float32, len(rows))
+	score = make([]float32, len(rows))
+	rc := C.lb_gpu_index_rerank(idx.h, (*C.float)(unsafe.Pointer(&query[0])), (*C.int64_t)(unsafe.Pointer(&rows[0])),
+		C.int64_t(len(rows)), C.int(C.LB_ORDER_UNROLL4), (*C.float)(unsafe.Pointer(&dist[0])), (*C.float)(unsafe.Pointer(&score[0])))
+	if rc != C.LB_OK {
+		return nil, nil, hipError(idx.h, "rerank", rc)
+	}
+	return dist, score, nil
+}
+
+// NodeIndex shards a corpus over every GPU of the node from ONE process (the Longbow server): one HIPIndex
+// per device, one RCCL communicator (lb_gpu_comm_init_all, SURVEY 8b's lb_gpu_comm_init(ndev)).  Search is
+// ShardedHNSW.SearchVectors' fan-out + concat + sort (internal/store/sharded_hnsw.go:414-503) done as shard
+// searches + one all-gather over xGMI + a device merge.  Which ids a shard holds is the caller's choice
+// (store.RingSharder, internal/store/sharding_strategy.go:40-127): Add takes the shard explicitly.
+type NodeIndex struct {
+	shards []*HIPIndex
+	comm   *C.lb_gpu_comm
+	mu     sync.RWMutex
+}
+
+func NewNodeIndex(devices []int, cfg HIPConfig) (*NodeIndex, error) {
+	if len(devices) == 0 {
+		return nil, fmt.Errorf("no devices given")
+	}
+	n := &NodeIndex{}
+	cdev := make([]C.int, len(devices))
+	for i, d := range devices {
+		c := cfg
+		c.DeviceID = d
+		ix, err := NewHIPIndexWithMetric(c)
+		if err != nil {
+			n.Close()
+			return nil, err
+		}
+		n.shards = append(n.shards, ix.(*HIPIndex))
+		cdev[i] = C.int(d)
+	}
+	var st C.int
+	n.comm = C.lb_gpu_comm_init_all(C.int(len(devices)), &cdev[0], &st)
+	if n.comm == nil {
+		n.Close()
+		return nil, hipError(nil, "comm init", st)
+	}
+	return n, nil
+}
+
+// Add appends vectors to one shard (ids are the global VectorIDs; they travel with the results).
+func (n *NodeIndex) Add(shard int, ids []int64, vectors []float32) error {
+	if shard < 0 || shard >= len(n.shards) {
+		return fmt.Errorf("shard %d out of range", shard)
+	}
+	return n.shards[shard].Add(ids, vectors)
+}
+
+// SearchBatch returns the global top-k of nq queries (row-major), nq*k results, query-major.
+func (n *NodeIndex) SearchBatch(queries []float32, nq, k int) ([]int64, []float32, error) {
+	n.mu.RLock()
+	defer n.mu.RUnlock()
+	if n.comm == nil {
+		return nil, nil, fmt.Errorf("index is closed")
+	}
+	if nq <= 0 || k <= 0 {
+		return nil, nil, nil
+	}
+	hs := make([]*C.lb_gpu_index, len(n.shards))
+	for i, s := range n.shards {
+		hs[i] = s.h
+	}
+	distances := make([]float32, nq*k)
+	labels := make([]int64, nq*k)
+	rc := C.lb_gpu_comm_search_all(n.comm, &hs[0], C.int64_t(nq), (*C.float)(unsafe.Pointer(&queries[0])), C.int(k),
+		(*C.float)(unsafe.Pointer(&distances[0])), (*C.int64_t)(unsafe.Pointer(&labels[0])))
+	if rc != C.LB_OK {
+		return nil, nil, fmt.Errorf("sharded search failed with code %d (%s)", int(rc), C.GoString(C.lb_gpu_comm_last_error(n.comm)))
+	}
+	return labels, distances, nil
+}
+
+func (n *NodeIndex) Close() error {
+	n.mu.Lock()
+	defer n.mu.Unlock()
+	if n.comm != nil {
+		C.lb_gpu_comm_free(n.comm)
+		n.comm = nil
+	}
+	for _, s := range n.shards {
+		s.Close()
+	}
+	n.shards = nil
+	return nil
+}

@@ -263,6 +263,31 @@ int lb_gpu_comm_search_device(lb_gpu_comm *c, lb_gpu_index *h, int64_t nq, const
 int lb_gpu_comm_search_all(lb_gpu_comm *c, lb_gpu_index *const *shards, int64_t nq, const float *queries, int k, float *dist,
                            int64_t *labels);
 
+/* ---- Arrow Flight framing (SURVEY f-1 / f-2) -----------------------------------------------------
+ * The bytes of the Flight messages in, the bytes of the response out: a Go (or C) host needs no Arrow glue.
+ * Return values of the lb_flight_* calls that parse requests are gRPC status codes, as the reference handler
+ * returns them (0 OK, 3 InvalidArgument, 5 NotFound, 9 FailedPrecondition, 13 Internal, 14 Unavailable), with
+ * the reference's message text in errbuf (nullable). */
+typedef struct lb_flight_datasets lb_flight_datasets; /* name -> index (VectorStore.getDataset) */
+lb_flight_datasets *lb_flight_datasets_new(void);
+void lb_flight_datasets_free(lb_flight_datasets *r);
+/* register (h != NULL) or remove (h == NULL) a dataset; the index stays owned by the caller */
+int lb_flight_datasets_put(lb_flight_datasets *r, const char *name, lb_gpu_index *h);
+/* VectorStore.handleVectorSearchExchange (internal/store/vector_search_exchange.go:31-217): ipc_in = an Arrow
+ * IPC stream with ONE request batch {dataset utf8, k int32 (default 10), ef int32 (ignored), query_vector
+ * FixedSizeList<float32> | List<float32>}, row 0 only; *ipc_out = an IPC stream with the response batch
+ * {id uint64, score float32} (min(k, N) rows), to be released with lb_flight_free_buffer. */
+int lb_flight_vector_search_exchange(lb_flight_datasets *reg, const uint8_t *ipc_in, size_t len_in, uint8_t **ipc_out,
+                                     size_t *len_out, char *errbuf, size_t errcap);
+/* One result batch {id uint64, score float32} as IPC stream bytes (trailing -1 labels trimmed): the per-query
+ * flight.Result of DoAction("VectorSearch") (internal/store/vector_search_action.go:180-231).  lb_status. */
+int lb_flight_encode_results(const int64_t *ids, const float *scores, int64_t n, uint8_t **ipc_out, size_t *len_out);
+void lb_flight_free_buffer(uint8_t *p);
+/* Append every record batch of an IPC stream: column "vector" FixedSizeList<float32>[dim] (its values buffer
+ * goes to lb_gpu_index_add as it lies in the message body) and optional "id" (uint32 / uint64 / int64,
+ * truncated to the reference's uint32 VectorID).  internal/store/store_lifecycle.go:66-76. */
+int lb_flight_index_add_ipc(lb_gpu_index *h, const uint8_t *ipc, size_t len, int64_t *rows_added, char *errbuf, size_t errcap);
+
 /* ---- hybrid fusion ---------------------------------------------------------------------
  * store.ReciprocalRankFusion (internal/store/rrf.go:10-51) for nq queries at once: per query a dense
  * ranking ids[kd] and a sparse ranking ids[ks] (best first, -1 = padding, ids unique within a list);

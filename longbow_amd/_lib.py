@@ -87,6 +87,13 @@ SIGNATURES = [
     ("lb_gpu_fill_uniform_device", _i, [_i, _vp, _i64, _u64, _i64, _vp]),
     ("lb_gpu_fill_codes_device", _i, [_i, _vp, _i64, _u64, _i64, _vp]),
     ("lb_gpu_fill_uniform_rows_device", _i, [_i, _vp, _vp, _i64, _i, _u64, _vp]),
+    ("lb_flight_datasets_new", _vp, []),
+    ("lb_flight_datasets_free", None, [_vp]),
+    ("lb_flight_datasets_put", _i, [_vp, C.c_char_p, _vp]),
+    ("lb_flight_vector_search_exchange", _i, [_vp, _vp, _sz, C.POINTER(_vp), C.POINTER(_sz), C.c_char_p, _sz]),
+    ("lb_flight_encode_results", _i, [_vp, _vp, _i64, C.POINTER(_vp), C.POINTER(_sz)]),
+    ("lb_flight_free_buffer", None, [_vp]),
+    ("lb_flight_index_add_ipc", _i, [_vp, _vp, _sz, C.POINTER(_i64), C.c_char_p, _sz]),
     ("lb_gpu_comm_init_all", _vp, [_i, _vp, _ip]),
     ("lb_gpu_comm_get_unique_id", _i, [_vp]),
     ("lb_gpu_comm_init_rank", _vp, [_i, _i, _i, _vp, _ip]),

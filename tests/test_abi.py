@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     src = open(os.path.join(ROOT, "include", "longbow_gpu.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(lb_(?:gpu|simd)_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(lb_(?:gpu|simd|flight)_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_library_builds_and_exports_every_declared_symbol():
