@@ -126,6 +126,15 @@ def leg_pq_adc(torch, dev, lib, _lib, cores, check=True):
     ms1 = timed_ms(lambda: enc.search_device(1, Q.data_ptr(), K, od.data_ptr(), ol.data_ptr()), torch, dev, n=12, skip=4)
     ms4 = timed_ms(lambda: enc.search_device(4, Q.data_ptr(), K, od.data_ptr(), ol.data_ptr()), torch, dev, n=8, skip=3)
     lab, dist = ol.cpu().numpy().copy(), od.cpu().numpy().copy()
+    enc.set_profiling(True)  # HIP events on the search stream around the pass over the codes
+    kms, dms = [], []
+    for _ in range(8):
+        enc.search_device(1, Q.data_ptr(), K, od.data_ptr(), ol.data_ptr())
+        a, b = enc.last_timing()
+        kms.append(a)
+        dms.append(b)
+    enc.set_profiling(False)
+    k_ms, d_ms = median(kms[2:]), median(dms[2:])
     lib.lb_debug_set_adc_prefilter.argtypes = [C.c_int]
     lib.lb_debug_set_adc_prefilter(0)
     try:
@@ -137,8 +146,10 @@ def leg_pq_adc(torch, dev, lib, _lib, cores, check=True):
         "workload": "100M x 768 f32 -> PQ m=96 K=256 codes (9.6 GB), asymmetric distance, k=100, B=1",
         "ms_per_query": round(ms1, 4), "queries_per_s": round(1e3 / ms1, 1),
         "ms_per_query_at_B4": round(ms4 / 4, 4),
-        "roofline": {"bound": "hbm", "kernel": "adc_prefilter_kernel (+ exact survivors)", "achieved": round(n * M / (ms1 * 1e-3) / 1e9, 1),
-                     "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(n * M / (ms1 * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+        "roofline": {"bound": "hbm", "kernel": "adc_prefilter_kernel", "achieved": round(n * M / (k_ms * 1e-3) / 1e9, 1),
+                     "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(n * M / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                     "kernel_ms": round(k_ms, 4), "whole_search_device_ms": round(d_ms, 4),
+                     "whole_search_frac_of_8TBs": round(n * M / (ms1 * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                      "algorithmic_bytes_per_query": n * M + 4 * M * 256 + 12 * K},
         "exact_f32_table_pass_ms": round(ms_exact, 4), "prefilter_equals_exact_pass": same,
         "encode": {"vectors": n, "seconds_incl_generation": round(enc_s, 2), "vectors_per_s": round(n / enc_s, 0)},

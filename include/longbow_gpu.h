@@ -219,6 +219,12 @@ int lb_gpu_pq_search(lb_gpu_pq *p, int64_t nq, const float *queries, int k, floa
 int lb_gpu_pq_search_device(lb_gpu_pq *p, int64_t nq, const float *d_queries, int k,
                             float *d_dist, int64_t *d_labels, void *stream);
 
+/* instrumentation (bench.py): HIP-event times of the most recent profiled search on this handle, recorded on the
+ * search stream: ms[0] = the pass over the codes of the LAST query (prefilter kernel, or the exact kernel when
+ * the prefilter is off), ms[1] = the whole search on the device.  Enable before the search; one search at a time. */
+int lb_gpu_pq_set_profiling(lb_gpu_pq *p, int enable);
+int lb_gpu_pq_last_timing(const lb_gpu_pq *p, float ms[2]);
+
 /* ---- cross-shard merge ---------------------------------------------------------
  * store.MergeSortedStreams (internal/store/result_merger.go:34-101) for S shards:
  * inputs [S][nq][k] ascending per (shard, query) (padding label -1 / FLT_MAX allowed),

@@ -76,6 +76,8 @@ SIGNATURES = [
     ("lb_gpu_pq_decode_device", _i, [_vp, _i64, _vp, _vp, _vp]),
     ("lb_gpu_pq_rerank", _i, [_vp, _vp, _vp, _i64, _vp, _vp]),
     ("lb_gpu_pq_rerank_device", _i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    ("lb_gpu_pq_set_profiling", _i, [_vp, _i]),
+    ("lb_gpu_pq_last_timing", _i, [_vp, _vp]),
     ("lb_gpu_pq_build_adc_table", _i, [_vp, _vp, _vp]),
     ("lb_gpu_pq_adc_distance_batch", _i, [_vp, _vp, _i64, _i64, _vp]),
     ("lb_gpu_pq_search", _i, [_vp, _i64, _vp, _i, _vp, _vp]),

@@ -47,6 +47,10 @@ struct lb_gpu_pq {
     std::vector<std::unique_ptr<PqScratch>> sc_free;
     mutable std::mutex err_mu;
     std::string last_error;
+    // instrumentation (bench.py): HIP events around the main code pass and the whole search of the last query
+    std::atomic<int> profiling{0};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    float prof_ms[2] = {0.f, 0.f};
     void set_error(const char *fmt, ...)
     {
         char buf[512];
@@ -226,6 +230,8 @@ void lb_gpu_pq_free(lb_gpu_pq *p)
         }
         if (p->d_codebooks) (void)hipFree(p->d_codebooks);
         if (p->d_codes) (void)hipFree(p->d_codes);
+        for (auto &e : p->ev)
+            if (e) (void)hipEventDestroy(e);
         if (p->stream) (void)hipStreamDestroy(p->stream);
     }
     delete p;
@@ -473,6 +479,21 @@ int lb_gpu_pq_rerank(lb_gpu_pq *p, const float *query, const int64_t *rows, int6
     return LB_OK;
 }
 
+int lb_gpu_pq_set_profiling(lb_gpu_pq *p, int enable)
+{
+    if (!p) return LB_ERR_INVALID_ARG;
+    p->profiling.store(enable ? 1 : 0);
+    return LB_OK;
+}
+
+int lb_gpu_pq_last_timing(const lb_gpu_pq *p, float ms[2])
+{
+    if (!p || !ms) return LB_ERR_INVALID_ARG;
+    ms[0] = p->prof_ms[0];
+    ms[1] = p->prof_ms[1];
+    return LB_OK;
+}
+
 // ---- search ----------------------------------------------------------------------------
 int lb_gpu_pq_search_device(lb_gpu_pq *p, int64_t nq, const float *d_queries, int k, float *d_dist,
                             int64_t *d_labels, void *stream)
@@ -513,6 +534,12 @@ int lb_gpu_pq_search_device(lb_gpu_pq *p, int64_t nq, const float *d_queries, in
         scp = acquire_scratch(p, nqi, cap, samp_count);
         PqScratch &sc = *scp;
         const bool prefilter = samp_count != 0 && g_adc_prefilter.load() != 0;
+        const bool prof = p->profiling.load() != 0;
+        if (prof) {
+            for (auto &e : p->ev)
+                if (!e) LBP_HIP(hipEventCreate(&e));
+            LBP_HIP(hipEventRecord(p->ev[0], s));
+        }
         launch_build_adc_table(p->d_codebooks, p->M, p->K, p->sub, d_queries, nqi, sc.d_tables, s, prefilter ? sc.d_minrng : nullptr);
         LBP_HIP(hipMemsetAsync(sc.cs.flags, 0, (size_t)nqi * 4, s));
         if (prefilter) LBP_HIP(hipMemsetAsync(sc.d_cand_cnt, 0, (size_t)nqi * 4, s));
@@ -533,12 +560,16 @@ int lb_gpu_pq_search_device(lb_gpu_pq *p, int64_t nq, const float *d_queries, in
                         int *prm = sc.d_params + q * 4;
                         uint8_t *qtab = sc.d_qtabs + (size_t)q * p->M * 256;
                         launch_adc_quantise(tab, sc.d_minrng + (size_t)q * p->M * 4, p->M, sc.cs.tau + q, qtab, prm, s);
+                        if (prof && q == nqi - 1) (void)hipEventRecord(p->ev[2], s);
                         launch_adc_prefilter(qtab, prm, p->M, p->d_codes, p->n, sc.d_cand, kCandCap, sc.d_cand_cnt + q, s);
+                        if (prof && q == nqi - 1) (void)hipEventRecord(p->ev[3], s);
                         launch_adc_exact_candidates(tab, p->M, p->d_codes, sc.d_cand, sc.d_cand_cnt + q, kCandCap, prm, q,
                                                     sc.cs, s);
                         skip = prm;
                     }
+                    if (prof && q == nqi - 1 && !prefilter) (void)hipEventRecord(p->ev[2], s);
                     launch_adc_scan(tab, p->M, p->d_codes, 0, p->n, q, nullptr, sc.cs, false, nullptr, 0, s, skip);
+                    if (prof && q == nqi - 1 && !prefilter) (void)hipEventRecord(p->ev[3], s);
                     // the search's last select also writes the k results (redone queries overwrite them below)
                     launch_select(sc.cs, sc.d_slots + q, 1, k, 0u, s, false, (uint32_t)std::min<int64_t>(k, p->n), &em);
                     return;
@@ -573,7 +604,16 @@ int lb_gpu_pq_search_device(lb_gpu_pq *p, int64_t nq, const float *d_queries, in
         for (int q = 0; q < nqi; q++)
             if (sc.h_flags[q] & 1u) scan_query(q, 2); // chunks that cannot overflow the list
         LB_LAUNCH_CHECK();
+        if (prof) LBP_HIP(hipEventRecord(p->ev[1], s));
         LBP_HIP(hipStreamSynchronize(s));
+        if (prof) {
+            float a = 0.f, b = 0.f;
+            if (samp_count && hipEventElapsedTime(&a, p->ev[2], p->ev[3]) != hipSuccess) a = 0.f;
+            if (hipEventElapsedTime(&b, p->ev[0], p->ev[1]) != hipSuccess) b = 0.f;
+            (void)hipGetLastError();
+            p->prof_ms[0] = a;
+            p->prof_ms[1] = b;
+        }
         release_scratch(p, std::move(scp));
     } catch (const HipErrP &e) {
         return pq_fail(p, e);

@@ -141,6 +141,15 @@ class PQEncoder:
         _lib.check(self._lib.lb_gpu_pq_search_device(self._h, nq, d_queries, k, d_dist, d_labels, stream),
                    self._h, pq=True)
 
+    def set_profiling(self, on):
+        _lib.check(self._lib.lb_gpu_pq_set_profiling(self._h, 1 if on else 0), self._h, pq=True)
+
+    def last_timing(self):
+        """(ms of the last query's pass over the codes, ms of the whole search on the device)"""
+        ms = (C.c_float * 2)()
+        _lib.check(self._lib.lb_gpu_pq_last_timing(self._h, ms), self._h, pq=True)
+        return float(ms[0]), float(ms[1])
+
     def Close(self):
         if self._h:
             self._lib.lb_gpu_pq_free(self._h)
