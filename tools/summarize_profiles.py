@@ -8,7 +8,7 @@ usage: python tools/summarize_profiles.py r01"""
 import csv, glob, json, os, sys
 from collections import defaultdict
 
-R = sys.argv[1] if len(sys.argv) > 1 else "r01"
+R = sys.argv[1] if len(sys.argv) > 1 else "r02"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", f"prof_{R}")
 DST = os.path.join(ROOT, "profiles")
@@ -28,7 +28,7 @@ f = find("stats", "kernel_stats.csv")
 if f:
     rows = list(csv.reader(open(f)))
     with open(os.path.join(DST, f"{R}_kernel_stats_bench.csv"), "w", newline="") as o:
-        csv.writer(o, quoting=csv.QUOTE_NONNUMERIC).writerows(rows[:16])
+        csv.writer(o, quoting=csv.QUOTE_NONNUMERIC).writerows(rows[:40])
     print("kernel stats ->", f"{R}_kernel_stats_bench.csv")
 
 
@@ -101,3 +101,52 @@ if f:
                        f"LDS bank conflict cycles = {int(c.get('SQ_LDS_BANK_CONFLICT', 0))}")
         open(os.path.join(DST, f"{R}_pmc_sq_gemm.txt"), "w").write("\n".join(out) + "\n")
         print("sq ->", f"{R}_pmc_sq_gemm.txt")
+
+
+# ---- PQ / ADC kernels (config 4): stats + SQ counters + traffic of the code-pass kernels
+f = find("pq_stats", "kernel_stats.csv")
+if f:
+    rows = list(csv.reader(open(f)))
+    with open(os.path.join(DST, f"{R}_kernel_stats_pq.csv"), "w", newline="") as o:
+        csv.writer(o, quoting=csv.QUOTE_NONNUMERIC).writerows(rows[:20])
+    print("pq kernel stats ->", f"{R}_kernel_stats_pq.csv")
+out = ["# tools/bench_pq.py 100 1 (100M x m=96 codes, k=100, B=1) under rocprofv3 --pmc (kernel-trace only), one counter group per run.",
+       "# Per-dispatch medians over the launches of each code-pass kernel; SQ_* are summed over the chip by rocprofv3.",
+       "# adc_prefilter_kernel = byte-table pass (ds_read_u8 gathers); adc_scan_dma_kernel = exact f32-table pass (ds_read_b32 gathers)."]
+for sub in ("pq_sq1", "pq_sq2", "pq_fetch"):
+    f = find(sub, "counter_collection.csv")
+    if not f:
+        continue
+    acc = defaultdict(lambda: defaultdict(dict))
+    dur = defaultdict(dict)
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])
+        if "adc_prefilter_kernel" not in k and "adc_scan_dma_kernel" not in k:
+            continue
+        d = int(r["Dispatch_Id"])
+        acc[k][r["Counter_Name"]][d] = acc[k][r["Counter_Name"]].get(d, 0.0) + float(r["Counter_Value"])
+        dur[k][d] = int(r.get("End_Timestamp", 0) or 0) - int(r.get("Start_Timestamp", 0) or 0)
+    for k in sorted(acc):
+        big = {d: t for d, t in dur[k].items() if t > 500_000}  # the full passes (skipped launches return at once)
+        if not big:
+            continue
+        ds = sorted(big, key=lambda d: big[d])
+        med = ds[len(ds) // 2]
+        out.append(f"[{sub}] {k}: {len(big)} full passes, median duration {big[med]} ns")
+        for c in sorted(acc[k]):
+            v = acc[k][c].get(med, 0.0)
+            extra = ""
+            if c == "FETCH_SIZE":
+                extra = f"  -> {v * 1024 * 2 / 1e9:.3f} GB corrected (x2, gfx950) vs 9.600 GB algorithmic"
+            out.append(f"    {c} = {int(v)}{extra}")
+        c = {n: acc[k][n].get(med, 0.0) for n in acc[k]}
+        if "SQ_LDS_IDX_ACTIVE" in c and "SQ_LDS_BANK_CONFLICT" in c and big[med] > 0:
+            # LDS array cycles per CU = IDX_ACTIVE / 256; the kernel's duration in shader cycles at ~2.4 GHz
+            per_cu = c["SQ_LDS_IDX_ACTIVE"] / 256.0
+            out.append(f"    derived: LDS-array cycles per CU = {per_cu:.3e} = {per_cu / 2.4e9 * 1e3:.3f} ms at 2.4 GHz of a {big[med] / 1e6:.3f} ms pass "
+                       f"({per_cu / 2.4e9 * 1e9 / big[med] * 100:.0f} % busy); conflict share of LDS cycles = {c['SQ_LDS_BANK_CONFLICT'] / max(c['SQ_LDS_IDX_ACTIVE'], 1):.2f}")
+        if "SQ_INSTS_LDS" in c and "SQ_INSTS_VALU" in c:
+            out.append(f"    derived: per 64-row tile: {c['SQ_INSTS_LDS'] / (1e8 / 64):.0f} LDS instructions, {c['SQ_INSTS_VALU'] / (1e8 / 64):.0f} VALU instructions")
+if len(out) > 3:
+    open(os.path.join(DST, f"{R}_pmc_pq.txt"), "w").write("\n".join(out) + "\n")
+    print("pq counters ->", f"{R}_pmc_pq.txt")
