@@ -70,7 +70,9 @@ const char *lb_gpu_status_string(int status);
 #define LB_MAX_DIM 8192
 lb_gpu_index *lb_gpu_index_new(int device, int dim, int metric, int *out_status);
 
-/* Close (faiss_gpu.go:147-167): frees HBM; idempotent on NULL. */
+/* Close (faiss_gpu.go:147-167): frees HBM; idempotent on NULL.  Must not race with any other call on the same
+ * handle: the caller's lock orders Close after the last Add / Search (the Go shim's RWMutex does, as
+ * faiss_gpu.go:148 does); a call on a freed handle is a use-after-free like with any C handle. */
 void lb_gpu_index_free(lb_gpu_index *h);
 
 /* Text of the last failure on this handle ("" if none).  Valid until the next

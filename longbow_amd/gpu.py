@@ -72,9 +72,9 @@ class Index:
         with self._lock:
             if self._closed:
                 return
-            self._lib.lb_gpu_index_free(self._h)
-            self._h = None
+            h, self._h = self._h, None  # no other thread may be inside a call on this index (as for the C handle)
             self._closed = True
+            self._lib.lb_gpu_index_free(h)
 
     # -- superset ----------------------------------------------------------------
     def SearchBatch(self, queries, k):
