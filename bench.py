@@ -442,6 +442,40 @@ def main():
                 idx.set_candidate_mode(0)
             except Exception:
                 pass
+        # the same contraction with the f32 operands split in registers: no second corpus image
+        try:
+            idx.set_candidate_mode(2)
+            for _ in range(2):
+                step()
+            idx.set_profiling(True)
+            f_ms, f_fb = 0.0, 0
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+                f_ms += idx.last_timing()["gemm"][0]
+                f_fb += idx.last_fallbacks
+            torch.cuda.synchronize(dev)
+            f_el = time.perf_counter() - t1
+            idx.set_profiling(False)
+            labf, ddf = step()
+            same = bool(np.array_equal(labf.cpu().numpy(), lab_h) and np.array_equal(ddf.cpu().numpy(), dist_h))
+            ach = 3.0 * flops_per_step * args.steps / (f_ms * 1e-3) / 1e12 if f_ms > 0 else 0.0
+            result["split_bf16_in_registers"] = {
+                "value": round(B * args.steps / f_el, 1), "unit": "queries/s", "ms_per_step": round(1e3 * f_el / args.steps, 4),
+                "results_identical_to_f32_mode": same, "fallback_queries": int(f_fb), "extra_hbm_bytes": 0,
+                "roofline": {"bound": "mfma", "kernel": "gemm_filter_kernel<split in registers>", "achieved": round(ach, 1),
+                             "peak": 2500.0, "unit": "TFLOP/s (bf16, 3 MFMA passes counted)", "frac": round(ach / 2500.0, 4),
+                             "kernel_ms_per_step": round(f_ms / args.steps, 4)},
+                "note": "opt-in lb_gpu_index_set_candidate_mode(2): as split_bf16_candidates but the f32 tiles are split to bf16 "
+                        "hi/lo after the LDS read -- no second copy of the corpus"}
+        except Exception as e:
+            result["split_bf16_in_registers"] = {"error": str(e)}
+        finally:
+            try:
+                idx.set_candidate_mode(0)
+            except Exception:
+                pass
 
     if single:
         # ---- p50 single-query latency (the DoExchange path is single-query) ------------------------

@@ -87,8 +87,10 @@ int lb_gpu_index_set_order(lb_gpu_index *h, int order);
  * re-done by the exact scan):
  *   LB_CAND_F32_MFMA   (default) q.x on the f32 MFMA (v_mfma_f32_32x32x2_f32)
  *   LB_CAND_SPLIT_BF16 q.x as hi*hi + hi*lo + lo*hi on the bf16 MFMA over a split image of the corpus
- *                      (x = hi + lo + O(2^-18)); costs a second N*dim*4-byte copy in HBM; dim % 32 == 0. */
-typedef enum { LB_CAND_F32_MFMA = 0, LB_CAND_SPLIT_BF16 = 1 } lb_candidate_mode;
+ *                      (x = hi + lo + O(2^-18)); costs a second N*dim*4-byte copy in HBM; dim % 32 == 0.
+ *   LB_CAND_SPLIT_BF16_INREG the same contraction with BOTH f32 operands split into bf16 pairs in registers after
+ *                      the LDS read: no second copy.  (Batches of 5..384 queries always run this way.) */
+typedef enum { LB_CAND_F32_MFMA = 0, LB_CAND_SPLIT_BF16 = 1, LB_CAND_SPLIT_BF16_INREG = 2 } lb_candidate_mode;
 int lb_gpu_index_set_candidate_mode(lb_gpu_index *h, int mode);
 int64_t lb_gpu_index_ntotal(const lb_gpu_index *h);
 int lb_gpu_index_dim(const lb_gpu_index *h);

@@ -561,11 +561,15 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     if (!light_sample) launch_init_cand(w->cs, nullptr, nq, s);
     if (metric == LB_METRIC_COSINE && !norm_riders) launch_query_norms(order, d_q, nullptr, nq, h->dim, w->d_qna, s);
     // candidate contraction: exact f32 MFMA, or 3 x bf16 MFMA on the split images
-    const bool split = h->cand_mode.load() == 1 && h->d_Xs != nullptr && h->xs_rows == h->n && h->dim % 32 == 0;
+    const int cmode = h->cand_mode.load();
+    // 1: pre-split bf16 image of the corpus; 2: f32 operands split in registers (no image)
+    const int split = (cmode == 1 && h->d_Xs != nullptr && h->xs_rows == h->n && h->dim % 32 == 0) ? 1
+                      : (cmode == 2 && narrow_ok) ? 2 : 0;
     const float *gx = h->d_X, *gq = d_q;
     const float u24 = 5.9604645e-8f;
     float gamma = 1.05f * (float)(h->dim + 8) * u24; // k-ordered f32 fma chain of length D
-    if (split) {
+    if (split == 2) gamma = 1.05f * ((float)(3 * h->dim / 16 + 24) * u24 + 3.0f * 3.8146973e-6f);
+    if (split == 1) {
         const size_t need = (size_t)nq * h->dim * sizeof(float);
         if (w->d_qs_bytes < need) {
             if (w->d_qs) (void)hipFree(w->d_qs);
@@ -591,7 +595,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     static const double kCost64 = lb_tunable("LB_COST64_US", nsplit_on ? 560 : 800) * 1e-3;
     const int tiles_n = (nq + 31) / 32, tiles_64 = (nq + 63) / 64, tiles_w = (nq + 127) / 128;
     const double c32 = (nq <= 32 || tiles_n <= 10) ? kCost32 * tiles_n : 1e9, c64 = kCost64 * tiles_64, cw = 1.49 * tiles_w;
-    const bool narrow_allowed = !split && narrow_ok && nq <= narrow_max;
+    const bool narrow_allowed = split != 1 && narrow_ok && nq <= narrow_max;
     bool use_narrow = narrow_allowed && (nq <= 32 || std::min(c32, c64) < cw);
     bool tile64 = use_narrow && nq > 32 && c64 <= c32;
     if (force64 == 0) { tile64 = false; use_narrow = narrow_allowed && (nq <= 32 || c32 < cw); }
@@ -1096,10 +1100,10 @@ int lb_gpu_index_set_order(lb_gpu_index *h, int order)
 
 int lb_gpu_index_set_candidate_mode(lb_gpu_index *h, int mode)
 {
-    if (!h || (mode != 0 && mode != 1)) return LB_ERR_INVALID_ARG;
+    if (!h || (mode != 0 && mode != 1 && mode != 2)) return LB_ERR_INVALID_ARG;
     std::unique_lock<std::shared_mutex> g(h->mu);
     if (h->closed) return LB_ERR_CLOSED;
-    if (mode == 1 && h->dim % 32 != 0) {
+    if (mode != 0 && h->dim % 32 != 0) {
         h->set_error("split-bf16 candidates need dim %% 32 == 0 (dim = %d)", h->dim);
         return LB_ERR_UNSUPPORTED;
     }

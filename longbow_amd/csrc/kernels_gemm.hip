@@ -82,7 +82,7 @@ __device__ __forceinline__ f32x4 load_chunk(const float *base, int64_t row, int 
 // 2^-18|x|).  The inner product is then hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (exact
 // bf16 products, f32 accumulation): ~f32-accurate candidate keys at 3/16 of the f32 MFMA cycles.
 // Staging, LDS image and epilogue are shared with the f32 kernel (same bytes per row and K-step).
-template <int METRIC, int ALIGNED, int ABL = 0, bool GLDS = false, bool SPLIT = false>
+template <int METRIC, int ALIGNED, int ABL = 0, bool GLDS = false, int SPLIT = 0>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_filter_kernel(GemmArgs a)
 {
     // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so the
@@ -247,7 +247,39 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_filter_kernel(GemmArgs a
         }
         const float *As = lds[cur][0];
         const float *Bs = lds[cur][1];
-        if (SPLIT) {
+        if (SPLIT == 2) {
+            // split in registers (as gemm_filter_narrow_kernel<.., SPLIT>): the LDS image is plain f32; MFMA k-step ks
+            // covers floats [16 ks, 16 ks + 16) of the K-step, lane half h supplies 8 of them = two 16-B chunks
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                const int ch = 4 * ks + 2 * h;
+                bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const int ra_ = wr * 64 + t * 32 + l31, rb_ = wc * 64 + t * 32 + l31;
+                    const f32x4 a0 = *reinterpret_cast<const f32x4 *>(&As[swz_off(ra_, ch)]), a1 = *reinterpret_cast<const f32x4 *>(&As[swz_off(ra_, ch + 1)]);
+                    const f32x4 b0 = *reinterpret_cast<const f32x4 *>(&Bs[swz_off(rb_, ch)]), b1 = *reinterpret_cast<const f32x4 *>(&Bs[swz_off(rb_, ch + 1)]);
+                    const float xa[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                    const float xb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const __bf16 ha = (__bf16)xa[i], hb = (__bf16)xb[i];
+                        ah[t][i] = ha;
+                        al[t][i] = (__bf16)(xa[i] - (float)ha);
+                        bh[t][i] = hb;
+                        bl[t][i] = (__bf16)(xb[i] - (float)hb);
+                    }
+                }
+#pragma unroll
+                for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+                    for (int tn = 0; tn < 2; tn++) {
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+                    }
+            }
+        } else if (SPLIT == 1) {
             // chunk c of a row's 128-B piece: c = 0..3 -> hi k-blocks (8 k each), c = 4..7 -> lo k-blocks.
             // For the 16-k step ks, lane half h supplies k-block 2*ks + h (the MFMA's k = 8h + j).
             bf16x8 ah[2][2], al[2][2], bh[2][2], bl[2][2]; // [buffer][tile]
@@ -498,7 +530,7 @@ int g_gemm_ablation = 0; // profiling aid (diagnostic build only); always 0 in t
 
 void launch_gemm_filter(int metric, const float *X, const float *norm2, const float *rnorm,
                         int64_t row_begin, int64_t row_end, int D, const float *Q, int nq,
-                        const uint8_t *mask, const uint32_t *rowmap, CandState cs, bool boot, bool split,
+                        const uint8_t *mask, const uint32_t *rowmap, CandState cs, bool boot, int split,
                         hipStream_t s)
 {
     if (row_end <= row_begin || nq <= 0) return;
@@ -516,19 +548,19 @@ void launch_gemm_filter(int metric, const float *X, const float *norm2, const fl
                          ((reinterpret_cast<uintptr_t>(Q) & 15) == 0);
     const int mode = !aligned ? 0 : (D % BK == 0 ? 2 : 1);
 #ifdef LB_DIAG // timing-only ablations and the clock probe exist only in the diagnostic build
-    if (split && g_gemm_ablation > 0 && metric == METRIC_COS) {
+    if (split == 1 && g_gemm_ablation > 0 && metric == METRIC_COS) {
         switch (g_gemm_ablation) {
-        case 1: hipLaunchKernelGGL((gemm_filter_kernel<METRIC_COS, 2, 1, true, true>), grid, dim3(GEMM_THREADS), 0, s, a); return;
-        case 2: hipLaunchKernelGGL((gemm_filter_kernel<METRIC_COS, 2, 2, true, true>), grid, dim3(GEMM_THREADS), 0, s, a); return;
-        case 5: hipLaunchKernelGGL((gemm_filter_kernel<METRIC_COS, 2, 5, true, true>), grid, dim3(GEMM_THREADS), 0, s, a); return;
-        case 6: hipLaunchKernelGGL((gemm_filter_kernel<METRIC_COS, 2, 6, true, true>), grid, dim3(GEMM_THREADS), 0, s, a); return;
+        case 1: hipLaunchKernelGGL((gemm_filter_kernel<METRIC_COS, 2, 1, true, 1>), grid, dim3(GEMM_THREADS), 0, s, a); return;
+        case 2: hipLaunchKernelGGL((gemm_filter_kernel<METRIC_COS, 2, 2, true, 1>), grid, dim3(GEMM_THREADS), 0, s, a); return;
+        case 5: hipLaunchKernelGGL((gemm_filter_kernel<METRIC_COS, 2, 5, true, 1>), grid, dim3(GEMM_THREADS), 0, s, a); return;
+        case 6: hipLaunchKernelGGL((gemm_filter_kernel<METRIC_COS, 2, 6, true, 1>), grid, dim3(GEMM_THREADS), 0, s, a); return;
         default: break;
         }
     }
     static const int env_abl = lb_tunable("LB_GEMM_ABL", 0);
     if (env_abl > 0 && g_gemm_ablation == 0) g_gemm_ablation = env_abl;
     if (!split && g_gemm_ablation == 8 && metric == METRIC_COS && mode == 2) { // A/B: default cache policy on the corpus stream
-        hipLaunchKernelGGL((gemm_filter_kernel<METRIC_COS, 2, 8, true, false>), grid, dim3(GEMM_THREADS), 0, s, a);
+        hipLaunchKernelGGL((gemm_filter_kernel<METRIC_COS, 2, 8, true, 0>), grid, dim3(GEMM_THREADS), 0, s, a);
         return;
     }
     if (!split && g_gemm_ablation > 0 && metric == METRIC_COS && mode == 2) {
@@ -556,11 +588,18 @@ void launch_gemm_filter(int metric, const float *X, const float *norm2, const fl
     // direct-to-LDS staging is the default for the aligned, D % 32 == 0 case (LB_GEMM_GLDS=0 or
     // g_gemm_glds = -1 selects the register-staged pipeline for A/B runs)
     static const bool env_noglds = lb_tunable("LB_GEMM_GLDS", 1) == 0;
-    if (split) {
+    if (split == 1) {
         // X / Q are split-bf16 images (caller guarantees D % 32 == 0 and 16-B alignment)
-        if (metric == METRIC_L2) hipLaunchKernelGGL((gemm_filter_kernel<METRIC_L2, 2, 0, true, true>), grid, dim3(GEMM_THREADS), 0, s, a);
-        else if (metric == METRIC_COS) hipLaunchKernelGGL((gemm_filter_kernel<METRIC_COS, 2, 0, true, true>), grid, dim3(GEMM_THREADS), 0, s, a);
-        else hipLaunchKernelGGL((gemm_filter_kernel<METRIC_DOT, 2, 0, true, true>), grid, dim3(GEMM_THREADS), 0, s, a);
+        if (metric == METRIC_L2) hipLaunchKernelGGL((gemm_filter_kernel<METRIC_L2, 2, 0, true, 1>), grid, dim3(GEMM_THREADS), 0, s, a);
+        else if (metric == METRIC_COS) hipLaunchKernelGGL((gemm_filter_kernel<METRIC_COS, 2, 0, true, 1>), grid, dim3(GEMM_THREADS), 0, s, a);
+        else hipLaunchKernelGGL((gemm_filter_kernel<METRIC_DOT, 2, 0, true, 1>), grid, dim3(GEMM_THREADS), 0, s, a);
+        return;
+    }
+    if (split == 2) {
+        // X / Q are the plain f32 operands, split in registers (D % 32 == 0, 16-B aligned)
+        if (metric == METRIC_L2) hipLaunchKernelGGL((gemm_filter_kernel<METRIC_L2, 2, 0, true, 2>), grid, dim3(GEMM_THREADS), 0, s, a);
+        else if (metric == METRIC_COS) hipLaunchKernelGGL((gemm_filter_kernel<METRIC_COS, 2, 0, true, 2>), grid, dim3(GEMM_THREADS), 0, s, a);
+        else hipLaunchKernelGGL((gemm_filter_kernel<METRIC_DOT, 2, 0, true, 2>), grid, dim3(GEMM_THREADS), 0, s, a);
         return;
     }
     if (g_gemm_glds >= 0 && !env_noglds && g_gemm_ablation == 0 && mode == 2) {

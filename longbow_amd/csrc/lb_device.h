@@ -119,8 +119,8 @@ void launch_row_norms(const float *X, int64_t n, int D, float *norm2, float *rno
 // boot: every row is stored at list[row - row_begin] (no admission test, no atomics).
 void launch_gemm_filter(int metric, const float *X, const float *norm2, const float *rnorm,
                         int64_t row_begin, int64_t row_end, int D, const float *Q, int nq,
-                        const uint8_t *mask, const uint32_t *rowmap, CandState cs, bool boot, bool split,
-                        hipStream_t s);
+                        const uint8_t *mask, const uint32_t *rowmap, CandState cs, bool boot, int split,
+                        hipStream_t s); // split: 0 f32 MFMA, 1 pre-split bf16 images, 2 f32 operands split in registers
 // small/mid-size batches (5..384 queries): 256-row x 32-query tiles, HBM-bound; needs D % 32 == 0, 16-B aligned X/Q
 void launch_gemm_filter_narrow(int metric, const float *X, const float *norm2, const float *rnorm,
                                int64_t row_begin, int64_t row_end, int D, const float *Q, int nq,

@@ -414,6 +414,13 @@ def test_split_bf16_candidates_give_identical_results(oracle, metric):
         oi, od = oracle.search_batch(metric, Q, X, k, nthreads=8)
         assert_same(lab, dist, oi, od, f"split metric={metric} n={n} d={d}")
         fb = idx.last_fallbacks
+        idx.set_candidate_mode(2)          # the same contraction with the operands split in registers (no image)
+        lab2, dist2 = idx.SearchBatch(Q, k)
+        assert np.array_equal(lab2, lab) and np.array_equal(dist2, dist)
+        big = np.concatenate([Q] * (400 // nq + 1))[:400]   # > 384 queries: the 128-query tile in this mode
+        labb, distb = idx.SearchBatch(big, k)
+        assert np.array_equal(labb[:nq], lab) and np.array_equal(distb[:nq], dist)
+        assert np.array_equal(labb[nq:2 * nq], lab[: min(nq, 400 - nq)]) if 2 * nq <= 400 else True
         idx.set_candidate_mode(0)
         lab0, dist0 = idx.SearchBatch(Q, k)
         assert np.array_equal(lab0, lab) and np.array_equal(dist0, dist)
