@@ -84,6 +84,24 @@ class Index {
         return wrap("search", lb_gpu_index_search(h_, nq, queries, k, distances, ids));
     }
 
+    // The distance step of processChunkInternal (internal/store/parallel_search.go:274-364) on rows that are
+    // resident on the GPU: dist[i] as simd.EuclideanDistanceBatchFlat computes it (4-accumulator order),
+    // score[i] = 1/(1+dist[i]).  rows are row positions.
+    Error Rerank(const std::vector<float> &query, const std::vector<int64_t> &rows, std::vector<float> &dist,
+                 std::vector<float> &score)
+    {
+        std::shared_lock<std::shared_mutex> g(mu_);
+        if (closed_) return {LB_ERR_CLOSED, "index is closed"};
+        if ((int)query.size() != dim_)
+            return {LB_ERR_INVALID_ARG, "query vector dimension " + std::to_string(query.size()) +
+                                            " does not match index dimension " + std::to_string(dim_)};
+        dist.assign(rows.size(), 0.f);
+        score.assign(rows.size(), 0.f);
+        if (rows.empty()) return {};
+        return wrap("rerank", lb_gpu_index_rerank(h_, query.data(), rows.data(), (int64_t)rows.size(), LB_ORDER_UNROLL4,
+                                                  dist.data(), score.data()));
+    }
+
     Error Close() // idempotent
     {
         std::unique_lock<std::shared_mutex> g(mu_);
@@ -132,4 +150,145 @@ inline std::pair<Index *, Error> NewIndexWithConfig(const GPUConfig &cfg)
 inline std::pair<Index *, Error> NewIndex() { return NewIndexWithConfig(GPUConfig{}); }
 
 } // namespace gpu
+
+// ---- internal/simd: MetricType, KernelRegistry, dispatch (internal/simd/registry.go:8-124, dispatch.go:264-302) ----
+namespace simd {
+
+enum MetricType { MetricEuclidean = 0, MetricCosine = 1, MetricDotProduct = 2 };
+inline const char *String(MetricType m) // MetricType.String(), registry.go:17-28
+{
+    switch (m) {
+    case MetricEuclidean: return "euclidean";
+    case MetricCosine: return "cosine";
+    case MetricDotProduct: return "dot";
+    default: return "unknown";
+    }
+}
+enum SIMDDataType { DataTypeFloat32 = 0, DataTypeFloat16 = 1 /* ... registry.go:32-47 */ };
+
+// core.DistanceMetric strings (internal/core/enums.go:6-13) and MetricType.String()'s "dot"
+inline bool MetricFromCore(const std::string &name, MetricType &out)
+{
+    if (name == "euclidean" || name.empty()) { out = MetricEuclidean; return true; }
+    if (name == "cosine") { out = MetricCosine; return true; }
+    if (name == "dot_product" || name == "dot") { out = MetricDotProduct; return true; }
+    return false;
+}
+
+// one query x n rows of a flat buffer -> results (simd.EuclideanDistanceBatchFlat's signature, batch_operations.go:64-87)
+using BatchFlatFunc = int (*)(const float *query, const float *flat, int64_t n, int dims, float *results);
+constexpr int BatchFlatDims = -1; // KernelKey.Dims of batch kernels (go/internal/simd/hip_kernels.go)
+
+struct KernelKey {
+    int Metric, DataType, Dims;
+    bool operator<(const KernelKey &o) const
+    {
+        if (Metric != o.Metric) return Metric < o.Metric;
+        if (DataType != o.DataType) return DataType < o.DataType;
+        return Dims < o.Dims;
+    }
+};
+
+// KernelRegistry.Register / Get: exact (metric, type, dims) first, then the generic dims = 0 entry, else null
+class KernelRegistry {
+  public:
+    void Register(MetricType m, SIMDDataType dt, int dims, BatchFlatFunc k)
+    {
+        std::unique_lock<std::shared_mutex> g(mu_);
+        for (auto &e : kernels_)
+            if (!(e.first < KernelKey{m, dt, dims}) && !(KernelKey{m, dt, dims} < e.first)) { e.second = k; return; }
+        kernels_.emplace_back(KernelKey{m, dt, dims}, k);
+    }
+    BatchFlatFunc Get(MetricType m, SIMDDataType dt, int dims) const
+    {
+        std::shared_lock<std::shared_mutex> g(mu_);
+        BatchFlatFunc generic = nullptr;
+        for (const auto &e : kernels_) {
+            if (e.first.Metric != m || e.first.DataType != dt) continue;
+            if (e.first.Dims == dims) return e.second;
+            if (e.first.Dims == 0) generic = e.second;
+        }
+        return generic;
+    }
+
+  private:
+    mutable std::shared_mutex mu_;
+    std::vector<std::pair<KernelKey, BatchFlatFunc>> kernels_;
+};
+
+inline int HIPDevice = 0;
+template <int METRIC>
+inline int hipBatchFlat(const float *q, const float *flat, int64_t n, int dims, float *results)
+{
+    return lb_simd_distance_batch_flat(HIPDevice, METRIC, LB_ORDER_UNROLL4, q, flat, n, dims, results);
+}
+// the registry with the HIP batch kernels plugged in, as go/internal/simd/hip_kernels.go's init() does
+inline KernelRegistry &Registry()
+{
+    static KernelRegistry *r = [] {
+        auto *x = new KernelRegistry();
+        x->Register(MetricEuclidean, DataTypeFloat32, BatchFlatDims, hipBatchFlat<LB_METRIC_EUCLIDEAN>);
+        x->Register(MetricCosine, DataTypeFloat32, BatchFlatDims, hipBatchFlat<LB_METRIC_COSINE>);
+        x->Register(MetricDotProduct, DataTypeFloat32, BatchFlatDims, hipBatchFlat<LB_METRIC_DOT>);
+        return x;
+    }();
+    return *r;
+}
+// DispatchDistance's rule for one query against n rows: 0 = ok, else an lb_status
+inline int DispatchBatchFlat(MetricType m, const float *q, const float *flat, int64_t n, int dims, float *results)
+{
+    BatchFlatFunc k = Registry().Get(m, DataTypeFloat32, BatchFlatDims);
+    if (!k) return LB_ERR_UNSUPPORTED; // "simd: no kernel found"
+    return k(q, flat, n, dims, results);
+}
+
+} // namespace simd
+
+// ---- internal/pq: PQEncoder's query side + codec (internal/pq/encoder.go:76-158, adc_table.go:15-72) ----
+namespace pq {
+
+class PQEncoder {
+  public:
+    PQEncoder(const PQEncoder &) = delete;
+    PQEncoder &operator=(const PQEncoder &) = delete;
+    ~PQEncoder() { if (p_) lb_gpu_pq_free(p_); }
+    // DeserializePQEncoder (persistence.go:38-73) onto the GPU; null + status on error
+    static PQEncoder *Deserialize(const std::vector<uint8_t> &blob, int device, int &status)
+    {
+        lb_gpu_pq *p = lb_gpu_pq_new(device, blob.data(), blob.size(), &status);
+        if (!p) return nullptr;
+        auto *e = new PQEncoder();
+        e->p_ = p;
+        e->M = lb_gpu_pq_m(p);
+        e->Dims = lb_gpu_pq_dims(p);
+        return e;
+    }
+    int Encode(const std::vector<float> &vectors, std::vector<uint8_t> &codes) // n x Dims -> n x M
+    {
+        if (vectors.size() % (size_t)Dims != 0) return LB_ERR_INVALID_ARG; // "vector dimension mismatch"
+        const int64_t n = (int64_t)(vectors.size() / (size_t)Dims);
+        codes.assign((size_t)n * M, 0);
+        return lb_gpu_pq_encode(p_, n, vectors.data(), codes.data());
+    }
+    int Decode(const std::vector<uint8_t> &codes, std::vector<float> &vectors)
+    {
+        if (codes.size() % (size_t)M != 0) return LB_ERR_INVALID_ARG; // "code length mismatch"
+        const int64_t n = (int64_t)(codes.size() / (size_t)M);
+        vectors.assign((size_t)n * Dims, 0.f);
+        return lb_gpu_pq_decode(p_, n, codes.data(), vectors.data());
+    }
+    int BuildADCTable(const std::vector<float> &query, std::vector<float> &table)
+    {
+        if ((int)query.size() != Dims) return LB_ERR_INVALID_ARG; // "query dimension mismatch"
+        table.assign((size_t)M * 256, 0.f);
+        return lb_gpu_pq_build_adc_table(p_, query.data(), table.data());
+    }
+    int M = 0, Dims = 0;
+
+  private:
+    PQEncoder() = default;
+    lb_gpu_pq *p_ = nullptr;
+};
+
+} // namespace pq
 } // namespace longbow

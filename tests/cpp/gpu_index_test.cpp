@@ -8,6 +8,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <string>
 #include <memory>
 #include <random>
 #include <vector>
@@ -155,15 +157,107 @@ static void TestGPUIndex_BatchedMetricsMatchOracle()
     std::printf("ok   TestGPUIndex_BatchedMetricsMatchOracle\n");
 }
 
+// internal/simd/registry.go:94-124: exact dims first, then the generic entry, else nil; metric names
+static int fake_a(const float *, const float *, int64_t, int, float *) { return 101; }
+static int fake_b(const float *, const float *, int64_t, int, float *) { return 102; }
+static void TestSimd_RegistryLookupRule()
+{
+    using namespace longbow::simd;
+    KernelRegistry r;
+    r.Register(MetricEuclidean, DataTypeFloat32, 0, fake_a);
+    r.Register(MetricEuclidean, DataTypeFloat32, 128, fake_b);
+    REQUIRE(r.Get(MetricEuclidean, DataTypeFloat32, 128) == fake_b, "exact match first");
+    REQUIRE(r.Get(MetricEuclidean, DataTypeFloat32, 384) == fake_a, "generic fallback");
+    REQUIRE(r.Get(MetricCosine, DataTypeFloat32, 128) == nullptr, "nil when neither");
+    REQUIRE(r.Get(MetricEuclidean, DataTypeFloat16, 128) == nullptr, "type is part of the key");
+    r.Register(MetricEuclidean, DataTypeFloat32, 128, fake_a);
+    REQUIRE(r.Get(MetricEuclidean, DataTypeFloat32, 128) == fake_a, "re-registering replaces");
+    REQUIRE(Registry().Get(MetricCosine, DataTypeFloat32, BatchFlatDims) != nullptr, "HIP batch kernels registered");
+    REQUIRE(Registry().Get(MetricCosine, DataTypeFloat32, 768) == nullptr, "batch kernels never answer a per-pair lookup");
+    MetricType m;
+    REQUIRE(MetricFromCore("dot_product", m) && m == MetricDotProduct, "core name");
+    REQUIRE(MetricFromCore("dot", m) && m == MetricDotProduct && std::string(String(m)) == "dot", "String()");
+    REQUIRE(MetricFromCore("euclidean", m) && m == MetricEuclidean && !MetricFromCore("manhattan", m), "names");
+    std::printf("ok   TestSimd_RegistryLookupRule\n");
+}
+
+// DispatchBatchFlat through the registry, the re-rank entry and the PQ codec against the oracle
+static void TestSimd_Rerank_PQ_MatchOracle()
+{
+    using namespace longbow;
+    const int n = 4000, d = 64, M = 8;
+    std::mt19937 rng(11);
+    std::uniform_real_distribution<float> u(0.f, 1.f);
+    std::vector<float> X((size_t)n * d), q(d);
+    for (auto &v : X) v = u(rng);
+    for (auto &v : q) v = u(rng);
+    std::vector<float> res(n), want(n);
+    for (int metric = 0; metric < 3; metric++) {
+        REQUIRE(simd::DispatchBatchFlat((simd::MetricType)metric, q.data(), X.data(), n, d, res.data()) == LB_OK, "dispatch %d", metric);
+        lbo_batch_flat(metric, 1, q.data(), X.data(), n, d, want.data());
+        for (int i = 0; i < n; i++) {
+            const float w = metric == 2 ? -want[i] : want[i]; // the simd kernels return the RAW dot product
+            REQUIRE(res[i] == w, "metric %d row %d: %.9g vs %.9g", metric, i, res[i], w);
+        }
+    }
+    auto [raw, err] = NewIndexWithConfig(GPUConfig{0, d});
+    REQUIRE(!err, "%s", err.message.c_str());
+    std::unique_ptr<Index> idx(raw);
+    std::vector<int64_t> ids(n);
+    for (int i = 0; i < n; i++) ids[i] = i;
+    REQUIRE(!idx->Add(ids, X), "add");
+    std::vector<int64_t> rows = {5, 0, 3999, 17, 17, -1, 4000};
+    std::vector<float> dist, score;
+    err = idx->Rerank(q, rows, dist, score);
+    REQUIRE(!err, "%s", err.message.c_str());
+    lbo_batch_flat(0, 1, q.data(), X.data(), n, d, want.data());
+    for (size_t i = 0; i < 5; i++) {
+        REQUIRE(dist[i] == want[(size_t)rows[i]], "rerank row %lld", (long long)rows[i]);
+        REQUIRE(score[i] == 1.0f / (1.0f + dist[i]), "score");
+    }
+    REQUIRE(dist[5] == 3.402823466e+38f && score[5] == 0.f && dist[6] == 3.402823466e+38f, "rows outside the index");
+    // PQ: blob (persistence.go:9-35) -> Encode / Decode / BuildADCTable
+    const int sub = d / M;
+    std::vector<float> cb((size_t)M * 256 * sub);
+    for (auto &v : cb) v = u(rng);
+    std::vector<uint8_t> blob(12 + cb.size() * 4);
+    const uint32_t hdr[3] = {(uint32_t)d, (uint32_t)M, 256u};
+    std::memcpy(blob.data(), hdr, 12);
+    std::memcpy(blob.data() + 12, cb.data(), cb.size() * 4);
+    int st = 0;
+    std::unique_ptr<pq::PQEncoder> enc(pq::PQEncoder::Deserialize(blob, 0, st));
+    REQUIRE(enc && st == LB_OK, "deserialize %d", st);
+    std::vector<uint8_t> codes, wc(M);
+    std::vector<float> V(X.begin(), X.begin() + 200 * d);
+    REQUIRE(enc->Encode(V, codes) == LB_OK && codes.size() == (size_t)200 * M, "encode");
+    for (int i = 0; i < 200; i++) {
+        lbo_pq_encode(cb.data(), M, 256, sub, V.data() + (size_t)i * d, wc.data());
+        for (int j = 0; j < M; j++) REQUIRE(codes[(size_t)i * M + j] == wc[j], "code %d/%d", i, j);
+    }
+    std::vector<float> dec, wd(d), table, wt((size_t)M * 256);
+    REQUIRE(enc->Decode(codes, dec) == LB_OK, "decode");
+    lbo_pq_decode(cb.data(), M, 256, sub, codes.data(), wd.data());
+    for (int j = 0; j < d; j++) REQUIRE(dec[j] == wd[j], "decode %d", j);
+    REQUIRE(enc->BuildADCTable(q, table) == LB_OK, "table");
+    lbo_build_adc_table(cb.data(), M, 256, sub, q.data(), wt.data());
+    for (size_t j = 0; j < wt.size(); j++) REQUIRE(table[j] == wt[j], "table %zu", j);
+    blob[8] = 16; // K = 16: the encodeSequential branch is not supported -> LB_ERR_UNSUPPORTED (blob size no longer matches: invalid)
+    std::unique_ptr<pq::PQEncoder> bad(pq::PQEncoder::Deserialize(blob, 0, st));
+    REQUIRE(!bad && st != LB_OK, "K != 256 must be refused");
+    std::printf("ok   TestSimd_Rerank_PQ_MatchOracle\n");
+}
+
 int main()
 {
     TestGPUIndex_InvalidDimension(); // needs no device
+    TestSimd_RegistryLookupRule();   // host logic only
     bool skipped = false;
     TestGPUIndex_Basic(skipped);
     if (skipped) return failures ? 1 : 77;
     TestGPUIndex_Validation();
     TestGPUIndex_BenchFixtureMatchesBruteForce();
     TestGPUIndex_BatchedMetricsMatchOracle();
+    TestSimd_Rerank_PQ_MatchOracle();
     if (failures) { std::fprintf(stderr, "%d test(s) failed\n", failures); return 1; }
     std::printf("PASS\n");
     return 0;

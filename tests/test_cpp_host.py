@@ -31,6 +31,7 @@ def test_cpp_mirror_compiles_and_validates_without_a_device(tmp_path):
     exe = _build(tmp_path)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert "ok   TestGPUIndex_InvalidDimension" in r.stdout, r.stdout + r.stderr
+    assert "ok   TestSimd_RegistryLookupRule" in r.stdout, r.stdout + r.stderr
     assert r.returncode in (0, SKIP_RC), r.stdout + r.stderr
     if r.returncode == SKIP_RC:
         assert "GPU support not enabled in this build" in r.stdout
@@ -44,5 +45,5 @@ def test_cpp_mirror_matches_reference_tests_and_oracle_on_gpu(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
     for name in ("TestGPUIndex_Basic", "TestGPUIndex_Validation", "TestGPUIndex_BenchFixtureMatchesBruteForce",
-                 "TestGPUIndex_BatchedMetricsMatchOracle"):
+                 "TestGPUIndex_BatchedMetricsMatchOracle", "TestSimd_RegistryLookupRule", "TestSimd_Rerank_PQ_MatchOracle"):
         assert f"ok   {name}" in r.stdout, r.stdout
