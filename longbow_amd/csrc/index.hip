@@ -113,6 +113,8 @@ struct HostStage {
 // hipMemMap).  Appending never copies the rows already resident and never needs old + new at once, so an
 // index can grow to fill the 288 GB.  If the driver refuses any of the calls the index falls back to
 // geometric hipMalloc + copy (vmm.ok == false).
+std::atomic<int> g_vmm_fail_next{0}; // test hook: the next mapping attempt reports a driver refusal
+
 struct VmmBuf {
     bool ok = false;
     int device = 0;
@@ -147,6 +149,7 @@ struct VmmBuf {
     {
         if (need <= mapped) return;
         if (need > reserved) throw lb::HipErr{hipErrorOutOfMemory, "corpus larger than the device"};
+        if (g_vmm_fail_next.exchange(0)) throw lb::HipErr{hipErrorInvalidValue, "hipMemSetAccess (forced by the test hook)"};
         // geometric steps (at least the request, at least what is mapped already, at most 1 GiB beyond the
         // request): small indexes stay small, 288 GB take ~300 handles
         size_t want = need - mapped;
@@ -1387,6 +1390,7 @@ int lb_gpu_index_last_timing(const lb_gpu_index *hc, float ms[5], int n_launch[5
 
 // Test hooks (both settings are exact; they only choose between two schedules / expose host logic).
 void lb_debug_set_sample_tau(int v) { g_sample_tau.store(v); } // 0: classic bootstrap schedule only
+void lb_debug_vmm_fail_next(int v) { g_vmm_fail_next.store(v); } // the next in-place growth is refused (-> hipMalloc + copy)
 void lb_debug_set_add_register_min(long long bytes) { g_add_register_min.store(bytes); } // ingest A/B (tools/bench_add.py)
 // host-only: the sampled-threshold plan for a view of n rows (tests check its invariants without a GPU);
 // out = {on, span, count, m}

@@ -431,3 +431,33 @@ def test_split_bf16_candidates_give_identical_results(oracle, metric):
     with pytest.raises(gpu.LongbowGPUError):
         idx.set_candidate_mode(1)
     idx.Close()
+
+
+def test_growth_survives_a_refused_mapping(oracle):
+    """the corpus grows in place through the virtual-memory API; when the driver refuses to extend the mapping
+    (forced here) the rows move once into a hipMalloc buffer and the index keeps working, ids and all"""
+    gpu_or_skip()
+    import ctypes as C
+    from longbow_amd import _lib
+    lib = _lib.load()
+    lib.lb_debug_vmm_fail_next.argtypes = [C.c_int]
+    rng = np.random.default_rng(31)
+    d, k = 48, 15
+    X = rng.random((9000, d), dtype=F)
+    ids = np.arange(9000, dtype=np.int64) * 3 + 7
+    Q = rng.random((6, d), dtype=F)
+    idx = new_index(d, 0)
+    idx.Add(ids[:1000], X[:1000])
+    try:
+        lib.lb_debug_vmm_fail_next(1)
+        idx.reserve(700_000)                      # needs more than what is mapped: refused -> migrate
+    finally:
+        lib.lb_debug_vmm_fail_next(0)
+    idx.Add(ids[1000:5000], X[1000:5000])         # geometric hipMalloc growth from here on
+    idx.Add(ids[5000:], X[5000:])
+    assert idx.ntotal == 9000
+    for qs in (Q[:1], Q):
+        lab, dist = idx.SearchBatch(qs, k)
+        oi, od = oracle.search_batch(0, qs, X, k, ids=ids)
+        assert_same(lab, dist, oi, od, "after the forced migration")
+    idx.Close()
