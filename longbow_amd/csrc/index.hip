@@ -53,6 +53,7 @@ struct Workspace {
     int *d_qsel = nullptr;
     int *d_iota = nullptr;       // [nq_cap] 0,1,2,...: the slot list of "every query", filled once
     uint32_t *d_smap = nullptr;  // [cap] sampled rows of the first pass
+    uint32_t *d_done = nullptr;  // [nq_cap] arrival tickets of the split re-rank (zero between launches)
     uint32_t *h_flags = nullptr; // pinned
     int *h_qsel = nullptr;       // pinned
     // host-API staging (device side)
@@ -77,6 +78,7 @@ struct Workspace {
         if (d_qsel) (void)hipFree(d_qsel);
         if (d_iota) (void)hipFree(d_iota);
         if (d_smap) (void)hipFree(d_smap);
+        if (d_done) (void)hipFree(d_done);
         if (h_flags) (void)hipHostFree(h_flags);
         if (h_qsel) (void)hipHostFree(h_qsel);
         if (d_q) (void)hipFree(d_q);
@@ -301,6 +303,8 @@ std::unique_ptr<Workspace> acquire_ws(lb_gpu_index *h, int nq, uint32_t cap)
     LB_HIP(hipMalloc(&w->cs.cnt, (size_t)w->nq_cap * sizeof(uint32_t)));
     LB_HIP(hipMalloc(&w->cs.tau, (size_t)w->nq_cap * sizeof(uint64_t)));
     LB_HIP(hipMalloc(&w->cs.flags, (size_t)w->nq_cap * sizeof(uint32_t)));
+    LB_HIP(hipMalloc(&w->d_done, (size_t)w->nq_cap * sizeof(uint32_t)));
+    LB_HIP(hipMemset(w->d_done, 0, (size_t)w->nq_cap * sizeof(uint32_t)));
     LB_HIP(hipMalloc(&w->cs.stripes, (size_t)kScanMaxQ * LB_STRIPES * LB_STRIPE_PAD * sizeof(uint32_t)));
     LB_HIP(hipMalloc(&w->d_qna, (size_t)w->nq_cap * sizeof(float)));
     LB_HIP(hipMalloc(&w->d_qsel, (size_t)w->nq_cap * sizeof(int)));
@@ -559,7 +563,8 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     // up to 8 queries the sample is scored by the wave-per-row kernel (candidate keys; 22-28 us against
     // 44 us for 8192 rows through the 32-workgroup MFMA launch); larger batches sample through the MFMA
     // kernel itself.  Up to 64 queries the exact query norms ride in the threshold launch.
-    const bool light_sample = sp.on && nq <= 8;
+    static const int light_max = lb_tunable("LB_LIGHT_SAMPLE_MAXQ", 8);
+    const bool light_sample = sp.on && nq <= light_max;
     const bool norm_riders = sp.on && nq <= 64 && metric == LB_METRIC_COSINE;
     if (!light_sample) launch_init_cand(w->cs, nullptr, nq, s);
     if (metric == LB_METRIC_COSINE && !norm_riders) launch_query_norms(order, d_q, nullptr, nq, h->dim, w->d_qna, s);
@@ -671,7 +676,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     {
         ProfScope p(w, s, prof, 2);
         launch_rerank(metric, order, h->d_X, h->dim, d_q, nq, w->d_qna, w->cs, kc, k, h->d_maxnorm2, gamma,
-                      h->has_ids ? h->d_ids : nullptr, d_dist, d_lab, s, w->h_flags);
+                      h->has_ids ? h->d_ids : nullptr, d_dist, d_lab, s, w->h_flags, w->d_done);
     }
     std::vector<int> bad;
     if (collect_flagged(w, s, nq, 3u | 4u, nullptr, 0, bad, /*on_host=*/true) > 0) {

@@ -12,6 +12,7 @@
 #include "lb_device.h"
 
 #include <float.h>
+#include <algorithm>
 
 #pragma clang fp contract(off)
 
@@ -405,6 +406,7 @@ struct RerankArgs {
     int64_t *out_labels;
     int aligned;
     uint32_t *flags_host; // pinned host copy of the slots' status words (no D2H copy after the batch), or null
+    uint32_t *done;       // [nq] arrival tickets of rerank_split_kernel (zero between launches), or null
 };
 
 // Shared tail of the re-rank kernels: containment check, final (distance,row) ordering, output.
@@ -692,13 +694,182 @@ __global__ __launch_bounds__(SEL_THREADS) void rerank_tiled_kernel(RerankArgs a)
     rerank_finish<METRIC>(a, qi, tid, nc, P, sq, skey, scmp, s_count, s_w, na);
 }
 
+// ---------------------------------------------------------------------------
+// rerank_split_kernel: the same arithmetic again, spread over kc/16 workgroups per query.  A workgroup owns 16
+// candidates: its 256 lanes fetch the 16 rows whole (up to 1024 dims per stage, every 16-B piece in flight at once:
+// ONE memory round trip for D <= 1024 instead of D/64 dependent stages), 16 lanes then walk one row each out of LDS
+// in the reference's order and leave (exact entry, compare value) behind the list; the last workgroup of a query to
+// arrive (ticket counter, reset for the next launch) does the containment check, the final ordering and the output.
+// Measured at 1M x 768, kc = 256: 39 us -> see DESIGN.md for the whole-search effect.
+// LDS: tile f32[16][1028] | q stage f32[1024] | rows u32[16]   (finish: q[Dpad] | keys u64[P] | cmp f32[P] | scalars)
+constexpr int RS_ROWS = 16, RS_SD = 1024, RS_LD = RS_SD + 4;
+
+template <int METRIC, int ORDER>
+__global__ __launch_bounds__(SEL_THREADS) void rerank_split_kernel(RerankArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int s_last;
+    const int qi = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int D = a.D; // D % 4 == 0 and 16-B aligned rows (checked by the launcher)
+    const uint32_t Pmax = next_pow2((uint32_t)a.kc);
+    uint64_t *list = a.cs.lists + (size_t)qi * a.cs.cap;
+    // this workgroup's candidates, fetched beside the count (positions < Pmax <= cap are always readable)
+    const uint64_t my_entry = tid < RS_ROWS ? list[blockIdx.x * RS_ROWS + tid] : 0ull;
+    const uint32_t nc = min(a.cs.cnt[qi], (uint32_t)a.kc);
+    uint64_t *exact = list + Pmax;                                   // [Pmax] exact entries (cap >= 4 kc)
+    float *cmpv = reinterpret_cast<float *>(list + 2 * (size_t)Pmax); // [Pmax] compare values
+    const float na = (METRIC == METRIC_COS) ? a.qna[qi] : 0.f;
+    const uint32_t c0 = blockIdx.x * RS_ROWS;
+
+    if (c0 < nc) { // workgroup-uniform
+        float *tile = reinterpret_cast<float *>(smem);
+        float *qs = tile + RS_ROWS * RS_LD;
+        uint32_t *srow = reinterpret_cast<uint32_t *>(qs + RS_SD);
+        const uint64_t first_entry = __shfl(my_entry, 0); // c0 < nc: lane 0 holds a real candidate
+        if (tid < RS_ROWS) srow[tid] = entry_row(c0 + tid < nc ? my_entry : first_entry);
+        __syncthreads();
+        const float *q = a.Q + (int64_t)qi * D;
+        f32x4 stg[RS_ROWS], stq;
+        auto load_stage = [&](int d0) {
+            const int k = d0 + tid * 4;
+            if (k < D) {
+                stq = *reinterpret_cast<const f32x4 *>(q + k);
+#pragma unroll
+                for (int r = 0; r < RS_ROWS; r++) stg[r] = *reinterpret_cast<const f32x4 *>(a.X + (int64_t)srow[r] * D + k);
+            }
+        };
+        // UNROLL4: the four accumulator chains of a row are independent, so four lanes share a row (lane t owns
+        // chain t: elements 4g + t) and the quad's first lane adds them up in the reference's order; SEQ: one lane per row.
+        constexpr bool QUAD = ORDER == ORDER_UNROLL4;
+        const int myr = QUAD ? (tid >> 2) : tid, myt = QUAD ? (tid & 3) : 0;
+        const bool worker = tid < (QUAD ? 4 * RS_ROWS : RS_ROWS);
+        float a0 = 0.f, b0 = 0.f; // this lane's chain of acc / nb (SEQ: the only chain)
+        load_stage(0);
+        for (int d0 = 0; d0 < D; d0 += RS_SD) {
+            if (d0 + tid * 4 < D) {
+                *reinterpret_cast<f32x4 *>(&qs[tid * 4]) = stq;
+#pragma unroll
+                for (int r = 0; r < RS_ROWS; r++) *reinterpret_cast<f32x4 *>(&tile[r * RS_LD + tid * 4]) = stg[r];
+            }
+            __syncthreads();
+            if (d0 + RS_SD < D) load_stage(d0 + RS_SD); // in flight under the compute below
+            if (worker) {
+                const int nel = min(D, d0 + RS_SD) - d0;
+                const float *xr = &tile[myr * RS_LD];
+                if (QUAD) {
+#pragma unroll 8
+                    for (int e = myt; e < nel; e += 4) {
+                        const float xv = xr[e], qv = qs[e];
+                        if (METRIC == METRIC_COS) b0 = b0 + xv * xv;
+                        if (METRIC == METRIC_L2) {
+                            const float d = qv - xv;
+                            a0 = a0 + d * d;
+                        } else {
+                            a0 = a0 + qv * xv;
+                        }
+                    }
+                } else {
+#pragma unroll 4
+                    for (int g = 0; g < (nel >> 2); g++) {
+                        const f32x4 xv = *reinterpret_cast<const f32x4 *>(&xr[g * 4]);
+                        const f32x4 qv = *reinterpret_cast<const f32x4 *>(&qs[g * 4]);
+                        const float xe[4] = {xv.x, xv.y, xv.z, xv.w}, qe[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            if (METRIC == METRIC_COS) b0 = b0 + xe[u] * xe[u];
+                            if (METRIC == METRIC_L2) {
+                                const float d = qe[u] - xe[u];
+                                a0 = a0 + d * d;
+                            } else {
+                                a0 = a0 + qe[u] * xe[u];
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads(); // the stage is free again
+        }
+        float t = a0, nbt = b0;
+        if (QUAD) { // (s0 + s1) + s2 + s3, as the reference's unrolled loops finish
+            const int base = tid & ~3;
+            const float a1 = __shfl(a0, base + 1), a2 = __shfl(a0, base + 2), a3 = __shfl(a0, base + 3);
+            const float b1 = __shfl(b0, base + 1), b2 = __shfl(b0, base + 2), b3 = __shfl(b0, base + 3);
+            t = a0 + a1;
+            t = t + a2;
+            t = t + a3;
+            nbt = b0 + b1;
+            nbt = nbt + b2;
+            nbt = nbt + b3;
+        }
+        const uint32_t c = c0 + myr;
+        if (worker && myt == 0 && c < nc) {
+            float dist, cmp;
+            if (METRIC == METRIC_L2) {
+                dist = (float)sqrt((double)t);
+                cmp = t; // compare in d^2 space
+            } else if (METRIC == METRIC_COS) {
+                if (D == 0 || na == 0.0f || nbt == 0.0f) dist = 1.0f;
+                else dist = 1.0f - __fdiv_rn(t, (float)sqrt((double)na * (double)nbt));
+                cmp = dist;
+            } else {
+                dist = -t;
+                cmp = dist;
+            }
+            __hip_atomic_store(&exact[c], pack_entry(dist, srow[myr]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&cmpv[c], cmp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // ---- the last workgroup of the query to get here finishes it ----
+    // The results above went out as device-scope (write-through) stores and are read back below with device-scope
+    // loads, so waiting for their acknowledgement orders them before the ticket; a __threadfence() here would write
+    // back the whole per-XCD L2 once per workgroup (measured: 3.3 ms instead of 0.1 at 1024 queries).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t t = atomicAdd(&a.done[qi], 1u);
+        s_last = (t == gridDim.x - 1u) ? 1 : 0;
+        if (s_last) a.done[qi] = 0; // ready for the next launch on this workspace
+    }
+    __syncthreads();
+    if (!s_last) return;
+
+    const uint32_t P = next_pow2(nc > 0 ? nc : 1);
+    const int Dpad = (D + 3) & ~3;
+    float *sq = reinterpret_cast<float *>(smem);
+    uint64_t *skey = reinterpret_cast<uint64_t *>(smem + (size_t)Dpad * 4);
+    float *scmp = reinterpret_cast<float *>(skey + Pmax);
+    unsigned int &s_count = *reinterpret_cast<unsigned int *>(scmp + Pmax);
+    float &s_w = *reinterpret_cast<float *>(scmp + Pmax + 1);
+    if (METRIC != METRIC_COS) { // the containment bound of L2 / dot needs |q|
+        const float *q = a.Q + (int64_t)qi * D;
+        for (int i = tid; i < D; i += SEL_THREADS) sq[i] = q[i];
+    }
+    if (tid == 0) { s_count = 0; s_w = 0.f; }
+    __syncthreads();
+    for (uint32_t c = tid; c < P; c += SEL_THREADS) {
+        uint64_t e = kEntryMax;
+        float cmp = FLT_MAX;
+        if (c < nc) { // written by other workgroups of this launch: read at device scope, not through this CU's L1
+            e = __hip_atomic_load(&exact[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            cmp = __hip_atomic_load(&cmpv[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        skey[c] = e;
+        scmp[c] = cmp;
+        if (c == (uint32_t)a.kc - 1 && c < nc) s_w = cmp; // the candidate with the worst approximate key
+    }
+    __syncthreads();
+    rerank_finish<METRIC>(a, qi, tid, nc, P, sq, skey, scmp, s_count, s_w, na);
+}
+
 void launch_rerank(int metric, int order, const float *X, int D, const float *Q, int nq,
                    const float *qna, CandState cs, int kc, int k, const uint32_t *d_maxnorm2, float gamma,
-                   const int64_t *ids, float *out_dist, int64_t *out_labels, hipStream_t s, uint32_t *flags_host)
+                   const int64_t *ids, float *out_dist, int64_t *out_labels, hipStream_t s, uint32_t *flags_host, uint32_t *done)
 {
     if (nq <= 0) return;
     RerankArgs a;
     a.flags_host = flags_host;
+    a.done = done;
     a.X = X; a.D = D; a.Q = Q; a.qna = qna; a.cs = cs; a.kc = kc; a.k = k;
     a.maxnorm2 = d_maxnorm2; a.gamma = gamma; a.ids = ids; a.out_dist = out_dist; a.out_labels = out_labels;
     a.aligned = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
@@ -706,6 +877,24 @@ void launch_rerank(int metric, int order, const float *X, int D, const float *Q,
     const size_t P = next_pow2_host((uint32_t)kc);
     const size_t shmem = (size_t)Dpad * 4 + P * 8 + P * 4 + 16;
     dim3 grid(nq), block(SEL_THREADS);
+    static const int split_on = lb_tunable("LB_RERANK_SPLIT", 1);
+    // Worth it while the whole launch is one wave of workgroups (a workgroup's life is a chain of ~8 memory round trips,
+    // two resident per CU): 30 vs 38-40 us at 8 queries, 33 vs 40 at 16, level at 32, slower from 64 on (66 vs 42 us).
+    if (a.aligned && D >= 4 && done != nullptr && split_on && cs.cap >= 3u * (uint32_t)P && (size_t)nq * (P / RS_ROWS) <= 256) {
+        const size_t sh_rows = (size_t)RS_ROWS * RS_LD * 4 + RS_SD * 4 + RS_ROWS * 4;
+        const size_t sh3 = std::max(sh_rows, shmem);
+        dim3 grid3((unsigned)(P / RS_ROWS), (unsigned)nq);
+#define LB_RRS(M, O)                                                                \
+    do {                                                                            \
+        allow_big_lds(rerank_split_kernel<M, O>, sh3);                              \
+        hipLaunchKernelGGL((rerank_split_kernel<M, O>), grid3, block, sh3, s, a);   \
+    } while (0)
+        if (metric == METRIC_L2) { if (order == ORDER_UNROLL4) LB_RRS(METRIC_L2, ORDER_UNROLL4); else LB_RRS(METRIC_L2, ORDER_SEQ); }
+        else if (metric == METRIC_COS) { if (order == ORDER_UNROLL4) LB_RRS(METRIC_COS, ORDER_UNROLL4); else LB_RRS(METRIC_COS, ORDER_SEQ); }
+        else { if (order == ORDER_UNROLL4) LB_RRS(METRIC_DOT, ORDER_UNROLL4); else LB_RRS(METRIC_DOT, ORDER_SEQ); }
+#undef LB_RRS
+        return;
+    }
     if (a.aligned && D >= 4) {
         const int Dq = (D + 63) & ~63;
         const size_t sh2 = (size_t)Dq * 4 + SEL_THREADS * 4 + (size_t)SEL_THREADS * RR_LD * 4 + P * 8 + P * 4 + 16;

@@ -167,7 +167,8 @@ void launch_sample_map(const uint32_t *rowmap, int64_t span, uint32_t count, uin
 // gamma: relative rounding-error bound of the candidate inner products (depends on the contraction)
 void launch_rerank(int metric, int order, const float *X, int D, const float *Q, int nq,
                    const float *qna, CandState cs, int kc, int k, const uint32_t *d_maxnorm2, float gamma,
-                   const int64_t *ids, float *out_dist, int64_t *out_labels, hipStream_t s, uint32_t *flags_host = nullptr);
+                   const int64_t *ids, float *out_dist, int64_t *out_labels, hipStream_t s, uint32_t *flags_host = nullptr,
+                   uint32_t *done = nullptr);
 
 // ||q||^2 per selected query slot in the requested accumulation order (cosine).
 void launch_query_norms(int order, const float *Q, const int *qsel, int nsel, int D, float *qna,
