@@ -600,7 +600,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     static const int force64 = lb_tunable("LB_NARROW_TILE64", -1);
     static const bool nsplit_on = lb_tunable("LB_NARROW_SPLIT", 1) != 0;
     static const double kCost32 = lb_tunable("LB_COST32_US", nsplit_on ? 500 : 430) * 1e-3;
-    static const double kCost64 = lb_tunable("LB_COST64_US", nsplit_on ? 560 : 800) * 1e-3;
+    static const double kCost64 = lb_tunable("LB_COST64_US", nsplit_on ? 480 : 800) * 1e-3;
     const int tiles_n = (nq + 31) / 32, tiles_64 = (nq + 63) / 64, tiles_w = (nq + 127) / 128;
     const double c32 = (nq <= 32 || tiles_n <= 10) ? kCost32 * tiles_n : 1e9, c64 = kCost64 * tiles_64, cw = 1.49 * tiles_w;
     const bool narrow_allowed = split != 1 && narrow_ok && nq <= narrow_max;
@@ -608,8 +608,17 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     bool tile64 = use_narrow && nq > 32 && c64 <= c32;
     if (force64 == 0) { tile64 = false; use_narrow = narrow_allowed && (nq <= 32 || c32 < cw); }
     if (force64 == 1 && narrow_allowed && nq > 32) { use_narrow = true; tile64 = true; }
-    const bool nsplit = use_narrow && nsplit_on;
-    if (nsplit) gamma = 1.05f * ((float)(3 * h->dim / 16 + 24) * u24 + 3.0f * 3.8146973e-6f); // as the split image mode
+    bool nsplit = use_narrow && nsplit_on;
+    // Between the 64-query tile's HBM-bound passes and the f32 tile: the 128-query tile with the same in-register
+    // split contraction (0.755 ms per pass at 1M x 768 against 2 x 0.48 for two 64-query passes).
+    static const double kCostWS = lb_tunable("LB_COSTWS_US", 755) * 1e-3;
+    int wsplit = split;
+    if (nsplit && tile64 && split == 0 && kCostWS * tiles_w < c64) {
+        use_narrow = false;
+        nsplit = false;
+        wsplit = 2;
+    }
+    if (nsplit || wsplit == 2) gamma = 1.05f * ((float)(3 * h->dim / 16 + 24) * u24 + 3.0f * 3.8146973e-6f); // as the split image mode
     auto candidates = [&](int64_t b, int64_t e, const uint32_t *rowmap, bool boot) {
         ProfScope p(w, s, prof, 0);
         if (use_narrow)
@@ -617,7 +626,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
                                       w->cs, boot, s, tile64, nsplit);
         else
             launch_gemm_filter(metric, gx, h->d_norm2, h->d_rnorm, b, e, h->dim, gq, nq, mask, rowmap, w->cs,
-                               boot, split, s);
+                               boot, wsplit, s);
     };
     int64_t pos = 0;
     int step = 0;
