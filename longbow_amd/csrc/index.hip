@@ -577,7 +577,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     const float u24 = 5.9604645e-8f;
     float gamma = 1.05f * (float)(h->dim + 8) * u24; // k-ordered f32 fma chain of length D
     if (split == 2) gamma = 1.05f * ((float)(3 * h->dim / 16 + 24) * u24 + 3.0f * 3.8146973e-6f);
-    if (split == 1) {
+    auto split_queries = [&]() { // hi / lo bf16 image of the batch (same bytes as the f32 rows)
         const size_t need = (size_t)nq * h->dim * sizeof(float);
         if (w->d_qs_bytes < need) {
             if (w->d_qs) (void)hipFree(w->d_qs);
@@ -587,6 +587,9 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
             w->d_qs_bytes = need;
         }
         launch_split_bf16(d_q, w->d_qs, nq, h->dim, s);
+    };
+    if (split == 1) {
+        split_queries();
         gx = h->d_Xs;
         gq = w->d_qs;
         // 3D/16 MFMA accumulations + <=16-term block sums, plus the dropped lo*lo / residual terms
@@ -609,21 +612,30 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     if (force64 == 0) { tile64 = false; use_narrow = narrow_allowed && (nq <= 32 || c32 < cw); }
     if (force64 == 1 && narrow_allowed && nq > 32) { use_narrow = true; tile64 = true; }
     bool nsplit = use_narrow && nsplit_on;
-    // Between the 64-query tile's HBM-bound passes and the f32 tile: the 128-query tile with the same in-register
-    // split contraction (0.755 ms per pass at 1M x 768 against 2 x 0.48 for two 64-query passes).
-    static const double kCostWS = lb_tunable("LB_COSTWS_US", 755) * 1e-3;
+    // Between the 64-query tile's HBM-bound passes and the f32 tile: the 256-row x 128-query tile with the same split
+    // contraction, corpus operand split in registers (kernels_gemm_tall.hip; measured at 1M x 768: 0.83 ms for one
+    // query tile, 1.33 for two, 1.85 for three, against 0.48 per 64-query pass).
+    static const double kCostWS0 = lb_tunable("LB_COSTWS0_US", 270) * 1e-3, kCostWS = lb_tunable("LB_COSTWS_US", 535) * 1e-3;
     int wsplit = split;
-    if (nsplit && tile64 && split == 0 && kCostWS * tiles_w < c64) {
+    if (nsplit && tile64 && split == 0 && kCostWS0 + kCostWS * tiles_w < c64) {
         use_narrow = false;
         nsplit = false;
         wsplit = 2;
     }
     if (nsplit || wsplit == 2) gamma = 1.05f * ((float)(3 * h->dim / 16 + 24) * u24 + 3.0f * 3.8146973e-6f); // as the split image mode
+    // the split contraction beyond the narrow tiles runs on the 256-row tile (kernels_gemm_tall.hip): corpus image
+    // (wsplit 1) or f32 corpus split in registers (wsplit 2), queries as the split image either way
+    static const int tall_on = lb_tunable("LB_TALL", 1);
+    const bool use_tall = !use_narrow && wsplit != 0 && tall_on && narrow_ok;
+    if (use_tall && wsplit == 2) split_queries();
     auto candidates = [&](int64_t b, int64_t e, const uint32_t *rowmap, bool boot) {
         ProfScope p(w, s, prof, 0);
         if (use_narrow)
             launch_gemm_filter_narrow(metric, gx, h->d_norm2, h->d_rnorm, b, e, h->dim, gq, nq, mask, rowmap,
                                       w->cs, boot, s, tile64, nsplit);
+        else if (use_tall)
+            launch_gemm_filter_tall(metric, gx, h->d_norm2, h->d_rnorm, b, e, h->dim, w->d_qs, nq, mask, rowmap, w->cs,
+                                    boot, wsplit, s);
         else
             launch_gemm_filter(metric, gx, h->d_norm2, h->d_rnorm, b, e, h->dim, gq, nq, mask, rowmap, w->cs,
                                boot, wsplit, s);

@@ -77,8 +77,8 @@ __device__ __forceinline__ f32x4 load_chunk(const float *base, int64_t row, int 
 // GLDS: stage tiles with direct-to-LDS DMA loads (global_load_lds_dwordx4; needs ALIGNED == 2).
 // The LDS image is lane-linear per wave instruction (base + lane*16), so the chunk swizzle is
 // applied to the per-lane SOURCE address; the image is identical to the register-staged one.
-// SPLIT: X and Q are the split-bf16 images produced by split_bf16_kernel: per row and group of 32
-// k, 64 B of bf16 "hi" values followed by 64 B of bf16 "lo" values (x ~ hi + lo, |x-hi-lo| <=
+// SPLIT: X and Q are the split-bf16 images produced by split_bf16_kernel: per row and group of 16
+// k, 32 B of bf16 "hi" values followed by 32 B of bf16 "lo" values (x ~ hi + lo, |x-hi-lo| <=
 // 2^-18|x|).  The inner product is then hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (exact
 // bf16 products, f32 accumulation): ~f32-accurate candidate keys at 3/16 of the f32 MFMA cycles.
 // Staging, LDS image and epilogue are shared with the f32 kernel (same bytes per row and K-step).
@@ -280,18 +280,18 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_filter_kernel(GemmArgs a
                     }
             }
         } else if (SPLIT == 1) {
-            // chunk c of a row's 128-B piece: c = 0..3 -> hi k-blocks (8 k each), c = 4..7 -> lo k-blocks.
-            // For the 16-k step ks, lane half h supplies k-block 2*ks + h (the MFMA's k = 8h + j).
+            // a row's 128-B piece = two 16-k groups of [hi 32 B | lo 32 B]: for the 16-k step ks, lane half h supplies
+            // k = 8h .. 8h+7 of it: chunk 4 ks + h (hi) and 4 ks + 2 + h (lo)
             bf16x8 ah[2][2], al[2][2], bh[2][2], bl[2][2]; // [buffer][tile]
             auto ldfrag = [&](int buf, int ks) {
-                const int kb = 2 * ks + h;
+                const int kb = 4 * ks + h;
 #pragma unroll
                 for (int t = 0; t < 2; t++) {
                     const int ra_ = wr * 64 + t * 32 + l31, rb_ = wc * 64 + t * 32 + l31;
                     ah[buf][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(&As[swz_off(ra_, kb)]));
-                    al[buf][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(&As[swz_off(ra_, 4 + kb)]));
+                    al[buf][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(&As[swz_off(ra_, 2 + kb)]));
                     bh[buf][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(&Bs[swz_off(rb_, kb)]));
-                    bl[buf][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(&Bs[swz_off(rb_, 4 + kb)]));
+                    bl[buf][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(&Bs[swz_off(rb_, 2 + kb)]));
                 }
             };
             ldfrag(0, 0);
@@ -486,8 +486,8 @@ void read_clock_probe(unsigned long long out[8], bool reset)
     }
 }
 
-// f32 [rows][D] -> split-bf16 image of the same byte shape (D % 32 == 0): per row and 32-k group,
-// 32 bf16 hi values (x rounded to nearest even) then 32 bf16 lo values (x - hi rounded).
+// f32 [rows][D] -> split-bf16 image of the same byte shape (D % 32 == 0): per row and 16-k group,
+// 16 bf16 hi values (x rounded to nearest even) then 16 bf16 lo values (x - hi rounded): one MFMA k-block per 64 B.
 __global__ __launch_bounds__(256) void split_bf16_kernel(const float *src, float *dst, int64_t n8)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
@@ -501,11 +501,11 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float *src, float
             hi[j] = hh;
             lo[j] = (__bf16)(x[j] - (float)hh);
         }
-        const int64_t grp = i >> 2; // 32-k group index over the flattened [rows*D/32]
-        const int kb = (int)(i & 3);
-        char *g = reinterpret_cast<char *>(dst) + grp * 128;
+        const int64_t grp = i >> 1; // 16-k group index over the flattened [rows*D/16]
+        const int kb = (int)(i & 1);
+        char *g = reinterpret_cast<char *>(dst) + grp * 64;
         *reinterpret_cast<bf16x8 *>(g + kb * 16) = hi;
-        *reinterpret_cast<bf16x8 *>(g + 64 + kb * 16) = lo;
+        *reinterpret_cast<bf16x8 *>(g + 32 + kb * 16) = lo;
     }
 }
 

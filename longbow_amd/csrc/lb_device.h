@@ -129,6 +129,11 @@ void launch_gemm_filter_narrow(int metric, const float *X, const float *norm2, c
                                bool split = false);                // split: 3 x bf16 MFMA on operands split in registers
 // f32 [rows][D] -> split-bf16 image (same byte shape; D % 32 == 0) consumed by the split GEMM
 void launch_split_bf16(const float *src, float *dst, int64_t rows, int D, hipStream_t s);
+// split-bf16 contraction on the 256-row x 128-query tile (kernels_gemm_tall.hip); Qs = split image of the batch;
+// asplit 1: X is the split image of the corpus, 2: X is the f32 corpus (split in registers)
+void launch_gemm_filter_tall(int metric, const float *X, const float *norm2, const float *rnorm, int64_t row_begin,
+                             int64_t row_end, int D, const float *Qs, int nq, const uint8_t *mask, const uint32_t *rowmap,
+                             CandState cs, bool boot, int asplit, hipStream_t s);
 
 // per query: sort the list, keep the best kc, tau = kc-th entry (or max), flag overflow.
 // qsel (nullable): only these query slots.  boot_rows > 0: the list was filled by a bootstrap

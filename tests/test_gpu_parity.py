@@ -433,6 +433,39 @@ def test_split_bf16_candidates_give_identical_results(oracle, metric):
     idx.Close()
 
 
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_tall_tile_every_route(oracle, metric):
+    """the 256-row tile of the split contraction (kernels_gemm_tall.hip) on each of its routes: default path at 65-384
+    queries (corpus split in registers), candidate mode 1 (corpus image, 128- and 256-query tiles) and mode 2, with a
+    ragged row count, a ragged last query tile, a predicate mask and a selective filter (row list) -- all equal to the
+    oracle bit for bit and to each other"""
+    gpu_or_skip()
+    rng = np.random.default_rng(500 + metric)
+    n, d, k = 41111, 96, 20                       # n % 256 != 0: the last corpus tile is ragged
+    X = (rng.random((n, d), dtype=F) - F(0.4)) * F(2.0)
+    Q = (rng.random((512, d), dtype=F) - F(0.4)) * F(2.0)
+    idx = new_index(d, metric)
+    idx.Add(None, X)
+    want = {}
+    for nq in (70, 200, 384, 512):
+        want[nq] = oracle.search_batch(metric, Q[:nq], X, k, nthreads=8)
+    for mode in (0, 1, 2):
+        idx.set_candidate_mode(mode)
+        for nq in (70, 200, 384, 512):            # 512 in mode 1: the 256-query tile
+            lab, dist = idx.SearchBatch(Q[:nq], k)
+            assert_same(lab, dist, want[nq][0], want[nq][1], f"tall metric={metric} mode={mode} nq={nq}")
+    for frac in (0.97, 0.3):                      # per-row test / compacted row list
+        mask = (rng.random(n) < frac).astype(np.uint8)
+        idx.set_filter(mask)
+        oi, od = oracle.search_batch(metric, Q[:130], X, k, mask=mask, nthreads=8)
+        for mode in (0, 1):
+            idx.set_candidate_mode(mode)
+            lab, dist = idx.SearchBatch(Q[:130], k)
+            assert_same(lab, dist, oi, od, f"tall masked metric={metric} mode={mode} frac={frac}")
+    idx.set_filter(None)
+    idx.Close()
+
+
 def test_growth_survives_a_refused_mapping(oracle):
     """the corpus grows in place through the virtual-memory API; when the driver refuses to extend the mapping
     (forced here) the rows move once into a hipMalloc buffer and the index keeps working, ids and all"""

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Batch-size sweep on one MI355X: queries/s and effective corpus-read rate vs batch size
 (1M x 768 f32 cosine, k = 100), with the library's own per-class device timing.
-usage: python tools/bench_sweep.py [rows]   (SWEEP=1,2,4,... selects the batch sizes)"""
+usage: python tools/bench_sweep.py [rows]   (SWEEP=1,2,4,... selects the batch sizes, CAND_MODE=1|2 the opt-in candidate modes)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -14,6 +14,7 @@ X = torch.empty((rows, D), device="cuda"); Q = torch.empty((1024, D), device="cu
 lib.lb_gpu_fill_uniform_device(0, X.data_ptr(), X.numel(), 12345, 0, None)
 lib.lb_gpu_fill_uniform_device(0, Q.data_ptr(), Q.numel(), 42, 0, None)
 idx = gpu.NewIndexWithConfig(gpu.GPUConfig(0, D, 1)); idx.reserve(rows); idx.add_device(rows, X.data_ptr())
+if os.environ.get('CAND_MODE'): idx.set_candidate_mode(int(os.environ['CAND_MODE']))  # 1 = split image, 2 = split in registers
 for B in [int(x) for x in os.environ.get('SWEEP', '1,2,4,8,9,16,24,32,48,64,96,97,128,256,512,1024').split(',')]:
     od = torch.empty((B, K), device="cuda"); ol = torch.empty((B, K), dtype=torch.int64, device="cuda")
     q = Q[:B].contiguous()
