@@ -430,7 +430,7 @@ def main():
             result["split_bf16_candidates"] = {
                 "value": round(B * args.steps / f_el, 1), "unit": "queries/s", "ms_per_step": round(1e3 * f_el / args.steps, 4),
                 "results_identical_to_f32_mode": same, "fallback_queries": int(f_fb),
-                "roofline": {"bound": "mfma", "kernel": "gemm_filter_kernel<split>", "achieved": round(ach, 1),
+                "roofline": {"bound": "mfma", "kernel": "gemm_filter_tall_kernel<corpus image>", "achieved": round(ach, 1),
                              "peak": 2500.0, "unit": "TFLOP/s (bf16, 3 MFMA passes counted)", "frac": round(ach / 2500.0, 4),
                              "kernel_ms_per_step": round(f_ms / args.steps, 4)},
                 "note": "opt-in lb_gpu_index_set_candidate_mode(1): candidates from hi*hi+hi*lo+lo*hi on bf16 MFMA; "
@@ -464,7 +464,7 @@ def main():
             result["split_bf16_in_registers"] = {
                 "value": round(B * args.steps / f_el, 1), "unit": "queries/s", "ms_per_step": round(1e3 * f_el / args.steps, 4),
                 "results_identical_to_f32_mode": same, "fallback_queries": int(f_fb), "extra_hbm_bytes": 0,
-                "roofline": {"bound": "mfma", "kernel": "gemm_filter_kernel<split in registers>", "achieved": round(ach, 1),
+                "roofline": {"bound": "mfma", "kernel": "gemm_filter_tall_kernel<split in registers>", "achieved": round(ach, 1),
                              "peak": 2500.0, "unit": "TFLOP/s (bf16, 3 MFMA passes counted)", "frac": round(ach / 2500.0, 4),
                              "kernel_ms_per_step": round(f_ms / args.steps, 4)},
                 "note": "opt-in lb_gpu_index_set_candidate_mode(2): as split_bf16_candidates but the f32 tiles are split to bf16 "

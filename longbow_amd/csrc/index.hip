@@ -617,7 +617,10 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     // query tile, 1.33 for two, 1.85 for three, against 0.48 per 64-query pass).
     static const double kCostWS0 = lb_tunable("LB_COSTWS0_US", 270) * 1e-3, kCostWS = lb_tunable("LB_COSTWS_US", 535) * 1e-3;
     int wsplit = split;
-    if (nsplit && tile64 && split == 0 && kCostWS0 + kCostWS * tiles_w < c64) {
+    // (only with enough tiles to fill the chip a few times over: 512 workgroups run at once, and at 125k visible rows
+    // x 256 queries the 978 tall tiles came out 5 % behind the 3908 smaller ones)
+    const bool tall_fills = (n / 256) * tiles_w >= 2048;
+    if (nsplit && tile64 && split == 0 && tall_fills && kCostWS0 + kCostWS * tiles_w < c64) {
         use_narrow = false;
         nsplit = false;
         wsplit = 2;

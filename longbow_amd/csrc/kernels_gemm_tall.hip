@@ -19,6 +19,12 @@
 // the counted ones below (with __builtin_amdgcn_global_load_lds every later LDS read waits for vmcnt(0), i.e.
 // for the stage that was just requested).
 //
+// Measured and dropped (1M x 768, 1024 queries, no effect beyond the 3 % run-to-run noise): wave priority raised over the
+// MFMA block, a fixed priority difference between the two workgroups of a CU, the DMA requests issued behind the first
+// fragment reads instead of in front of them, and an epilogue with one atomic round trip per lane instead of one per
+// MFMA tile.  rocprofv3 (tools/prof_tall.sh): no LDS bank conflicts, LDS index unit 13 % busy, shader clock 1.77 GHz under
+// this kernel (2.10 under the f32 kernel): the matrix pipe is busy 60 % of the kernel's cycles.
+//
 // Operands.  Queries always come as the split image (launch_split_bf16 on the batch: hi / lo bf16 pairs in the
 // bytes of the f32 row).  The corpus is either the same kind of image (ASPLIT == 1, LB_CAND_SPLIT_BF16) or the
 // plain f32 rows split in registers after the LDS read (ASPLIT == 2: no second copy of the corpus).
@@ -162,12 +168,6 @@ __global__ __launch_bounds__(128 * NWC, NWC == 2 ? 2 : 1) void gemm_filter_tall_
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
     const int nk = a.D / TBK; // D % 32 == 0 (launcher)
-#ifdef LB_DIAG
-    if (a.abl >= 8) { // A/B: asymmetric issue priority between the two workgroups that share a CU (wave slot parity)
-        const uint32_t slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4); // HW_ID.wave_id
-        if (slot & 1) __builtin_amdgcn_s_setprio(3);
-    }
-#endif
     issue(0);
     // one burst behind the first stage (not needed before the epilogue): side inputs and thresholds
     const float side_aux = METRIC == METRIC_L2 ? a.norm2[side_ri] : (METRIC == METRIC_COS ? a.rnorm[side_ri] : 0.f);
