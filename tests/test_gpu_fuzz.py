@@ -26,6 +26,7 @@ CASES = [
     (12, 3_000_000, 16, 10, (1, 6, 40)),      # beyond one sampled span: the growing chunks continue
     (13, 2_700_000, 8, 100, (2, 130)),
     (14, 100_000, 257, 20, (1, 7, 30)),
+    (15, 600_001, 32, 40, (130, 300)),         # enough 256-row tiles for the tall split tile on the default path
 ]
 
 
