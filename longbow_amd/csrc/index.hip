@@ -54,6 +54,10 @@ struct Workspace {
     int *d_iota = nullptr;       // [nq_cap] 0,1,2,...: the slot list of "every query", filled once
     uint32_t *d_smap = nullptr;  // [cap] sampled rows of the first pass
     uint32_t *d_done = nullptr;  // [nq_cap] arrival tickets of the split re-rank (zero between launches)
+    // fused sample (kernels_gemm_narrow.hip, FUSED): [0] = ticket counter that only grows, [1 ..] = ready epochs per slot
+    uint32_t *d_fsync = nullptr;
+    uint32_t fs_base = 0, fs_epoch = 0; // host mirror of the ticket counter; last epoch used
+    uint32_t *h_fail = nullptr;         // pinned: epoch of a launch whose waits gave up
     uint32_t *h_flags = nullptr; // pinned
     int *h_qsel = nullptr;       // pinned
     // host-API staging (device side)
@@ -79,6 +83,8 @@ struct Workspace {
         if (d_iota) (void)hipFree(d_iota);
         if (d_smap) (void)hipFree(d_smap);
         if (d_done) (void)hipFree(d_done);
+        if (d_fsync) (void)hipFree(d_fsync);
+        if (h_fail) (void)hipHostFree(h_fail);
         if (h_flags) (void)hipHostFree(h_flags);
         if (h_qsel) (void)hipHostFree(h_qsel);
         if (d_q) (void)hipFree(d_q);
@@ -305,6 +311,11 @@ std::unique_ptr<Workspace> acquire_ws(lb_gpu_index *h, int nq, uint32_t cap)
     LB_HIP(hipMalloc(&w->cs.flags, (size_t)w->nq_cap * sizeof(uint32_t)));
     LB_HIP(hipMalloc(&w->d_done, (size_t)w->nq_cap * sizeof(uint32_t)));
     LB_HIP(hipMemset(w->d_done, 0, (size_t)w->nq_cap * sizeof(uint32_t)));
+    LB_HIP(hipMalloc(&w->d_fsync, (size_t)(1 + w->nq_cap) * sizeof(uint32_t)));
+    LB_HIP(hipMemset(w->d_fsync, 0, (size_t)(1 + w->nq_cap) * sizeof(uint32_t)));
+    LB_HIP(hipMemset(w->cs.flags, 0, (size_t)w->nq_cap * sizeof(uint32_t)));
+    LB_HIP(hipHostMalloc(&w->h_fail, sizeof(uint32_t), hipHostMallocDefault));
+    *w->h_fail = 0;
     LB_HIP(hipMalloc(&w->cs.stripes, (size_t)kScanMaxQ * LB_STRIPES * LB_STRIPE_PAD * sizeof(uint32_t)));
     LB_HIP(hipMalloc(&w->d_qna, (size_t)w->nq_cap * sizeof(float)));
     LB_HIP(hipMalloc(&w->d_qsel, (size_t)w->nq_cap * sizeof(int)));
@@ -563,11 +574,6 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     // up to 8 queries the sample is scored by the wave-per-row kernel (candidate keys; 22-28 us against
     // 44 us for 8192 rows through the 32-workgroup MFMA launch); larger batches sample through the MFMA
     // kernel itself.  Up to 64 queries the exact query norms ride in the threshold launch.
-    static const int light_max = lb_tunable("LB_LIGHT_SAMPLE_MAXQ", 8);
-    const bool light_sample = sp.on && nq <= light_max;
-    const bool norm_riders = sp.on && nq <= 64 && metric == LB_METRIC_COSINE;
-    if (!light_sample) launch_init_cand(w->cs, nullptr, nq, s);
-    if (metric == LB_METRIC_COSINE && !norm_riders) launch_query_norms(order, d_q, nullptr, nq, h->dim, w->d_qna, s);
     // candidate contraction: exact f32 MFMA, or 3 x bf16 MFMA on the split images
     const int cmode = h->cand_mode.load();
     // 1: pre-split bf16 image of the corpus; 2: f32 operands split in registers (no image)
@@ -631,6 +637,15 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     static const int tall_on = lb_tunable("LB_TALL", 1);
     const bool use_tall = !use_narrow && wsplit != 0 && tall_on && narrow_ok;
     if (use_tall && wsplit == 2) split_queries();
+    // Up to 64 queries on the narrow split tiles the sample and its thresholds ride INSIDE the candidate launch (FUSED
+    // in kernels_gemm_narrow.hip: 19-34 us of sample + 13 us of threshold kernel off the critical path).
+    static const int fused_max = lb_tunable("LB_FUSED_SAMPLE_MAXQ", 32); // (measured level or behind at 33-64 queries: the 64-query tile)
+    const bool fused = sp.on && use_narrow && nsplit && !tile64 && nq <= fused_max;
+    static const int light_max = lb_tunable("LB_LIGHT_SAMPLE_MAXQ", 8);
+    const bool light_sample = sp.on && !fused && nq <= light_max;
+    const bool norm_riders = sp.on && nq <= 64 && metric == LB_METRIC_COSINE;
+    if (!light_sample && !fused) launch_init_cand(w->cs, nullptr, nq, s);
+    if (metric == LB_METRIC_COSINE && !norm_riders) launch_query_norms(order, d_q, nullptr, nq, h->dim, w->d_qna, s);
     auto candidates = [&](int64_t b, int64_t e, const uint32_t *rowmap, bool boot) {
         ProfScope p(w, s, prof, 0);
         if (use_narrow)
@@ -645,7 +660,9 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     };
     int64_t pos = 0;
     int step = 0;
+    uint32_t fused_epoch = 0;
     if (sp.on) { // sampled threshold, then one pass over the span (see sample_plan)
+        const uint32_t *smap = w->d_smap;
         if (light_sample) {
             ProfScope p(w, s, prof, 1);
             launch_sample_scores(metric, order, h->d_X, h->dim, sp.span, sp.count, rv.rowmap, mask, d_q, nullptr, nq,
@@ -653,7 +670,6 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
             launch_sample_tau(w->cs, nullptr, nq, sp.count, sp.m, false, s, d_q, h->dim,
                               norm_riders ? w->d_qna : nullptr, order);
         } else {
-            const uint32_t *smap = w->d_smap;
             {
                 std::lock_guard<std::mutex> g(h->smap_mu);
                 if (!h->smap_valid) {
@@ -673,12 +689,34 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
                 if (h->smap_span == sp.span && h->smap_count == sp.count) smap = h->d_smap;
             }
             if (smap == w->d_smap) launch_sample_map(rv.rowmap, sp.span, sp.count, w->d_smap, s);
-            candidates(0, sp.count, smap, /*boot=*/true);
-            ProfScope p(w, s, prof, 1);
-            launch_sample_tau(w->cs, nullptr, nq, sp.count, sp.m, false, s, d_q, h->dim,
-                              norm_riders ? w->d_qna : nullptr, order);
+            if (!fused) {
+                candidates(0, sp.count, smap, /*boot=*/true);
+                ProfScope p(w, s, prof, 1);
+                launch_sample_tau(w->cs, nullptr, nq, sp.count, sp.m, false, s, d_q, h->dim,
+                                  norm_riders ? w->d_qna : nullptr, order);
+            }
         }
-        candidates(0, sp.span, rv.rowmap, /*boot=*/false);
+        if (fused) {
+            ProfScope p(w, s, prof, 0);
+            FusedSample fs;
+            fs.smap = smap;
+            fs.count = sp.count;
+            fs.m = sp.m;
+            fs.ticket = w->d_fsync;
+            fs.ticket_base = w->fs_base;
+            fs.ready = w->d_fsync + 1;
+            if (++w->fs_epoch == 0) w->fs_epoch = 1; // (0 = "never published")
+            fs.epoch = w->fs_epoch;
+            fs.qna = norm_riders ? w->d_qna : nullptr;
+            fs.order = order;
+            fs.fail_host = w->h_fail;
+            launch_gemm_filter_narrow_fused(metric, gx, h->d_norm2, h->d_rnorm, 0, sp.span, h->dim, gq, nq, mask, rv.rowmap,
+                                            w->cs, s, tile64, fs);
+            w->fs_base += fused_sample_blocks(sp.count, nq, tile64);
+            fused_epoch = fs.epoch;
+        } else {
+            candidates(0, sp.span, rv.rowmap, /*boot=*/false);
+        }
         {
             ProfScope p(w, s, prof, 1);
             launch_select(w->cs, nullptr, nq, kc, 0u, s, false, (uint32_t)kc);
@@ -703,7 +741,17 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
                       h->has_ids ? h->d_ids : nullptr, d_dist, d_lab, s, w->h_flags, w->d_done);
     }
     std::vector<int> bad;
-    if (collect_flagged(w, s, nq, 3u | 4u, nullptr, 0, bad, /*on_host=*/true) > 0) {
+    int nbad = collect_flagged(w, s, nq, 3u | 4u, nullptr, 0, bad, /*on_host=*/true);
+    if (fused_epoch != 0 && *w->h_fail == fused_epoch) {
+        // a wait inside the fused launch gave up (its workgroups were not co-resident): every query goes the exact way,
+        // and the ticket counter is re-based in case the launch did not run to completion
+        bad.resize((size_t)nq);
+        for (int i = 0; i < nq; i++) bad[(size_t)i] = i;
+        nbad = nq;
+        LB_HIP(hipMemsetAsync(w->d_fsync, 0, sizeof(uint32_t), s));
+        w->fs_base = 0;
+    }
+    if (nbad > 0) {
         fallbacks += (int64_t)bad.size();
         scan_with_retry(h, w, s, d_q, nq, bad, k, d_dist, d_lab, prof);
     }

@@ -127,6 +127,28 @@ void launch_gemm_filter_narrow(int metric, const float *X, const float *norm2, c
                                const uint8_t *mask, const uint32_t *rowmap, CandState cs, bool boot,
                                hipStream_t s, bool tile64 = false, // tile64: 128 rows x 64 queries per workgroup
                                bool split = false);                // split: 3 x bf16 MFMA on operands split in registers
+// Sampled threshold fused into the candidate pass (kernels_gemm_narrow.hip, FUSED): the first `n_blocks` workgroups of
+// the launch score `count` sampled rows (corpus rows smap[0..count)), then workgroup j < nq turns query j's sample keys
+// into tau[j] (the m-th smallest), zeroes cnt[j] / flags[j], writes the exact ||q_j||^2 (cosine) and publishes
+// ready[j] = epoch; the corpus tiles of the same launch pick the thresholds up in front of their epilogues.
+// ticket: a counter that only grows (every sample workgroup adds 1); ticket_base = its value before this launch.
+struct FusedSample {
+    const uint32_t *smap = nullptr;
+    uint32_t count = 0;
+    int m = 0;
+    uint32_t n_blocks = 0;
+    uint32_t *ticket = nullptr;
+    uint32_t ticket_base = 0;
+    uint32_t *ready = nullptr;
+    uint32_t epoch = 0;
+    float *qna = nullptr; // or null (not cosine)
+    int order = 0;
+    uint32_t *fail_host = nullptr; // pinned: set to `epoch` when a wait gave up (the host then redoes the batch exactly)
+};
+void launch_gemm_filter_narrow_fused(int metric, const float *X, const float *norm2, const float *rnorm, int64_t row_begin,
+                                     int64_t row_end, int D, const float *Q, int nq, const uint8_t *mask,
+                                     const uint32_t *rowmap, CandState cs, hipStream_t s, bool tile64, FusedSample fs);
+uint32_t fused_sample_blocks(uint32_t count, int nq, bool tile64); // sample workgroups such a launch starts with
 // f32 [rows][D] -> split-bf16 image (same byte shape; D % 32 == 0) consumed by the split GEMM
 void launch_split_bf16(const float *src, float *dst, int64_t rows, int D, hipStream_t s);
 // split-bf16 contraction on the 256-row x 128-query tile (kernels_gemm_tall.hip); Qs = split image of the batch;
