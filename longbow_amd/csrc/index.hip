@@ -719,7 +719,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         }
         {
             ProfScope p(w, s, prof, 1);
-            launch_select(w->cs, nullptr, nq, kc, 0u, s, false, (uint32_t)kc);
+            launch_select(w->cs, nullptr, nq, kc, 0u, s, false, (uint32_t)kc, nullptr, false, /*unsorted=*/true);
         }
         pos = sp.span;
         step = 1;
@@ -730,7 +730,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         candidates(pos, end, rv.rowmap, boot);
         {
             ProfScope p(w, s, prof, 1);
-            launch_select(w->cs, nullptr, nq, kc, boot ? (uint32_t)(end - pos) : 0u, s);
+            launch_select(w->cs, nullptr, nq, kc, boot ? (uint32_t)(end - pos) : 0u, s, false, 0u, nullptr, false, /*unsorted=*/true);
         }
         pos = end;
         step++;

@@ -118,7 +118,7 @@ template <int NT> // threads per workgroup: 256 (throughput, many queries) or 10
 __global__ __launch_bounds__(NT) void select_kernel(CandState cs, const int *qsel, int kc,
                                                              uint32_t boot_rows, uint32_t tau_only,
                                                              uint32_t need_at_least, uint32_t sort_max,
-                                                             EmitArgs em, uint32_t striped)
+                                                             EmitArgs em, uint32_t striped, uint32_t unsorted)
 {
     // tau_only: the list holds a *sample* of the rows; publish its kc-th entry (row bits saturated) as
     // the admission threshold and leave the list empty.  need_at_least: a list shorter than this means a
@@ -312,6 +312,33 @@ __global__ __launch_bounds__(NT) void select_kernel(CandState cs, const int *qse
         }
     }
     __syncthreads();
+    if (unsorted) {
+        // the caller re-ranks the kept entries anyway and only needs to know which one has the worst key: it goes to
+        // position kc - 1 (one swap), the other kc - 1 stay as the compaction left them -- no sort (-4 us)
+        unsigned long long *mx = reinterpret_cast<unsigned long long *>(hist);
+        if (tid == 0) mx[0] = 0ull;
+        __syncthreads();
+        unsigned long long m = 0ull;
+        for (uint32_t i = tid; i < (uint32_t)kc; i += NT) m = stage[i] > m ? stage[i] : m;
+        if (m) atomicMax(&mx[0], m);
+        __syncthreads();
+        const uint64_t worst = mx[0];
+        __syncthreads();
+        for (uint32_t i = tid; i < (uint32_t)kc; i += NT) {
+            const uint64_t e = stage[i];
+            if (e == worst && i != (uint32_t)kc - 1) { // entries are unique: one thread swaps
+                stage[i] = stage[kc - 1];
+                stage[kc - 1] = e;
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < (uint32_t)kc; i += NT) list[i] = stage[i];
+        if (tid == 0) {
+            cs.cnt[q] = (uint32_t)kc;
+            cs.tau[q] = pivot;
+        }
+        return; // (no emit on this route: the re-rank writes the results)
+    }
     // (this path has P > 2 * Pk, so sh[0..Pk) and the staging tail sh[P..P+Pk) do not overlap)
     for (uint32_t i = tid; i < Pk; i += NT) sh[i] = i < (uint32_t)kc ? stage[i] : kEntryMax;
     __syncthreads();
@@ -341,7 +368,7 @@ void launch_sample_map(const uint32_t *rowmap, int64_t span, uint32_t count, uin
 }
 
 void launch_select(CandState cs, const int *qsel, int nsel, int kc, uint32_t boot_rows, hipStream_t s,
-                   bool tau_only, uint32_t need_at_least, const EmitArgs *emit, bool striped)
+                   bool tau_only, uint32_t need_at_least, const EmitArgs *emit, bool striped, bool unsorted)
 {
     EmitArgs em{};
     if (emit) em = *emit;
@@ -354,12 +381,12 @@ void launch_select(CandState cs, const int *qsel, int nsel, int kc, uint32_t boo
         allow_big_lds(select_kernel<1024>, shmem);
         hipLaunchKernelGGL(select_kernel<1024>, dim3(nsel), dim3(1024), shmem, s, cs, qsel, kc, boot_rows,
                            tau_only ? 1u : 0u, need_at_least, sort_max, em,
-                           (striped && cs.stripes) ? 1u : 0u);
+                           (striped && cs.stripes) ? 1u : 0u, (unsorted && emit == nullptr) ? 1u : 0u);
     } else {
         allow_big_lds(select_kernel<256>, shmem);
         hipLaunchKernelGGL(select_kernel<256>, dim3(nsel), dim3(256), shmem, s, cs, qsel, kc, boot_rows,
                            tau_only ? 1u : 0u, need_at_least, sort_max, em,
-                           (striped && cs.stripes) ? 1u : 0u);
+                           (striped && cs.stripes) ? 1u : 0u, (unsorted && emit == nullptr) ? 1u : 0u);
     }
 }
 

@@ -172,7 +172,8 @@ struct EmitArgs {
 };
 void launch_select(CandState cs, const int *qsel, int nsel, int kc, uint32_t boot_rows, hipStream_t s,
                    bool tau_only = false, uint32_t need_at_least = 0, const EmitArgs *emit = nullptr,
-                   bool striped = false);
+                   bool striped = false,
+                   bool unsorted = false); // unsorted: the kept entries need not be ordered, only the worst one sits last
 // approximate distances of `count` evenly spaced positions of [0, span) for up to 8 query slots, written
 // as entries to lists[q][0..count) (also clears the slots' flags); cosine: `nsel` extra workgroups compute
 // the slots' exact ||q||^2 into qna in the requested order.  norm2/rnorm given ("keys" mode, up to 64 slots):
