@@ -27,7 +27,7 @@
 
 using namespace lb;
 
-namespace lb { extern int g_adc_ablation; extern int g_gemm_ablation; extern int g_gemm_glds; void read_clock_probe(unsigned long long out[8], bool reset); int debug_gemm_occupancy(); }
+namespace lb { extern int g_adc_ablation; extern int g_gemm_ablation; extern int g_gemm_glds; void read_clock_probe(unsigned long long out[8], bool reset); int debug_gemm_occupancy(); void read_fused_probe(unsigned long long out[8], bool reset); }
 
 namespace {
 
@@ -1487,6 +1487,7 @@ void lb_debug_set_gemm_glds(int v) { lb::g_gemm_glds = v; }
 void lb_debug_set_adc_ablation(int v) { lb::g_adc_ablation = v; }
 int lb_debug_gemm_occupancy(void) { return lb::debug_gemm_occupancy(); }
 void lb_debug_read_clock_probe(unsigned long long *out, int reset) { lb::read_clock_probe(out, reset != 0); }
+void lb_debug_read_fused_probe(unsigned long long *out, int reset) { lb::read_fused_probe(out, reset != 0); }
 #endif
 
 // ---- candidate re-rank (processChunkInternal) ------------------------------------------

@@ -57,6 +57,20 @@ struct NarrowArgs {
 
 __device__ __forceinline__ int nswz(int row, int chunk) { return row * NBK + ((chunk ^ ((row >> 1) & 7)) << 2); }
 
+#ifdef LB_DIAG
+// timing probe of the fused launch (100 MHz real-time ticks): [0] first entry stamp (min), [1] last threshold published
+// (max), [2] sum of the corpus workgroups' waits for thresholds, [3] corpus workgroups, [4] those that had to wait,
+// [5] last sample workgroup's keys out (max)
+__device__ unsigned long long g_fused_probe[8];
+void read_fused_probe(unsigned long long out[8], bool reset)
+{
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fused_probe), 8 * sizeof(unsigned long long));
+    if (reset) {
+        unsigned long long z[8] = {~0ull, 0, 0, 0, 0, 0, 0, 0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fused_probe), z, sizeof z);
+    }
+}
+#endif
 // ---- helpers of the fused sample (FUSED) ---------------------------------------------------------------------
 constexpr uint32_t kSpinLimit = 40000; // x ~0.25 us: a wait that long means the launch's workgroups are not co-resident
 
@@ -114,6 +128,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
     // the thresholds of the launch's own sample are then long published when the first epilogues need them, and a
     // launch has half as many pipeline fills and drains.
     constexpr int TPW = FUSED ? 2 : 1;
+#ifdef LB_DIAG
+    if (FUSED && threadIdx.x == 0) atomicMin(&g_fused_probe[0], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
     static_assert(TM * TN == 2, "two MFMA tiles (32 accumulator VGPRs) per wave");
     int b = blockIdx.x;
     const bool is_sample = FUSED && b < (int)a.fs.n_blocks;
@@ -221,6 +238,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
     }
     __syncthreads();
 
+    uint32_t spec_ready = 0;
+    uint64_t spec_tau = 0ull;
     f32x16 acc[TPW][TM][TN];
 #pragma unroll
     for (int tp = 0; tp < TPW; tp++) {
@@ -233,6 +252,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
         if (tp >= ntiles_here) continue; // (workgroup-uniform)
         for (int kt = 0; kt < nk; kt++) {
             const int cur = (tp * nk + kt) & 1;
+            if (FUSED && !is_sample && tp == ntiles_here - 1 && tid < NBN) {
+                // early look at this workgroup's thresholds (a K-loop ahead of their use): published long ago for all but
+                // the first workgroups of a launch, and the two dependent device-scope loads then cost nothing at the end
+                const int qj = q0 + tid < a.nq ? q0 + tid : a.nq - 1;
+                if (kt == 0) spec_ready = __hip_atomic_load(&a.fs.ready[qj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (kt == 3 && spec_ready == a.fs.epoch)
+                    spec_tau = __hip_atomic_load(&a.cs.tau[qj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             if (kt + 1 < nk) stage_in(srcA[tp], cur ^ 1, (kt + 1) * NBK);
             else if (tp + 1 < ntiles_here) stage_in(srcA[tp + 1 < TPW ? tp + 1 : tp], cur ^ 1, 0);
             const float *As = lds_all + cur * STAGE_F;
@@ -297,10 +324,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
 
     if (FUSED && !is_sample) { // thresholds published by the sample workgroups of this launch
         uint64_t *s_tau = reinterpret_cast<uint64_t *>(lds_all); // (the stages are free: the loops ended with a barrier)
+#ifdef LB_DIAG
+        const unsigned long long w0 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) {
+            atomicAdd(&g_fused_probe[3], 1ull);
+            if (__hip_atomic_load(&a.fs.ready[q0 < a.nq ? q0 : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.fs.epoch)
+                atomicAdd(&g_fused_probe[4], 1ull);
+        }
+#endif
         if (tid < NBN) {
             const int qj = q0 + tid;
             uint64_t tau = 0ull; // nothing passes
-            if (qj < a.nq) {
+            if (qj < a.nq && spec_ready == a.fs.epoch && nk > 3) {
+                tau = spec_tau;
+            } else if (qj < a.nq) {
                 bool ok = false;
                 for (uint32_t it = 0; it < kSpinLimit; it++) {
                     if (__hip_atomic_load(&a.fs.ready[qj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.fs.epoch) {
@@ -315,6 +352,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
             s_tau[tid] = tau;
         }
         __syncthreads();
+#ifdef LB_DIAG
+        if (tid == 0) atomicAdd(&g_fused_probe[2], (unsigned long long)__builtin_amdgcn_s_memrealtime() - w0);
+#endif
 #pragma unroll
         for (int tn = 0; tn < TN; tn++) {
             const uint64_t tau = s_tau[tn * 32 + l31];
@@ -413,6 +453,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) atomicAdd(a.fs.ticket, 1u);
+#ifdef LB_DIAG
+    if (tid == 0) atomicMax(&g_fused_probe[5], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
     const int j = (int)blockIdx.x;
     if (j >= a.nq) return;
     uint32_t *s_flag = reinterpret_cast<uint32_t *>(lds_all);
@@ -476,6 +519,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
         if (!all_in) *a.fs.fail_host = a.fs.epoch;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(&a.fs.ready[j], a.fs.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef LB_DIAG
+        atomicMax(&g_fused_probe[1], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
     }
 }
 
