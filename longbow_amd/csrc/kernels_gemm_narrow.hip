@@ -322,8 +322,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
         }
     }
 
+    // workgroup-local admission list of the FUSED corpus role, carved from the (now free) stages behind s_tau
+    constexpr int FL_CAP = 2048;
+    uint32_t *s_lcnt = reinterpret_cast<uint32_t *>(lds_all) + 256;
+    uint64_t *s_lent = reinterpret_cast<uint64_t *>(lds_all + 512);
+    uint16_t *s_lq = reinterpret_cast<uint16_t *>(lds_all + 512 + 2 * FL_CAP);
     if (FUSED && !is_sample) { // thresholds published by the sample workgroups of this launch
         uint64_t *s_tau = reinterpret_cast<uint64_t *>(lds_all); // (the stages are free: the loops ended with a barrier)
+        if (tid == 0) *s_lcnt = 0;
 #ifdef LB_DIAG
         const unsigned long long w0 = __builtin_amdgcn_s_memrealtime();
         if (tid == 0) {
@@ -429,6 +435,29 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
                         bits |= lt << (tm * 16 + g * 4 + e);
                     }
             bits &= vbits; // out-of-range rows and queries never pass (tau of a padded query decodes to NaN)
+            if (FUSED && bits) {
+                // admissions go to a workgroup-local list first (one LDS atomic per lane) and out to the per-query lists
+                // at the very end, every entry's returning global atomic in flight at once: at 32 queries a wave otherwise
+                // sits through ~7 of those round trips, one after the other, per pair of tiles
+                const uint32_t n = (uint32_t)__builtin_popcount(bits);
+                uint32_t lp = atomicAdd(s_lcnt, n);
+                if (lp + n <= (uint32_t)FL_CAP) {
+#pragma unroll
+                    for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+                        for (int g = 0; g < 4; g++)
+#pragma unroll
+                            for (int e = 0; e < 4; e++)
+                                if (bits & (1u << (tm * 16 + g * 4 + e))) {
+                                    s_lent[lp] = pack_entry(key_of(acc[tp][tm][tn][4 * g + e], aux[tm][g][e]), rid[tm][g][e]);
+                                    s_lq[lp] = (uint16_t)qj;
+                                    lp++;
+                                }
+                    bits = 0; // done
+                } else {
+                    for (uint32_t i = lp; i < lp + n && i < (uint32_t)FL_CAP; i++) s_lent[i] = kEntryMax; // reserved, unused
+                }
+            }
             if (bits) {
                 uint32_t pos = atomicAdd(&a.cs.cnt[qj], (uint32_t)__builtin_popcount(bits));
 #pragma unroll
@@ -444,6 +473,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
                             }
             }
         }
+    }
+    if (FUSED && !is_sample) { // flush the workgroup-local admissions
+        __syncthreads();
+        const uint32_t total = *s_lcnt < (uint32_t)FL_CAP ? *s_lcnt : (uint32_t)FL_CAP;
+        for (uint32_t i = tid; i < total; i += NTHREADS) {
+            const uint64_t ent = s_lent[i];
+            if (ent == kEntryMax) continue;
+            const int q = (int)s_lq[i];
+            const uint32_t pos = atomicAdd(&a.cs.cnt[q], 1u);
+            if (pos < a.cs.cap) a.cs.lists[(size_t)q * a.cs.cap + pos] = ent;
+        }
+        return;
     }
     if (!is_sample) return;
 
