@@ -322,7 +322,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
         }
     }
 
-    // workgroup-local admission list of the FUSED corpus role, carved from the (now free) stages behind s_tau
+    // workgroup-local admission list (every non-bootstrap launch), carved from the (now free) stages behind s_tau
     constexpr int FL_CAP = 2048;
     uint32_t *s_lcnt = reinterpret_cast<uint32_t *>(lds_all) + 256;
     uint64_t *s_lent = reinterpret_cast<uint64_t *>(lds_all + 512);
@@ -367,6 +367,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
             tk[tn] = tau_key_of(tau);
             tr[tn] = entry_row(tau);
         }
+    } else if (!boot) {
+        if (tid == 0) *s_lcnt = 0;
+        __syncthreads();
     }
 
     // ---- epilogue (as in gemm_filter_kernel), one row tile after the other --------------------------
@@ -435,7 +438,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
                         bits |= lt << (tm * 16 + g * 4 + e);
                     }
             bits &= vbits; // out-of-range rows and queries never pass (tau of a padded query decodes to NaN)
-            if (FUSED && bits) {
+            if (bits) {
                 // admissions go to a workgroup-local list first (one LDS atomic per lane) and out to the per-query lists
                 // at the very end, every entry's returning global atomic in flight at once: at 32 queries a wave otherwise
                 // sits through ~7 of those round trips, one after the other, per pair of tiles
@@ -474,7 +477,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
             }
         }
     }
-    if (FUSED && !is_sample) { // flush the workgroup-local admissions
+    if (!boot) { // flush the workgroup-local admissions
         __syncthreads();
         const uint32_t total = *s_lcnt < (uint32_t)FL_CAP ? *s_lcnt : (uint32_t)FL_CAP;
         for (uint32_t i = tid; i < total; i += NTHREADS) {

@@ -262,6 +262,15 @@ __global__ __launch_bounds__(128 * NWC, NWC == 2 ? 2 : 1) void gemm_filter_tall_
         if (METRIC == METRIC_COS) return -dot * ax;
         return -dot;
     };
+    // workgroup-local admission list, carved from the ring (free: every wave is past the last K-step's reads once the
+    // barrier below is behind it)
+    constexpr int FL_CAP = 2048;
+    uint32_t *s_lcnt = reinterpret_cast<uint32_t *>(ring);
+    uint64_t *s_lent = reinterpret_cast<uint64_t *>(ring + 16);
+    uint16_t *s_lq = reinterpret_cast<uint16_t *>(ring + 16 + 2 * FL_CAP);
+    __syncthreads();
+    if (tid == 0) *s_lcnt = 0;
+    __syncthreads();
 #pragma unroll
     for (int tm = 0; tm < 4; tm++) {
         float aux[4][4];
@@ -309,7 +318,25 @@ __global__ __launch_bounds__(128 * NWC, NWC == 2 ? 2 : 1) void gemm_filter_tall_
                     bits |= lt << (g * 4 + e);
                 }
             bits &= vbits;
-            if (bits) { // one returning atomic reserves the lane's slots; the stores are fire-and-forget
+            if (bits) { // workgroup-local list first (as the fused narrow kernel): one LDS atomic per lane
+                const uint32_t n = (uint32_t)__builtin_popcount(bits);
+                uint32_t lp = atomicAdd(s_lcnt, n);
+                if (lp + n <= (uint32_t)FL_CAP) {
+#pragma unroll
+                    for (int g = 0; g < 4; g++)
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            if (bits & (1u << (g * 4 + e))) {
+                                s_lent[lp] = pack_entry(key_of(acc[tm][tn][4 * g + e], aux[g][e]), rid[g][e]);
+                                s_lq[lp] = (uint16_t)(qj - q0);
+                                lp++;
+                            }
+                    bits = 0;
+                } else {
+                    for (uint32_t i = lp; i < lp + n && i < (uint32_t)FL_CAP; i++) s_lent[i] = kEntryMax; // reserved, unused
+                }
+            }
+            if (bits) { // (local list full) one returning atomic reserves the lane's slots; the stores are fire-and-forget
                 uint32_t pos = atomicAdd(&a.cs.cnt[qj], (uint32_t)__builtin_popcount(bits));
 #pragma unroll
                 for (int g = 0; g < 4; g++)
@@ -320,6 +347,17 @@ __global__ __launch_bounds__(128 * NWC, NWC == 2 ? 2 : 1) void gemm_filter_tall_
                             pos++;
                         }
             }
+        }
+    }
+    if (!a.boot) { // flush the workgroup-local admissions: every entry's returning global atomic in flight at once
+        __syncthreads();
+        const uint32_t total = *s_lcnt < (uint32_t)FL_CAP ? *s_lcnt : (uint32_t)FL_CAP;
+        for (uint32_t i = tid; i < total; i += TTHREADS) {
+            const uint64_t ent = s_lent[i];
+            if (ent == kEntryMax) continue;
+            const int q = q0 + (int)s_lq[i];
+            const uint32_t pos = atomicAdd(&a.cs.cnt[q], 1u);
+            if (pos < a.cs.cap) a.cs.lists[(size_t)q * a.cs.cap + pos] = ent;
         }
     }
 }
