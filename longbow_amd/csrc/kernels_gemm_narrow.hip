@@ -324,12 +324,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
 
     // workgroup-local admission list (every non-bootstrap launch), carved from the (now free) stages behind s_tau
     constexpr int FL_CAP = 2048;
-    uint32_t *s_lcnt = reinterpret_cast<uint32_t *>(lds_all) + 256;
+    uint32_t *s_lcnt = reinterpret_cast<uint32_t *>(lds_all) + 256;     // entries in the list
+    uint32_t *s_qcnt = s_lcnt + 1;                                      // [NBN] of them per query of the tile ...
+    uint32_t *s_qbase = s_qcnt + NBN;                                   // [NBN] ... and where they start in the query's list
     uint64_t *s_lent = reinterpret_cast<uint64_t *>(lds_all + 512);
     uint16_t *s_lq = reinterpret_cast<uint16_t *>(lds_all + 512 + 2 * FL_CAP);
+    uint16_t *s_lr = s_lq + FL_CAP;                                     // rank of the entry among its query's
     if (FUSED && !is_sample) { // thresholds published by the sample workgroups of this launch
         uint64_t *s_tau = reinterpret_cast<uint64_t *>(lds_all); // (the stages are free: the loops ended with a barrier)
         if (tid == 0) *s_lcnt = 0;
+        if (tid < NBN) s_qcnt[tid] = 0;
 #ifdef LB_DIAG
         const unsigned long long w0 = __builtin_amdgcn_s_memrealtime();
         if (tid == 0) {
@@ -369,6 +373,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
         }
     } else if (!boot) {
         if (tid == 0) *s_lcnt = 0;
+        if (tid < NBN) s_qcnt[tid] = 0;
         __syncthreads();
     }
 
@@ -445,6 +450,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
                 const uint32_t n = (uint32_t)__builtin_popcount(bits);
                 uint32_t lp = atomicAdd(s_lcnt, n);
                 if (lp + n <= (uint32_t)FL_CAP) {
+                    uint32_t lr = atomicAdd(&s_qcnt[qj - q0], n);
 #pragma unroll
                     for (int tm = 0; tm < TM; tm++)
 #pragma unroll
@@ -453,8 +459,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
                             for (int e = 0; e < 4; e++)
                                 if (bits & (1u << (tm * 16 + g * 4 + e))) {
                                     s_lent[lp] = pack_entry(key_of(acc[tp][tm][tn][4 * g + e], aux[tm][g][e]), rid[tm][g][e]);
-                                    s_lq[lp] = (uint16_t)qj;
+                                    s_lq[lp] = (uint16_t)(qj - q0);
+                                    s_lr[lp] = (uint16_t)lr;
                                     lp++;
+                                    lr++;
                                 }
                     bits = 0; // done
                 } else {
@@ -477,15 +485,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
             }
         }
     }
-    if (!boot) { // flush the workgroup-local admissions
+    if (!boot) { // flush the workgroup-local admissions: ONE returning global atomic per query of the tile, all in flight
+        __syncthreads();
+        if (tid < NBN) {
+            const uint32_t n = s_qcnt[tid];
+            s_qbase[tid] = n ? atomicAdd(&a.cs.cnt[q0 + tid], n) : 0u; // (n != 0 implies a real query)
+        }
         __syncthreads();
         const uint32_t total = *s_lcnt < (uint32_t)FL_CAP ? *s_lcnt : (uint32_t)FL_CAP;
         for (uint32_t i = tid; i < total; i += NTHREADS) {
             const uint64_t ent = s_lent[i];
             if (ent == kEntryMax) continue;
-            const int q = (int)s_lq[i];
-            const uint32_t pos = atomicAdd(&a.cs.cnt[q], 1u);
-            if (pos < a.cs.cap) a.cs.lists[(size_t)q * a.cs.cap + pos] = ent;
+            const int ql = (int)s_lq[i];
+            const uint32_t pos = s_qbase[ql] + (uint32_t)s_lr[i];
+            if (pos < a.cs.cap) a.cs.lists[(size_t)(q0 + ql) * a.cs.cap + pos] = ent;
         }
         return;
     }

@@ -265,11 +265,15 @@ __global__ __launch_bounds__(128 * NWC, NWC == 2 ? 2 : 1) void gemm_filter_tall_
     // workgroup-local admission list, carved from the ring (free: every wave is past the last K-step's reads once the
     // barrier below is behind it)
     constexpr int FL_CAP = 2048;
-    uint32_t *s_lcnt = reinterpret_cast<uint32_t *>(ring);
-    uint64_t *s_lent = reinterpret_cast<uint64_t *>(ring + 16);
-    uint16_t *s_lq = reinterpret_cast<uint16_t *>(ring + 16 + 2 * FL_CAP);
+    uint32_t *s_lcnt = reinterpret_cast<uint32_t *>(ring);              // entries in the list
+    uint32_t *s_qcnt = s_lcnt + 1;                                      // [TBN] of them per query of the tile ...
+    uint32_t *s_qbase = s_qcnt + TBN;                                   // [TBN] ... and where they start in the query's list
+    uint64_t *s_lent = reinterpret_cast<uint64_t *>(ring + 1024);
+    uint16_t *s_lq = reinterpret_cast<uint16_t *>(ring + 1024 + 2 * FL_CAP);
+    uint16_t *s_lr = s_lq + FL_CAP;                                     // rank of the entry among its query's
     __syncthreads();
     if (tid == 0) *s_lcnt = 0;
+    if (tid < TBN) s_qcnt[tid] = 0;
     __syncthreads();
 #pragma unroll
     for (int tm = 0; tm < 4; tm++) {
@@ -322,6 +326,7 @@ __global__ __launch_bounds__(128 * NWC, NWC == 2 ? 2 : 1) void gemm_filter_tall_
                 const uint32_t n = (uint32_t)__builtin_popcount(bits);
                 uint32_t lp = atomicAdd(s_lcnt, n);
                 if (lp + n <= (uint32_t)FL_CAP) {
+                    uint32_t lr = atomicAdd(&s_qcnt[qj - q0], n);
 #pragma unroll
                     for (int g = 0; g < 4; g++)
 #pragma unroll
@@ -329,7 +334,9 @@ __global__ __launch_bounds__(128 * NWC, NWC == 2 ? 2 : 1) void gemm_filter_tall_
                             if (bits & (1u << (g * 4 + e))) {
                                 s_lent[lp] = pack_entry(key_of(acc[tm][tn][4 * g + e], aux[g][e]), rid[g][e]);
                                 s_lq[lp] = (uint16_t)(qj - q0);
+                                s_lr[lp] = (uint16_t)lr;
                                 lp++;
+                                lr++;
                             }
                     bits = 0;
                 } else {
@@ -349,15 +356,20 @@ __global__ __launch_bounds__(128 * NWC, NWC == 2 ? 2 : 1) void gemm_filter_tall_
             }
         }
     }
-    if (!a.boot) { // flush the workgroup-local admissions: every entry's returning global atomic in flight at once
+    if (!a.boot) { // flush the workgroup-local admissions: ONE returning global atomic per query of the tile, all in flight
+        __syncthreads();
+        if (tid < TBN) {
+            const uint32_t n = s_qcnt[tid];
+            s_qbase[tid] = n ? atomicAdd(&a.cs.cnt[q0 + tid], n) : 0u; // (n != 0 implies a real query)
+        }
         __syncthreads();
         const uint32_t total = *s_lcnt < (uint32_t)FL_CAP ? *s_lcnt : (uint32_t)FL_CAP;
         for (uint32_t i = tid; i < total; i += TTHREADS) {
             const uint64_t ent = s_lent[i];
             if (ent == kEntryMax) continue;
-            const int q = q0 + (int)s_lq[i];
-            const uint32_t pos = atomicAdd(&a.cs.cnt[q], 1u);
-            if (pos < a.cs.cap) a.cs.lists[(size_t)q * a.cs.cap + pos] = ent;
+            const int ql = (int)s_lq[i];
+            const uint32_t pos = s_qbase[ql] + (uint32_t)s_lr[i];
+            if (pos < a.cs.cap) a.cs.lists[(size_t)(q0 + ql) * a.cs.cap + pos] = ent;
         }
     }
 }
