@@ -905,9 +905,10 @@ void launch_rerank(int metric, int order, const float *X, int D, const float *Q,
     const size_t shmem = (size_t)Dpad * 4 + P * 8 + P * 4 + 16;
     dim3 grid(nq), block(SEL_THREADS);
     static const int split_on = lb_tunable("LB_RERANK_SPLIT", 1);
-    // Worth it while the whole launch is one wave of workgroups (a workgroup's life is a chain of ~8 memory round trips,
-    // two resident per CU): 30 vs 38-40 us at 8 queries, 33 vs 40 at 16, level at 32, slower from 64 on (66 vs 42 us).
-    if (a.aligned && D >= 4 && done != nullptr && split_on && cs.cap >= 3u * (uint32_t)P && (size_t)nq * (P / RS_ROWS) <= 256) {
+    static const int split_max_wg = lb_tunable("LB_RERANK_SPLIT_MAXWG", 512);
+    // Worth it while the whole launch is resident at once (a workgroup's life is a chain of ~8 memory round trips, two
+    // resident per CU): 30 vs 38-40 us at 8 queries, 33 vs 40 at 16, 35 vs 39 at 32, slower from 64 on (66 vs 42 us).
+    if (a.aligned && D >= 4 && done != nullptr && split_on && cs.cap >= 3u * (uint32_t)P && (size_t)nq * (P / RS_ROWS) <= (size_t)split_max_wg) {
         const size_t sh_rows = (size_t)RS_ROWS * RS_LD * 4 + RS_SD * 4 + RS_ROWS * 4;
         const size_t sh3 = std::max(sh_rows, shmem);
         dim3 grid3((unsigned)(P / RS_ROWS), (unsigned)nq);
