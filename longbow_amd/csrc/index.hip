@@ -398,6 +398,7 @@ struct SamplePlan {
     int m = 0;
 };
 std::atomic<int> g_sample_tau{lb_tunable("LB_SAMPLE_TAU", 1)};
+std::atomic<int> g_fused_fail_next{0}; // test hook: treat the next fused launch as one whose waits gave up
 // Add batches of at least this many bytes pin the caller's buffer instead of staging it (0 = never)
 std::atomic<long long> g_add_register_min{(long long)lb_tunable("LB_ADD_REGISTER_MIN_MB", 64) << 20};
 static SamplePlan sample_plan(int64_t n, int keep, uint32_t cap, uint32_t count_max = 8192u)
@@ -742,7 +743,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     }
     std::vector<int> bad;
     int nbad = collect_flagged(w, s, nq, 3u | 4u, nullptr, 0, bad, /*on_host=*/true);
-    if (fused_epoch != 0 && *w->h_fail == fused_epoch) {
+    if (fused_epoch != 0 && (*w->h_fail == fused_epoch || g_fused_fail_next.exchange(0) != 0)) {
         // a wait inside the fused launch gave up (its workgroups were not co-resident): every query goes the exact way,
         // and the ticket counter is re-based in case the launch did not run to completion
         bad.resize((size_t)nq);
@@ -1468,6 +1469,7 @@ int lb_gpu_index_last_timing(const lb_gpu_index *hc, float ms[5], int n_launch[5
 // Test hooks (both settings are exact; they only choose between two schedules / expose host logic).
 void lb_debug_set_sample_tau(int v) { g_sample_tau.store(v); } // 0: classic bootstrap schedule only
 void lb_debug_vmm_fail_next(int v) { g_vmm_fail_next.store(v); } // the next in-place growth is refused (-> hipMalloc + copy)
+void lb_debug_fused_fail_next(int v) { g_fused_fail_next.store(v); } // the next fused sample launch counts as timed out (-> exact path for the batch)
 void lb_debug_set_add_register_min(long long bytes) { g_add_register_min.store(bytes); } // ingest A/B (tools/bench_add.py)
 // host-only: the sampled-threshold plan for a view of n rows (tests check its invariants without a GPU);
 // out = {on, span, count, m}

@@ -466,6 +466,44 @@ def test_tall_tile_every_route(oracle, metric):
     idx.Close()
 
 
+def test_fused_sample_launch_and_its_give_up_path(oracle):
+    """5-32 queries on >= 64k rows: the sampled threshold rides inside the candidate launch (sample tiles, per-query
+    threshold workgroups, corpus workgroups that pick the thresholds up).  Results equal the oracle; when a wait inside
+    the launch gives up (forced here through the host hook) the whole batch is redone on the exact path and the next
+    searches run fused again."""
+    gpu_or_skip()
+    import ctypes as C
+    from longbow_amd import _lib
+    lib = _lib.load()
+    lib.lb_debug_fused_fail_next.argtypes = [C.c_int]
+    rng = np.random.default_rng(99)
+    n, d, k = 150_000, 64, 25
+    X = rng.standard_normal((n, d)).astype(F)
+    Q = rng.standard_normal((32, d)).astype(F)
+    for metric in (0, 1, 2):
+        idx = new_index(d, metric)
+        idx.Add(None, X)
+        want = {nq: oracle.search_batch(metric, Q[:nq], X, k, nthreads=8) for nq in (5, 9, 32)}
+        for rep in range(3):
+            for nq in (5, 9, 32):
+                lab, dist = idx.SearchBatch(Q[:nq], k)
+                assert_same(lab, dist, want[nq][0], want[nq][1], f"fused metric={metric} nq={nq} rep={rep}")
+                assert idx.last_fallbacks <= nq // 4
+        lib.lb_debug_fused_fail_next(1)
+        lab, dist = idx.SearchBatch(Q[:9], k)
+        assert_same(lab, dist, want[9][0], want[9][1], f"fused give-up metric={metric}")
+        assert idx.last_fallbacks == 9
+        lab, dist = idx.SearchBatch(Q[:32], k)
+        assert_same(lab, dist, want[32][0], want[32][1], f"fused after give-up metric={metric}")
+        assert idx.last_fallbacks <= 8
+        mask = (rng.random(n) < 0.6).astype(np.uint8)   # compacted row list under the fused launch
+        idx.set_filter(mask)
+        oi, od = oracle.search_batch(metric, Q[:16], X, k, mask=mask, nthreads=8)
+        lab, dist = idx.SearchBatch(Q[:16], k)
+        assert_same(lab, dist, oi, od, f"fused masked metric={metric}")
+        idx.Close()
+
+
 def test_growth_survives_a_refused_mapping(oracle):
     """the corpus grows in place through the virtual-memory API; when the driver refuses to extend the mapping
     (forced here) the rows move once into a hipMalloc buffer and the index keeps working, ids and all"""
