@@ -22,7 +22,7 @@
 // Measured and dropped (1M x 768, 1024 queries, no effect beyond the 3 % run-to-run noise): wave priority raised over the
 // MFMA block, a fixed priority difference between the two workgroups of a CU, the DMA requests issued behind the first
 // fragment reads instead of in front of them, and an epilogue with one atomic round trip per lane instead of one per
-// MFMA tile.  rocprofv3 (tools/prof_tall.sh): no LDS bank conflicts, LDS index unit 13 % busy, shader clock 1.77 GHz under
+// MFMA tile.  rocprofv3 (tools/prof_tall.sh): no LDS bank conflicts in the main loop, LDS index unit 13 % busy, shader clock 1.77 GHz under
 // this kernel (2.10 under the f32 kernel): the matrix pipe is busy 60 % of the kernel's cycles.
 //
 // Operands.  Queries always come as the split image (launch_split_bf16 on the batch: hi / lo bf16 pairs in the
