@@ -640,7 +640,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     if (use_tall && wsplit == 2) split_queries();
     // Up to 64 queries on the narrow split tiles the sample and its thresholds ride INSIDE the candidate launch (FUSED
     // in kernels_gemm_narrow.hip: 19-34 us of sample + 13 us of threshold kernel off the critical path).
-    static const int fused_max = lb_tunable("LB_FUSED_SAMPLE_MAXQ", 32); // (measured level or behind at 33-64 queries: the 64-query tile)
+    static const int fused_max = lb_tunable("LB_FUSED_SAMPLE_MAXQ", 32); // (33-64 queries, the 64-query tile: measured level)
     const bool fused = sp.on && use_narrow && nsplit && nq <= fused_max && nq <= 64;
     static const int light_max = lb_tunable("LB_LIGHT_SAMPLE_MAXQ", 8);
     const bool light_sample = sp.on && !fused && nq <= light_max;

@@ -60,7 +60,7 @@ __device__ __forceinline__ int nswz(int row, int chunk) { return row * NBK + ((c
 #ifdef LB_DIAG
 // timing probe of the fused launch (100 MHz real-time ticks): [0] first entry stamp (min), [1] last threshold published
 // (max), [2] sum of the corpus workgroups' waits for thresholds, [3] corpus workgroups, [4] those that had to wait,
-// [5] last sample workgroup's keys out (max)
+// [5] last sample workgroup's keys out (max), [6] last threshold workgroup has its keys loaded, [7] ... its rounds done
 __device__ unsigned long long g_fused_probe[8];
 void read_fused_probe(unsigned long long out[8], bool reset)
 {
@@ -74,15 +74,6 @@ void read_fused_probe(unsigned long long out[8], bool reset)
 // ---- helpers of the fused sample (FUSED) ---------------------------------------------------------------------
 constexpr uint32_t kSpinLimit = 40000; // x ~0.25 us: a wait that long means the launch's workgroups are not co-resident
 
-__device__ __forceinline__ uint64_t wave_min_u64_shfl(uint64_t v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const uint64_t o = __shfl_xor(v, off);
-        v = o < v ? o : v;
-    }
-    return v;
-}
 // ||q||^2 in the reference's accumulation order (as kernels_scan.hip: exact_sq_norm_lds), q in LDS, one lane
 __device__ __forceinline__ float narrow_exact_sq_norm(const float *sq, int D, int order)
 {
@@ -517,6 +508,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
     if (j >= a.nq) return;
     uint32_t *s_flag = reinterpret_cast<uint32_t *>(lds_all);
     if (tid == 0) a.cs.flags[j] = 0; // (nothing in this launch sets status bits; select / re-rank run behind it)
+    if (a.fs.qna) { // cosine: exact ||q_j||^2 for the re-rank -- while the slower sample workgroups finish
+        float *sq = lds_all + 64;
+        const float *q = a.Q + (int64_t)j * a.D;
+        for (int i = tid; i < a.D; i += NTHREADS) sq[i] = q[i];
+        __syncthreads();
+        if (tid == 0) a.fs.qna[j] = narrow_exact_sq_norm(sq, a.D, a.fs.order);
+        __syncthreads();
+    }
     if (tid == 0) {
         uint32_t ok = 0;
         for (uint32_t it = 0; it < kSpinLimit; it++) {
@@ -542,34 +541,53 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
             const uint32_t idx = (uint32_t)tid + (uint32_t)NTHREADS * i;
             e[i] = idx < a.fs.count ? __hip_atomic_load(&klist[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kEntryMax;
         }
-        uint64_t *s_wmin = reinterpret_cast<uint64_t *>(lds_all) + 8; // [2][4]
-        kth = kEntryMax;
-        for (int r = 0; r < a.fs.m; r++) {
+#ifdef LB_DIAG
+        if (tid == 0 && e[0] != 0) atomicMax(&g_fused_probe[6], (unsigned long long)__builtin_amdgcn_s_memrealtime()); // keys loaded
+#endif
+        // two levels, no workgroup barrier inside the rounds: each wave extracts the m smallest of ITS 2048 entries (m rounds
+        // of a wave-wide minimum on DPP), then wave 0 extracts the m-th smallest of the 4 m survivors
+        uint64_t *s_top = reinterpret_cast<uint64_t *>(lds_all) + 8; // [4][32]
+        const int m = a.fs.m; // <= 32
+        for (int r = 0; r < m; r++) {
             uint64_t v = e[0];
 #pragma unroll
             for (int i = 1; i < PER; i++) v = e[i] < v ? e[i] : v;
-            v = wave_min_u64_shfl(v);
-            if (lane == 0) s_wmin[(r & 1) * 4 + wave] = v;
-            __syncthreads();
-            uint64_t g = s_wmin[(r & 1) * 4];
+            v = wave_min_u64(v);
+            if (lane == 0) s_top[wave * 32 + r] = v;
+            if (v != kEntryMax) {
 #pragma unroll
-            for (int w = 1; w < 4; w++) g = s_wmin[(r & 1) * 4 + w] < g ? s_wmin[(r & 1) * 4 + w] : g;
-            kth = g;
-            if (g == kEntryMax) break; // fewer than m visible sample rows: no threshold
-#pragma unroll
-            for (int i = 0; i < PER; i++)
-                if (e[i] == g) e[i] = kEntryMax; // entries are unique
+                for (int i = 0; i < PER; i++)
+                    if (e[i] == v) e[i] = kEntryMax; // entries are unique
+            }
         }
+        __syncthreads();
+        kth = kEntryMax;
+        if (wave == 0) {
+            uint64_t c0 = lane < m ? s_top[lane] : kEntryMax, c1 = lane < m ? s_top[32 + lane] : kEntryMax;       // (lanes 0..31:
+            uint64_t c2 = lane < m ? s_top[64 + lane] : kEntryMax, c3 = lane < m ? s_top[96 + lane] : kEntryMax;  //  4 entries each)
+            if (lane >= 32) c0 = c1 = c2 = c3 = kEntryMax;
+            for (int r = 0; r < m; r++) {
+                uint64_t v = c0 < c1 ? c0 : c1;
+                const uint64_t w2 = c2 < c3 ? c2 : c3;
+                v = w2 < v ? w2 : v;
+                v = wave_min_u64(v);
+                kth = v;
+                if (v == kEntryMax) break; // fewer than m visible sample rows: no threshold
+                if (c0 == v) c0 = kEntryMax;
+                if (c1 == v) c1 = kEntryMax;
+                if (c2 == v) c2 = kEntryMax;
+                if (c3 == v) c3 = kEntryMax;
+            }
+            if (lane == 0) s_top[0] = kth;
+        }
+        __syncthreads();
+        kth = s_top[0];
         if (kth != kEntryMax) kth |= 0xffffffffull; // row bits saturated, as sample_tau_kernel
+#ifdef LB_DIAG
+        if (tid == 0) atomicMax(&g_fused_probe[7], (unsigned long long)__builtin_amdgcn_s_memrealtime()); // rounds done
+#endif
     }
     __syncthreads();
-    if (a.fs.qna) { // cosine: exact ||q_j||^2 for the re-rank (off every critical path here)
-        float *sq = lds_all + 64;
-        const float *q = a.Q + (int64_t)j * a.D;
-        for (int i = tid; i < a.D; i += NTHREADS) sq[i] = q[i];
-        __syncthreads();
-        if (tid == 0) a.fs.qna[j] = narrow_exact_sq_norm(sq, a.D, a.fs.order);
-    }
     if (tid == 0) {
         __hip_atomic_store(&a.cs.cnt[j], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&a.cs.tau[j], kth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -649,35 +649,6 @@ void launch_sample_scores(int metric, int order, const float *X, int D, int64_t 
 constexpr int ST_THREADS = 1024;
 constexpr int ST_PER = 8;
 
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint64_t min_dpp_u64(uint64_t v)
-{
-    const int lo = (int)(uint32_t)v, hi = (int)(uint32_t)(v >> 32);
-    const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
-    const int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
-    const uint64_t o = ((uint64_t)(uint32_t)ohi << 32) | (uint64_t)(uint32_t)olo;
-    return o < v ? o : v;
-}
-// minimum over each row of 16 lanes, left in every lane of the row
-__device__ __forceinline__ uint64_t row16_min_u64(uint64_t v)
-{
-    v = min_dpp_u64<0xB1, 0xf>(v);  // quad_perm [1,0,3,2]
-    v = min_dpp_u64<0x4E, 0xf>(v);  // quad_perm [2,3,0,1]
-    v = min_dpp_u64<0x141, 0xf>(v); // row_half_mirror
-    v = min_dpp_u64<0x140, 0xf>(v); // row_mirror
-    return v;
-}
-// minimum over the 64 lanes, returned wave-uniform
-__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
-{
-    v = row16_min_u64(v);
-    v = min_dpp_u64<0x142, 0xa>(v); // row_bcast15: rows 1,3 <- lane 15 of rows 0,2
-    v = min_dpp_u64<0x143, 0xc>(v); // row_bcast31: rows 2,3 <- lane 31
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63);
-    return ((uint64_t)hi << 32) | lo;
-}
-
 __global__ __launch_bounds__(ST_THREADS) void sample_tau_kernel(CandState cs, const int *qsel, int nsel, uint32_t count, int m,
                                                                 int zero_stripes, const float *Q, int D, float *qna, int order)
 {

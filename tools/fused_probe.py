@@ -24,5 +24,5 @@ for B in [int(x) for x in sys.argv[1:]] or [8, 32]:
     idx.search_device(B, q.data_ptr(), K, od.data_ptr(), ol.data_ptr()); torch.cuda.synchronize()
     raw.lb_debug_read_fused_probe(probe, 1)
     t0 = probe[0]
-    print(f"B={B}: sample keys out at {(probe[5]-t0)/100:.1f} us, thresholds published at {(probe[1]-t0)/100:.1f} us; "
+    print(f"B={B}: sample keys out at {(probe[5]-t0)/100:.1f} us, keys loaded by {(probe[6]-t0)/100:.1f}, rounds done by {(probe[7]-t0)/100:.1f}, thresholds published at {(probe[1]-t0)/100:.1f} us; "
           f"{probe[3]} corpus workgroups, {probe[4]} found no threshold yet, mean fetch/wait {probe[2]/max(probe[3],1)/100:.2f} us")
