@@ -8,13 +8,18 @@
 // 32x32 tiles, 32 accumulator VGPRs); each wave stages exactly the 64 corpus rows it consumes
 // (8 direct-to-LDS DMA instructions of 1 KiB per K-step, nt policy) plus a quarter of the 4 KiB query
 // tile; LDS 2 x (32 + 4) KiB, two workgroups per CU = 64 KiB of corpus bytes in flight per CU.
-// LDS image, swizzle, k permutation and the epilogue (key, branch-free admission, one atomic per
-// lane) are those of the wide kernel.
+// LDS image, swizzle, k permutation and the admission test (key, branch-free) are those of the wide
+// kernel; admitted entries go through a workgroup-local LDS list and out with one returning global
+// atomic per query of the tile (the wide kernel's one-atomic-per-lane epilogue stalls a wave once per
+// lane with admissions -- fine under 41 us of MFMAs per tile, not under a 66 us HBM-bound one).
 //
 // The kernel is a template over the tile: <256 rows, 32 queries> (above) and <128 rows, 64 queries>
 // for batches of 33..~200 queries (each wave 32 rows x 64 queries, again 2 MFMA tiles; LDS
 // 2 x (16 + 8) KiB, three workgroups per CU), which would otherwise pay a second corpus pass per
-// extra 32 queries.
+// extra 32 queries; over SPLIT (the contraction on 3 x bf16 MFMA with both operands split in
+// registers: the default) and over FUSED (5..32 queries: the sampled threshold of the search rides
+// inside the launch -- sample tiles, per-query threshold workgroups, corpus workgroups of two row
+// tiles that pick the thresholds up; see FusedSample in lb_device.h and DESIGN.md 3.3).
 #include "lb_device.h"
 
 namespace lb {
