@@ -644,14 +644,21 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     const bool fused = sp.on && use_narrow && nsplit && nq <= fused_max && nq <= 64;
     static const int light_max = lb_tunable("LB_LIGHT_SAMPLE_MAXQ", 8);
     const bool light_sample = sp.on && !fused && nq <= light_max;
-    const bool norm_riders = sp.on && nq <= 64 && metric == LB_METRIC_COSINE;
+    static const int riders_max = lb_tunable("LB_NORM_RIDERS_MAXQ", 384);
+    const bool norm_riders = sp.on && nq <= riders_max && metric == LB_METRIC_COSINE;
     if (!light_sample && !fused) launch_init_cand(w->cs, nullptr, nq, s);
     if (metric == LB_METRIC_COSINE && !norm_riders) launch_query_norms(order, d_q, nullptr, nq, h->dim, w->d_qna, s);
+    static const bool sample_narrow = lb_tunable("LB_TALL_SAMPLE_NARROW", 1) != 0;
     auto candidates = [&](int64_t b, int64_t e, const uint32_t *rowmap, bool boot) {
         ProfScope p(w, s, prof, 0);
         if (use_narrow)
             launch_gemm_filter_narrow(metric, gx, h->d_norm2, h->d_rnorm, b, e, h->dim, gq, nq, mask, rowmap,
                                       w->cs, boot, s, tile64, nsplit);
+        else if (use_tall && boot && wsplit == 2 && sample_narrow)
+            // the 8192-row sample of a tall-tile search: the 64-query tile of the narrow kernel (same contraction, f32
+            // operands) gets through its 24 K-steps of 32 in 31-35 us, the tall tile through its 48 of 16 in 57
+            launch_gemm_filter_narrow(metric, h->d_X, h->d_norm2, h->d_rnorm, b, e, h->dim, d_q, nq, mask, rowmap, w->cs,
+                                      true, s, /*tile64=*/true, /*split=*/true);
         else if (use_tall)
             launch_gemm_filter_tall(metric, gx, h->d_norm2, h->d_rnorm, b, e, h->dim, w->d_qs, nq, mask, rowmap, w->cs,
                                     boot, wsplit, s);
