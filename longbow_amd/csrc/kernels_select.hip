@@ -376,8 +376,9 @@ void launch_select(CandState cs, const int *qsel, int nsel, int kc, uint32_t boo
     const size_t shmem = (size_t)next_pow2_host(cs.cap) * sizeof(uint64_t) + (256 + 4 + 8) * sizeof(uint32_t);
     // lists up to this size are simply sorted (one 1024-thread workgroup); larger ones take the radix select
     static const uint32_t sort_max_big = (uint32_t)lb_tunable("LB_SELECT_SORT_MAX", 0);
-    const uint32_t sort_max = nsel <= 32 ? sort_max_big : 0u;
-    if (nsel <= 32) { // few queries: one big workgroup each, latency matters
+    static const int big_max = lb_tunable("LB_SELECT_BIG_MAXQ", 512); // (1024-thread selects: 10 us less than 256-thread ones at 128-384 queries)
+    const uint32_t sort_max = nsel <= big_max ? sort_max_big : 0u;
+    if (nsel <= big_max) { // few queries: one big workgroup each, latency matters
         allow_big_lds(select_kernel<1024>, shmem);
         hipLaunchKernelGGL(select_kernel<1024>, dim3(nsel), dim3(1024), shmem, s, cs, qsel, kc, boot_rows,
                            tau_only ? 1u : 0u, need_at_least, sort_max, em,
