@@ -466,6 +466,30 @@ def test_tall_tile_every_route(oracle, metric):
     idx.Close()
 
 
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_every_path_boundary(oracle, metric):
+    """batch sizes on both sides of every switch of the path selection (exact scan | fused narrow launch | 64-query tile |
+    tall tile / multi-pass | f32 tile), on a corpus large enough for the sampled threshold, plain and under a filter"""
+    gpu_or_skip()
+    rng = np.random.default_rng(4242 + metric)
+    n, d, k = 70_001, 64, 12
+    X = rng.standard_normal((n, d)).astype(F)
+    Q = rng.standard_normal((385, d)).astype(F)
+    idx = new_index(d, metric)
+    idx.Add(None, X)
+    full = oracle.search_batch(metric, Q, X, k, nthreads=8)
+    for nq in (1, 4, 5, 8, 9, 16, 17, 32, 33, 64, 65, 128, 129, 192, 193, 384, 385):
+        lab, dist = idx.SearchBatch(Q[:nq], k)
+        assert_same(lab, dist, full[0][:nq], full[1][:nq], f"boundary metric={metric} nq={nq}")
+    mask = (rng.random(n) < 0.5).astype(np.uint8)
+    idx.set_filter(mask)
+    fm = oracle.search_batch(metric, Q[:129], X, k, mask=mask, nthreads=8)
+    for nq in (5, 32, 33, 65, 129):
+        lab, dist = idx.SearchBatch(Q[:nq], k)
+        assert_same(lab, dist, fm[0][:nq], fm[1][:nq], f"boundary masked metric={metric} nq={nq}")
+    idx.Close()
+
+
 def test_fused_sample_launch_and_its_give_up_path(oracle):
     """5-32 queries on >= 64k rows: the sampled threshold rides inside the candidate launch (sample tiles, per-query
     threshold workgroups, corpus workgroups that pick the thresholds up).  Results equal the oracle; when a wait inside
