@@ -16,10 +16,16 @@ namespace lb {
 constexpr int ADC_THREADS = 1024;
 
 __global__ __launch_bounds__(256) void build_adc_table_kernel(const float *codebooks, int M, int K, int sub,
-                                                              const float *Q, float *tables, float *minrng)
+                                                              const float *Q, float *tables, float *minrng,
+                                                              uint32_t *zero_a, uint32_t *zero_b)
 {
     const int q = blockIdx.y;
     const int i = blockIdx.x;
+    // per-query status words of the search that follows (saves two memset launches on its critical path)
+    if (i == 0 && threadIdx.x == 0) {
+        if (zero_a) zero_a[q] = 0;
+        if (zero_b) zero_b[q] = 0;
+    }
     float mn = __builtin_huge_valf(), mx = -__builtin_huge_valf();
     int bad = 0;
     const float *qs = Q + ((int64_t)q * M + i) * sub;
@@ -72,10 +78,11 @@ __global__ __launch_bounds__(256) void build_adc_table_kernel(const float *codeb
 }
 
 void launch_build_adc_table(const float *codebooks, int M, int K, int sub, const float *Q, int nq,
-                            float *tables, hipStream_t s, float *minrng)
+                            float *tables, hipStream_t s, float *minrng, uint32_t *zero_a, uint32_t *zero_b)
 {
     if (nq <= 0) return;
-    hipLaunchKernelGGL(build_adc_table_kernel, dim3(M, nq), dim3(256), 0, s, codebooks, M, K, sub, Q, tables, minrng);
+    hipLaunchKernelGGL(build_adc_table_kernel, dim3(M, nq), dim3(256), 0, s, codebooks, M, K, sub, Q, tables, minrng,
+                       zero_a, zero_b);
 }
 
 struct AdcArgs {

@@ -260,7 +260,8 @@ void launch_fill_uniform_rows(float *dst, const int64_t *ids, int64_t nrows, int
 // PQ
 // minrng (nullable): [nq][M][4] = {min, max - min, 1.0 if the subtable holds a NaN / negative / infinite entry, 0}
 void launch_build_adc_table(const float *codebooks, int M, int K, int sub, const float *Q, int nq,
-                            float *tables, hipStream_t s, float *minrng = nullptr);
+                            float *tables, hipStream_t s, float *minrng = nullptr,
+                            uint32_t *zero_a = nullptr, uint32_t *zero_b = nullptr); // zero_*: [nq] words cleared on the way
 // one query per launch: `table` is that query's [M*256] table; entries go to cs slot `slot`,
 // or (all_out != nullptr) every distance is written to all_out[row - out_base].
 // skip_if_ok (nullable): {s_tau, ok} of the byte-table prefilter; the launch returns at once when ok != 0

@@ -540,9 +540,8 @@ int lb_gpu_pq_search_device(lb_gpu_pq *p, int64_t nq, const float *d_queries, in
                 if (!e) LBP_HIP(hipEventCreate(&e));
             LBP_HIP(hipEventRecord(p->ev[0], s));
         }
-        launch_build_adc_table(p->d_codebooks, p->M, p->K, p->sub, d_queries, nqi, sc.d_tables, s, prefilter ? sc.d_minrng : nullptr);
-        LBP_HIP(hipMemsetAsync(sc.cs.flags, 0, (size_t)nqi * 4, s));
-        if (prefilter) LBP_HIP(hipMemsetAsync(sc.d_cand_cnt, 0, (size_t)nqi * 4, s));
+        launch_build_adc_table(p->d_codebooks, p->M, p->K, p->sub, d_queries, nqi, sc.d_tables, s, prefilter ? sc.d_minrng : nullptr,
+                               sc.cs.flags, prefilter ? sc.d_cand_cnt : nullptr); // (also clears the slots' status words)
         const EmitArgs em{k, nullptr, d_dist, d_labels, nullptr};
         // mode 0: sampled threshold (+ byte-table prefilter), 1: bootstrap chunks, 2: chunks that cannot overflow
         auto scan_query = [&](int q, int mode) {
