@@ -17,7 +17,12 @@ inputs resident in HBM.
   N > 1, --scaling strong   BASELINE config 3: a FIXED 10M x 768 dot corpus partitioned the same way;
                        value = global queries/s = 1024 / step_time; N = 1 holds all 10M rows.
 
-Launched for N > 1 by torch.distributed.run, one rank per GPU.  Prints ONE JSON line on rank 0.
+One rank per GPU.  `python bench.py --gpus N` with no WORLD_SIZE in the environment starts the N ranks itself
+(torch.distributed.run as a child process, BEFORE this process imports torch or touches the GPU) and relays rank 0's
+JSON line; under `python -m torch.distributed.run ... bench.py --gpus N` it is one of the ranks.  The exchange is the
+library's own RCCL path (lb_gpu_comm_*, LB_BENCH_COMM=lib, default; =torch: torch.distributed's all-gather).
+Every run also carries a `strong_c3` leg (BASELINE config 3: a fixed 10M x 768 dot corpus over the N GPUs).
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -34,6 +39,8 @@ N_ROWS, DIM, BATCH, K = 1_000_000, 768, 1024, 100
 METRIC_COSINE, METRIC_DOT = 1, 2
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X dense f32 MFMA (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_HBM_GBS = 8000.0          # HBM3E spec
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA (same guide)
+CAND_F32, CAND_IMAGE, CAND_INREG, CAND_AUTO = 0, 1, 2, 3  # lb_candidate_mode
 
 
 def host_cores():
@@ -86,14 +93,19 @@ def leg_batch_sweep(torch, dev, idx, Q, rows):
     batches sequentially, internal/store/vector_search_action.go:73)"""
     out = []
     stream = torch.cuda.current_stream(dev).cuda_stream
-    for B in (1, 2, 4, 8, 16, 32, 64, 128, 256):
+    for B in (1, 2, 4, 8, 16, 32, 64, 128, 256, 384, 512, 1024):
         od = torch.empty((B, K), device=dev)
         ol = torch.empty((B, K), dtype=torch.int64, device=dev)
         q = Q[:B].contiguous()
         ms = timed_ms(lambda: idx.search_device(B, q.data_ptr(), K, od.data_ptr(), ol.data_ptr(), stream), torch, dev, n=9, skip=3)
-        out.append({"batch": B, "ms": round(ms, 4), "queries_per_s": round(B / ms * 1e3, 1),
+        # binding roof of the batch: the corpus stream (HBM) or the split contraction's 3 x 2 B N D bf16 flop (MFMA)
+        hbm_ms = 4.0 * rows * DIM / (PEAK_HBM_GBS * 1e9) * 1e3
+        mfma_ms = 6.0 * B * rows * DIM / (PEAK_BF16_MFMA_TFLOPS * 1e12) * 1e3
+        out.append({"batch": B, "ms": round(ms, 4), "ms_per_query": round(ms / B, 5), "queries_per_s": round(B / ms * 1e3, 1),
                     "corpus_read_equiv_TBs": round(4.0 * rows * DIM / (ms * 1e-3) / 1e12, 3),
-                    "frac_of_8TBs": round(4.0 * rows * DIM / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)})
+                    "frac_of_8TBs": round(hbm_ms / ms, 4),
+                    "binding_roof": "hbm" if hbm_ms >= mfma_ms else "mfma_bf16_split",
+                    "frac_of_binding_roof": round(max(hbm_ms, mfma_ms) / ms, 4)})
     return out
 
 
@@ -135,13 +147,12 @@ def leg_pq_adc(torch, dev, lib, _lib, cores, check=True):
         dms.append(b)
     enc.set_profiling(False)
     k_ms, d_ms = median(kms[2:]), median(dms[2:])
-    lib.lb_debug_set_adc_prefilter.argtypes = [C.c_int]
-    lib.lb_debug_set_adc_prefilter(0)
+    enc.set_prefilter(False)  # the exact f32-table pass over every row (same results, A/B)
     try:
         ms_exact = timed_ms(lambda: enc.search_device(1, Q.data_ptr(), K, od.data_ptr(), ol.data_ptr()), torch, dev, n=8, skip=3)
         same = bool(np.array_equal(ol.cpu().numpy()[:1], lab[:1]) and np.array_equal(od.cpu().numpy()[:1], dist[:1]))
     finally:
-        lib.lb_debug_set_adc_prefilter(1)
+        enc.set_prefilter(True)
     res = {
         "workload": "100M x 768 f32 -> PQ m=96 K=256 codes (9.6 GB), asymmetric distance, k=100, B=1",
         "ms_per_query": round(ms1, 4), "queries_per_s": round(1e3 / ms1, 1),
@@ -222,89 +233,106 @@ def leg_filtered_hybrid(torch, dev, lib, _lib, cores):
             "parity": {"checked_queries": 2, "ok": ok}}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rows", type=int, default=N_ROWS, help="rows per GPU (weak) / global rows (strong: default 10M)")
-    ap.add_argument("--batch", type=int, default=BATCH)
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-fast", action="store_true", help="skip the split-bf16 candidate-mode leg")
-    ap.add_argument("--no-legs", action="store_true", help="skip the secondary legs (sweep, PQ, filtered hybrid)")
-    ap.add_argument("--cpu-queries", type=int, default=0, help="CPU baseline sample size (0 = 16 per core)")
-    args = ap.parse_args()
+def launch_ranks(args, argv):
+    """--gpus N > 1 without a launcher: start N fresh rank processes (torch.distributed.run) as a CHILD of this
+    process, relay rank 0's JSON line, exit with the child's code.  Nothing in this process has imported torch or
+    touched the GPU (a process that has initialised HIP must never exec or be re-used as a launcher on this pool)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["LB_BENCH_CHILD"] = "1"
+    if os.environ.get("LB_BENCH_LAUNCH_ECHO") == "1":  # CPU test hook: show what would be started, and from what state
+        print(json.dumps({"cmd": cmd, "torch_imported": "torch" in sys.modules,
+                          "longbow_imported": any(m.startswith("longbow_amd") for m in sys.modules)}), flush=True)
+        return 0
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:
+        out = out.rstrip("\n")
+        if out.startswith("{") and '"metric"' in out:
+            line = out
+        else:
+            print(out, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    return rc if rc != 0 else (0 if line is not None else 1)
 
-    import torch
-    import torch.distributed as dist
-    from longbow_amd import _lib, gpu
-    from longbow_amd.sharded import CommSearcher, GpuPartition, ShardedSearcher
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    # LB_BENCH_FORCE_DIST=1 exercises the collective path (process group, all-gather, merge) even with one
-    # rank, so the multi-GPU code can be rehearsed on a single-GPU box.
-    use_dist = world > 1 or os.environ.get("LB_BENCH_FORCE_DIST") == "1"
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29512")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+class Job:
+    """what every leg needs: torch, device, library, rank / world, the process group switch"""
 
-    lib = _lib.require_gpu(local_rank)
-    strong = args.scaling == "strong"
-    metric = METRIC_DOT if strong else METRIC_COSINE
-    B = args.batch
-    global_rows = (10_000_000 if args.rows == N_ROWS else args.rows) if strong else args.rows * world
 
-    # ---- synthetic inputs, generated in HBM (uniform [0,1), corpus seed 12345, queries 42) ----
-    shards_per_gpu = 8
-    part = GpuPartition(world, shards_per_gpu, 40)
-    if world > 1 or use_dist:
-        my_ids = rank_ids(part, rank, global_rows)
-    else:
-        my_ids = None
-    rows = int(my_ids.size) if my_ids is not None else global_rows
-    Q = torch.empty((B, DIM), device=dev)
-    _lib.check(lib.lb_gpu_fill_uniform_device(local_rank, Q.data_ptr(), Q.numel(), 42, 0, None))
-    idx = gpu.NewIndexWithConfig(gpu.GPUConfig(DeviceID=local_rank, Dimension=DIM, Metric=metric))
+def build_index(job, metric, rows_global, part, mode):
+    """this rank's shard of a synthetic corpus of rows_global rows (ids 0 .. rows_global-1, content a function of the
+    id), generated in HBM: SURVEY 8d -- uniform [0,1), corpus seed 12345"""
+    torch, dev, lib, _lib, gpu = job.torch, job.dev, job.lib, job._lib, job.gpu
+    di = job.local_rank
+    my_ids = rank_ids(part, job.rank, rows_global) if job.use_dist else None
+    rows = int(my_ids.size) if my_ids is not None else rows_global
+    idx = gpu.NewIndexWithConfig(gpu.GPUConfig(DeviceID=di, Dimension=DIM, Metric=metric))
+    idx.set_candidate_mode(mode)
     idx.reserve(rows)
     X = None
+    CH = 1_000_000
     if my_ids is None:
-        CH = 1_000_000
         if rows <= 2 * CH:
             X = torch.empty((rows, DIM), device=dev)
-            _lib.check(lib.lb_gpu_fill_uniform_device(local_rank, X.data_ptr(), X.numel(), 12345, 0, None))
+            _lib.check(lib.lb_gpu_fill_uniform_device(di, X.data_ptr(), X.numel(), 12345, 0, None))
             idx.add_device(rows, X.data_ptr())
         else:
             buf = torch.empty((CH, DIM), device=dev)
             for r0 in range(0, rows, CH):
                 c = min(CH, rows - r0)
-                _lib.check(lib.lb_gpu_fill_uniform_device(local_rank, buf.data_ptr(), c * DIM, 12345, r0 * DIM, None))
+                _lib.check(lib.lb_gpu_fill_uniform_device(di, buf.data_ptr(), c * DIM, 12345, r0 * DIM, None))
                 idx.add_device(c, buf.data_ptr())
             del buf
     else:
-        CH = 1_000_000
         buf = torch.empty((min(CH, max(rows, 1)), DIM), device=dev)
         ids_t = torch.from_numpy(my_ids).to(dev)
         for r0 in range(0, rows, CH):
             c = min(CH, rows - r0)
-            _lib.check(lib.lb_gpu_fill_uniform_rows_device(local_rank, buf.data_ptr(), ids_t[r0:r0 + c].data_ptr(), c, DIM, 12345, None))
+            _lib.check(lib.lb_gpu_fill_uniform_rows_device(di, buf.data_ptr(), ids_t[r0:r0 + c].data_ptr(), c, DIM, 12345, None))
             idx.add_device(c, buf.data_ptr(), ids_t[r0:r0 + c].data_ptr())
         del buf
-    comm_kind = os.environ.get("LB_BENCH_COMM", "torch")  # "lib": RCCL inside liblongbow_gpu.so (lb_gpu_comm_*)
-    searcher = None
-    if use_dist:
-        if comm_kind == "lib":
-            searcher = CommSearcher(idx, rank, world, device_index=local_rank, transport="rccl")
-        else:
-            searcher = ShardedSearcher(idx, rank, world, device=dev, force_collective=True)
+    return idx, X, rows
+
+
+def make_searcher(job, idx):
+    """the cross-shard step: lb_gpu_comm (RCCL inside liblongbow_gpu.so) by default, torch.distributed on request;
+    a communicator that cannot be stood up on EVERY rank falls back to torch on all of them (and says so)"""
+    if not job.use_dist:
+        return None, "single shard"
+    from longbow_amd.sharded import CommSearcher, ShardedSearcher
+    torch, dist = job.torch, job.dist
+    kind = os.environ.get("LB_BENCH_COMM", "lib")
+    if kind == "lib":
+        searcher, err = None, ""
+        try:
+            searcher = CommSearcher(idx, job.rank, job.world, device_index=job.local_rank, transport="rccl")
+        except Exception as e:  # noqa: BLE001 -- reported below
+            err = f"{type(e).__name__}: {e}"
+        ok = torch.tensor([1 if searcher is not None else 0], device=job.dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            return searcher, "lb_gpu_comm (RCCL all-gather inside liblongbow_gpu.so) + device merge"
+        if searcher is not None:
+            searcher.close()
+        kind = f"torch (lb_gpu_comm could not be initialised on every rank: {err or 'a peer failed'})"
+    return (ShardedSearcher(idx, job.rank, job.world, device=job.dev, force_collective=True),
+            f"{kind if kind != 'torch' else 'torch.distributed'} all-gather + device merge")
+
+
+def timed_steps(job, idx, searcher, Q, steps, warmup):
+    """W untimed + K timed steps bracketed by barrier + synchronize; MAX over ranks; library event timing per class"""
+    torch, dist, dev = job.torch, job.dist, job.dev
+    B = Q.shape[0]
     out_d = torch.empty((B, K), device=dev)
     out_l = torch.empty((B, K), dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -316,21 +344,20 @@ def main():
         return out_l, out_d
 
     def barrier():
-        if use_dist:
+        if job.use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     idx.set_profiling(True)  # HIP events on the search stream around each kernel class
-    gemm_ms, gemm_launches, fallbacks = 0.0, 0, 0
     cls_ms = {"gemm": 0.0, "select": 0.0, "rerank": 0.0, "scan": 0.0, "total": 0.0}
+    gemm_launches, fallbacks = 0, 0
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
         tm = idx.last_timing()
-        gemm_ms += tm["gemm"][0]
         gemm_launches += tm["gemm"][1]
         for c in cls_ms:
             cls_ms[c] += tm[c][0]
@@ -338,17 +365,111 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     idx.set_profiling(False)
-    shard_rows = [rows]
-    if use_dist:
+    if job.use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        cnt = torch.tensor([rows], device=dev, dtype=torch.int64)
-        allc = [torch.zeros_like(cnt) for _ in range(world)]
-        dist.all_gather(allc, cnt)
-        shard_rows = [int(c.item()) for c in allc]
     lab, dd = step()
-    lab_h, dist_h = lab.cpu().numpy(), dd.cpu().numpy()
+    return {"elapsed": elapsed, "cls_ms": cls_ms, "gemm_launches": gemm_launches, "fallbacks": fallbacks,
+            "labels": lab.cpu().numpy().copy(), "dist": dd.cpu().numpy().copy(), "step": step}
+
+
+def gather_rows(job, rows):
+    if not job.use_dist:
+        return [rows]
+    torch, dist = job.torch, job.dist
+    cnt = torch.tensor([rows], device=job.dev, dtype=torch.int64)
+    allc = [torch.zeros_like(cnt) for _ in range(job.world)]
+    dist.all_gather(allc, cnt)
+    return [int(c.item()) for c in allc]
+
+
+def shard_report(shard_rows):
+    return {"per_rank": shard_rows, "max": max(shard_rows), "mean": round(sum(shard_rows) / len(shard_rows), 1),
+            "max_over_mean": round(max(shard_rows) * len(shard_rows) / max(sum(shard_rows), 1), 4)}
+
+
+def leg_strong_c3(job, part, Q, steps, warmup, global_rows=10_000_000):
+    """BASELINE config 3: a FIXED 10M x 768 dot-product corpus over the job's GPUs (N = 1 holds all of it), library
+    default candidate mode, per-shard top-k exchanged and merged; value = global queries/s"""
+    idx, _, rows = build_index(job, METRIC_DOT, global_rows, part, CAND_AUTO)
+    searcher, how = make_searcher(job, idx)
+    r = timed_steps(job, idx, searcher, Q, steps, warmup)
+    shard_rows = gather_rows(job, rows)
+    B = Q.shape[0]
+    out = {"workload": "10Mx768 float32 dot-product, corpus sharded across the GPUs, RCCL top-k merge",
+           "scaling": "strong", "value": round(B * steps / r["elapsed"], 1), "unit": "queries/s (global, fixed 10M-row corpus)",
+           "ms_per_step": round(1e3 * r["elapsed"] / steps, 4), "steps": steps, "candidate_mode": "auto",
+           "fallback_queries": int(r["fallbacks"]), "shard_rows": shard_report(shard_rows), "exchange": how,
+           "device_ms_per_step": {c: round(v / steps, 4) for c, v in r["cls_ms"].items()}}
+    if hasattr(searcher, "close"):
+        searcher.close()
+    idx.Close()
+    job.torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=N_ROWS, help="rows per GPU (weak) / global rows (strong: default 10M)")
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fast", action="store_true", help="skip the candidate-mode legs (auto path, split-bf16 image)")
+    ap.add_argument("--no-legs", action="store_true", help="skip the secondary legs (sweep, strong C3, PQ, filtered hybrid)")
+    ap.add_argument("--cpu-queries", type=int, default=0, help="CPU baseline sample size (0 = 16 per core)")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("LB_BENCH_CHILD") != "1":
+        sys.exit(launch_ranks(args, sys.argv[1:]))  # before torch / the GPU library are imported
+
+    import torch
+    import torch.distributed as dist
+    from longbow_amd import _lib, gpu
+    from longbow_amd.sharded import GpuPartition
+
+    job = Job()
+    job.torch, job.dist, job._lib, job.gpu = torch, dist, _lib, gpu
+    job.world = world = int(os.environ.get("WORLD_SIZE", "1"))
+    job.rank = rank = int(os.environ.get("RANK", "0"))
+    job.local_rank = local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and not (world == 1 and args.gpus == 1):
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}, "
+                         "or with no launcher at all (bench.py then starts the ranks itself)")
+    torch.cuda.set_device(local_rank)
+    job.dev = dev = torch.device("cuda", local_rank)
+    # LB_BENCH_FORCE_DIST=1 exercises the collective path (process group, all-gather, merge) even with one
+    # rank, so the multi-GPU code can be rehearsed on a single-GPU box.
+    job.use_dist = use_dist = world > 1 or os.environ.get("LB_BENCH_FORCE_DIST") == "1"
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    job.lib = lib = _lib.require_gpu(local_rank)
+    strong = args.scaling == "strong"
+    metric = METRIC_DOT if strong else METRIC_COSINE
+    B = args.batch
+    global_rows = (10_000_000 if args.rows == N_ROWS else args.rows) if strong else args.rows * world
+
+    # ---- synthetic inputs, generated in HBM (SURVEY 8d: uniform [0,1), corpus seed 12345, queries 42) ----
+    shards_per_gpu = 8
+    part = GpuPartition(world, shards_per_gpu, 40)
+    Q = torch.empty((B, DIM), device=dev)
+    _lib.check(lib.lb_gpu_fill_uniform_device(local_rank, Q.data_ptr(), Q.numel(), 42, 0, None))
+    # the headline is measured in the STRICT mode (f32 MFMA candidates beyond 384 queries: dtype f32 end to end);
+    # the library's default (AUTO: split-bf16 candidates, same results) is the auto_path leg below
+    idx, X, rows = build_index(job, metric, global_rows, part, CAND_F32)
+    searcher, how = make_searcher(job, idx)
+    r = timed_steps(job, idx, searcher, Q, args.steps, args.warmup)
+    elapsed, cls_ms, step = r["elapsed"], r["cls_ms"], r["step"]
+    gemm_ms, gemm_launches, fallbacks = cls_ms["gemm"], r["gemm_launches"], r["fallbacks"]
+    lab_h, dist_h = r["labels"], r["dist"]
+    shard_rows = gather_rows(job, rows)
+    stream = torch.cuda.current_stream(dev).cuda_stream
 
     ms_per_step = 1e3 * elapsed / args.steps
     if strong:
@@ -368,12 +489,10 @@ def main():
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload, "dim": DIM, "batch": B, "k": K, "metric": "dot" if strong else "cosine",
-                   "global_rows": global_rows,
-                   "shard_rows": {"per_rank": shard_rows, "max": max(shard_rows), "mean": round(sum(shard_rows) / len(shard_rows), 1),
-                                  "max_over_mean": round(max(shard_rows) * len(shard_rows) / max(sum(shard_rows), 1), 4)},
+                   "global_rows": global_rows, "candidate_mode": "LB_CAND_F32_MFMA (strict; the library default is AUTO: auto_path leg)",
+                   "shard_rows": shard_report(shard_rows),
                    "sharding": (f"RingSharder({world * shards_per_gpu}, 40): {shards_per_gpu} ring shards per GPU packed by size "
-                                f"(one ring shard per GPU would be {GpuPartition(world, 1, 40).skew():.2f}x skewed) + "
-                                f"{'lb_gpu_comm (RCCL in the library)' if comm_kind == 'lib' else 'torch.distributed'} all-gather + device merge")
+                                f"(one ring shard per GPU would be {GpuPartition(world, 1, 40).skew():.2f}x skewed) + {how}")
                    if use_dist else "single shard",
                    "unit_of_value": "global queries/s" if strong else "one query searched over 1M x 768 rows"},
         "fallback_queries": int(fallbacks),
@@ -404,80 +523,66 @@ def main():
             "hbm_frac_of_8TBs_at_step_rate": round(bytes_per_step / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
         }
 
-    single = rank == 0 and world == 1 and not strong and X is not None
-    # ---- secondary leg: split-bf16 candidate contraction (3 x bf16 MFMA), same exact results ----------
-    if not args.no_fast and single:
-        try:
-            idx.set_candidate_mode(1)
-            for _ in range(2):
-                step()
-            idx.set_profiling(True)
-            f_ms, f_launch, f_fb = 0.0, 0, 0
-            torch.cuda.synchronize(dev)
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                step()
-                tm = idx.last_timing()
-                f_ms += tm["gemm"][0]
-                f_launch += tm["gemm"][1]
-                f_fb += idx.last_fallbacks
-            torch.cuda.synchronize(dev)
-            f_el = time.perf_counter() - t1
-            idx.set_profiling(False)
-            labf, ddf = step()
-            same = bool(np.array_equal(labf.cpu().numpy(), lab_h) and np.array_equal(ddf.cpu().numpy(), dist_h))
-            ach = 3.0 * flops_per_step * args.steps / (f_ms * 1e-3) / 1e12 if f_ms > 0 else 0.0
-            result["split_bf16_candidates"] = {
-                "value": round(B * args.steps / f_el, 1), "unit": "queries/s", "ms_per_step": round(1e3 * f_el / args.steps, 4),
+    single = world == 1 and not use_dist and not strong and X is not None
+
+    def mode_leg(mode, kernel_name, note):
+        """the same batch in another candidate mode: identical results required, own roofline"""
+        idx.set_candidate_mode(mode)
+        for _ in range(2):
+            step()
+        idx.set_profiling(True)
+        f_ms, f_launch, f_fb = 0.0, 0, 0
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+            tm = idx.last_timing()
+            f_ms += tm["gemm"][0]
+            f_launch += tm["gemm"][1]
+            f_fb += idx.last_fallbacks
+        torch.cuda.synchronize(dev)
+        f_el = time.perf_counter() - t1
+        idx.set_profiling(False)
+        labf, ddf = step()
+        labf, ddf = labf.cpu().numpy(), ddf.cpu().numpy()
+        same = bool(np.array_equal(labf, lab_h) and np.array_equal(ddf, dist_h))
+        ach = 3.0 * flops_per_step * args.steps / (f_ms * 1e-3) / 1e12 if f_ms > 0 else 0.0
+        return {"value": round(B * args.steps / f_el, 1), "unit": "queries/s", "ms_per_step": round(1e3 * f_el / args.steps, 4),
                 "results_identical_to_f32_mode": same, "fallback_queries": int(f_fb),
-                "roofline": {"bound": "mfma", "kernel": "gemm_filter_tall_kernel<corpus image>", "achieved": round(ach, 1),
-                             "peak": 2500.0, "unit": "TFLOP/s (bf16, 3 MFMA passes counted)", "frac": round(ach / 2500.0, 4),
-                             "kernel_ms_per_step": round(f_ms / args.steps, 4)},
-                "note": "opt-in lb_gpu_index_set_candidate_mode(1): candidates from hi*hi+hi*lo+lo*hi on bf16 MFMA; "
-                        "reported distances/ids still come from the exact f32 re-rank"}
-        except Exception as e:  # keep the primary line even if the optional leg fails
+                "roofline": {"bound": "mfma", "kernel": kernel_name, "achieved": round(ach, 1),
+                             "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s (bf16, 3 MFMA passes counted)",
+                             "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "kernel_ms_per_step": round(f_ms / args.steps, 4),
+                             "launches_per_step": f_launch / args.steps},
+                "note": note}, labf, ddf
+
+    auto_lab = auto_dist = None
+    if not args.no_fast and single:
+        # ---- the library's DEFAULT path (LB_CAND_AUTO): same exact results, no second copy of the corpus -------
+        try:
+            result["auto_path"], auto_lab, auto_dist = mode_leg(
+                CAND_AUTO, "gemm_filter_tall_kernel<split in registers>",
+                "LB_CAND_AUTO, the library default: candidates from hi*hi+hi*lo+lo*hi on the bf16 MFMA with both f32 operands "
+                "split in registers (no second corpus image); reported distances/ids come from the exact f32 re-rank and the "
+                "containment proof, as in every mode")
+            result["auto_path"]["extra_hbm_bytes"] = 0
+        except Exception as e:  # keep the primary line even if an optional leg fails
+            result["auto_path"] = {"error": str(e)}
+        # ---- opt-in: pre-split bf16 image of the corpus (a second N*D*4-byte copy) --------------------------------
+        try:
+            result["split_bf16_candidates"], _, _ = mode_leg(
+                CAND_IMAGE, "gemm_filter_tall_kernel<corpus image>",
+                "opt-in lb_gpu_index_set_candidate_mode(LB_CAND_SPLIT_BF16): the same contraction over a pre-split image")
+            result["split_bf16_candidates"]["extra_hbm_bytes"] = int(4 * rows * DIM)
+        except Exception as e:
             result["split_bf16_candidates"] = {"error": str(e)}
         finally:
             try:
-                idx.set_candidate_mode(0)
-            except Exception:
-                pass
-        # the same contraction with the f32 operands split in registers: no second corpus image
-        try:
-            idx.set_candidate_mode(2)
-            for _ in range(2):
-                step()
-            idx.set_profiling(True)
-            f_ms, f_fb = 0.0, 0
-            torch.cuda.synchronize(dev)
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                step()
-                f_ms += idx.last_timing()["gemm"][0]
-                f_fb += idx.last_fallbacks
-            torch.cuda.synchronize(dev)
-            f_el = time.perf_counter() - t1
-            idx.set_profiling(False)
-            labf, ddf = step()
-            same = bool(np.array_equal(labf.cpu().numpy(), lab_h) and np.array_equal(ddf.cpu().numpy(), dist_h))
-            ach = 3.0 * flops_per_step * args.steps / (f_ms * 1e-3) / 1e12 if f_ms > 0 else 0.0
-            result["split_bf16_in_registers"] = {
-                "value": round(B * args.steps / f_el, 1), "unit": "queries/s", "ms_per_step": round(1e3 * f_el / args.steps, 4),
-                "results_identical_to_f32_mode": same, "fallback_queries": int(f_fb), "extra_hbm_bytes": 0,
-                "roofline": {"bound": "mfma", "kernel": "gemm_filter_tall_kernel<split in registers>", "achieved": round(ach, 1),
-                             "peak": 2500.0, "unit": "TFLOP/s (bf16, 3 MFMA passes counted)", "frac": round(ach / 2500.0, 4),
-                             "kernel_ms_per_step": round(f_ms / args.steps, 4)},
-                "note": "opt-in lb_gpu_index_set_candidate_mode(2): as split_bf16_candidates but the f32 tiles are split to bf16 "
-                        "hi/lo after the LDS read -- no second copy of the corpus"}
-        except Exception as e:
-            result["split_bf16_in_registers"] = {"error": str(e)}
-        finally:
-            try:
-                idx.set_candidate_mode(0)
+                idx.set_candidate_mode(CAND_AUTO)
             except Exception:
                 pass
 
     if single:
+        idx.set_candidate_mode(CAND_AUTO)
         # ---- p50 single-query latency (the DoExchange path is single-query) ------------------------
         lat = []
         d1 = torch.empty((1, K), device=dev)
@@ -506,7 +611,7 @@ def main():
             "whole_search_frac_of_8TBs": round(4.0 * rows * DIM / (p50 * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
         if not args.no_legs:
             try:
-                result["batch_sweep"] = leg_batch_sweep(torch, dev, idx, Q, rows)
+                result["batch_sweep"] = leg_batch_sweep(torch, dev, idx, Q, rows)  # library default (AUTO)
             except Exception as e:
                 result["batch_sweep"] = {"error": str(e)}
 
@@ -520,6 +625,9 @@ def main():
         ok = bool(np.array_equal(oi, lab_h[sub]) and np.array_equal(od, dist_h[sub]))
         result["parity"] = {"checked_queries": int(len(sub)), "index_sets_equal": bool(np.array_equal(oi, lab_h[sub])),
                             "distances_bit_equal": bool(np.array_equal(od, dist_h[sub])), "ok": ok}
+        if auto_lab is not None and isinstance(result.get("auto_path"), dict):
+            a_ok = bool(np.array_equal(oi, auto_lab[sub]) and np.array_equal(od, auto_dist[sub]))
+            result["auto_path"]["parity"] = {"checked_queries": int(len(sub)), "vs": "oracle (full corpus)", "ok": a_ok}
         if not args.no_cpu_baseline:
             nqc = args.cpu_queries or 16 * cores  # 16 full-corpus scans per thread: tens of core-seconds
             nqc = min(nqc, B)
@@ -531,28 +639,39 @@ def main():
                           f"(reference idiom: queries partitioned over {cores} threads, SIMD C port of internal/simd)",
                 "seconds": round(secs, 2), "label_agreement_with_gpu": round(agree, 5)}
         del Xh
-        # ---- configs 4 and 5 (own corpora; the 1M x 768 index is released first) ----------------------
-        if not args.no_legs:
-            idx.Close()
-            idx = None
-            del X
-            X = None
+
+    # ---- BASELINE config 3 beside the headline, at every N (the fixed-corpus scaling of the same job) ----------
+    if hasattr(searcher, "close"):
+        searcher.close()
+    searcher = None
+    if not args.no_legs and not strong:
+        idx.Close()
+        idx = None
+        X = None
+        torch.cuda.empty_cache()
+        try:
+            result["strong_c3"] = leg_strong_c3(job, part, Q, max(3, args.steps // 4), 1)
+        except Exception as e:
+            if use_dist:
+                raise  # (a rank that skipped a collective leg would strand its peers)
+            result["strong_c3"] = {"error": f"{type(e).__name__}: {e}"}
+
+    if single and not args.no_legs:
+        # ---- configs 4 and 5 (own corpora; the 1M x 768 index was released above) ----------------------
+        cores = host_cores()
+        for name, fn in (("pq_adc", lambda: leg_pq_adc(torch, dev, lib, _lib, cores)),
+                         ("filtered_hybrid", lambda: leg_filtered_hybrid(torch, dev, lib, _lib, cores))):
+            try:
+                result[name] = fn()
+            except Exception as e:
+                result[name] = {"error": f"{type(e).__name__}: {e}"}
             torch.cuda.empty_cache()
-            for name, fn in (("pq_adc", lambda: leg_pq_adc(torch, dev, lib, _lib, cores)),
-                             ("filtered_hybrid", lambda: leg_filtered_hybrid(torch, dev, lib, _lib, cores))):
-                try:
-                    result[name] = fn()
-                except Exception as e:
-                    result[name] = {"error": f"{type(e).__name__}: {e}"}
-                torch.cuda.empty_cache()
 
     if rank == 0:
         print(json.dumps(result), flush=True)
     if idx is not None:
         idx.Close()
     if use_dist:
-        if hasattr(searcher, "close"):
-            searcher.close()
         dist.destroy_process_group()
 
 

@@ -50,7 +50,9 @@ typedef enum {
     LB_ERR_HIP = 4,         /* a HIP runtime call failed; see lb_gpu_last_error     */
     LB_ERR_OOM = 5,         /* HBM or pinned-host allocation failed                 */
     LB_ERR_UNSUPPORTED = 6, /* e.g. PQ with K != 256 (simd.go:350 stride)           */
-    LB_ERR_INTERNAL = 7
+    LB_ERR_INTERNAL = 7,
+    LB_ERR_CANCELLED = 8,   /* the call's lb_cancel fired: ctx.Err() == context.Canceled          */
+    LB_ERR_DEADLINE = 9     /* its deadline passed:        ctx.Err() == context.DeadlineExceeded  */
 } lb_status;
 
 typedef struct lb_gpu_index lb_gpu_index; /* opaque; replaces FaissGpuResourcesPtr +
@@ -68,6 +70,7 @@ const char *lb_gpu_status_string(int status);
  * the reason.  dim > LB_MAX_DIM -> NULL / LB_ERR_UNSUPPORTED (the kernels stage one query row in LDS;
  * the reference has no cap, embedding widths in practice are <= 4096). */
 #define LB_MAX_DIM 8192
+#define LB_MAX_K 2048 /* largest k of any search entry point (LB_ERR_UNSUPPORTED beyond) */
 lb_gpu_index *lb_gpu_index_new(int device, int dim, int metric, int *out_status);
 
 /* Close (faiss_gpu.go:147-167): frees HBM; idempotent on NULL.  Must not race with any other call on the same
@@ -81,19 +84,22 @@ const char *lb_gpu_last_error(const lb_gpu_index *h);
 
 int lb_gpu_index_set_order(lb_gpu_index *h, int order);
 
-/* How the batched path generates candidates before the exact f32 re-rank (results are identical
- * either way: the re-rank recomputes every reported distance in the reference's f32 order and a
- * rounding-error bound proves the candidate set contains the true top-k, else the query is
- * re-done by the exact scan):
- *   LB_CAND_F32_MFMA   (default) q.x on the f32 MFMA (v_mfma_f32_32x32x2_f32)
- *   LB_CAND_SPLIT_BF16 q.x as hi*hi + hi*lo + lo*hi on the bf16 MFMA over a split image of the corpus
- *                      (x = hi + lo + O(2^-18)); costs a second N*dim*4-byte copy in HBM; dim % 32 == 0.
- *   LB_CAND_SPLIT_BF16_INREG the same contraction with BOTH f32 operands split into bf16 pairs in registers after
- *                      the LDS read: no second copy.  (Batches of 5..384 queries always run this way.) */
-typedef enum { LB_CAND_F32_MFMA = 0, LB_CAND_SPLIT_BF16 = 1, LB_CAND_SPLIT_BF16_INREG = 2 } lb_candidate_mode;
+/* How the batched path generates candidates before the exact f32 re-rank.  Results are identical in every mode:
+ * the re-rank recomputes every reported distance in the reference's f32 order and a rounding-error bound proves
+ * that the candidate set contains the true top-k, else the query is re-done by the exact scan.
+ *   LB_CAND_AUTO       (default) the cheapest route at every batch size: narrow tiles (HBM-bound passes) for small
+ *                      batches, beyond them q.x as hi*hi + hi*lo + lo*hi on the bf16 MFMA with BOTH f32 operands split
+ *                      into bf16 pairs in registers after the LDS read (no second copy of the corpus).
+ *   LB_CAND_F32_MFMA   strict: beyond 384 queries q.x on the f32 MFMA (v_mfma_f32_32x32x2_f32); batches of
+ *                      5..384 queries as AUTO.  The headline of bench.py is measured in this mode.
+ *   LB_CAND_SPLIT_BF16 the split contraction over a pre-split image of the corpus (x = hi + lo + O(2^-18));
+ *                      costs a second N*dim*4-byte copy in HBM; dim % 32 == 0.
+ *   LB_CAND_SPLIT_BF16_INREG the in-register split for every batch beyond the narrow tiles (what AUTO picks). */
+typedef enum { LB_CAND_F32_MFMA = 0, LB_CAND_SPLIT_BF16 = 1, LB_CAND_SPLIT_BF16_INREG = 2, LB_CAND_AUTO = 3 } lb_candidate_mode;
 int lb_gpu_index_set_candidate_mode(lb_gpu_index *h, int mode);
 int64_t lb_gpu_index_ntotal(const lb_gpu_index *h);
 int lb_gpu_index_dim(const lb_gpu_index *h);
+int lb_gpu_index_device(const lb_gpu_index *h); /* GPUConfig.DeviceID (interface.go:15-19); -1 on NULL */
 
 /* Pre-size HBM for n_total rows (optional; add grows geometrically otherwise). */
 int lb_gpu_index_reserve(lb_gpu_index *h, int64_t n_total);
@@ -119,6 +125,25 @@ int lb_gpu_index_search(lb_gpu_index *h, int64_t nq, const float *queries, int k
  * library's own).  Results are complete when the call returns. */
 int lb_gpu_index_search_device(lb_gpu_index *h, int64_t nq, const float *d_queries, int k,
                                float *d_dist, int64_t *d_labels, void *stream);
+
+/* ---- cancellation: the ctx of SearchVectors(ctx, ...) ------------------------------------------
+ * The reference's brute-force loop polls ctx.Err() every 1000 rows (internal/store/adaptive_index.go:182).
+ * A cgo caller makes one lb_cancel per call, fires it from `go func(){ <-ctx.Done(); C.lb_cancel_fire(c) }()`
+ * (or sets the ctx's deadline on it) and passes it to a *_ctx entry point.  The library polls it on the host
+ * before every kernel launch of the search -- a launch covers at most one pass over <= 2.5M rows of one
+ * batch (dense) or one query's pass over the codes (PQ), i.e. <= ~12 ms on 1M x 768 x 1024 queries -- stops
+ * enqueuing, waits for what is already on the stream and returns LB_ERR_CANCELLED / LB_ERR_DEADLINE; the
+ * output buffers then hold unspecified values.  NULL ctx = never cancelled.  All calls are thread-safe. */
+typedef struct lb_cancel lb_cancel;
+lb_cancel *lb_cancel_new(void);
+void lb_cancel_fire(lb_cancel *c);                            /* idempotent                           */
+void lb_cancel_set_deadline_ms(lb_cancel *c, int64_t ms_from_now); /* < 0 clears the deadline          */
+int lb_cancel_state(const lb_cancel *c);                      /* 0, LB_ERR_CANCELLED or LB_ERR_DEADLINE */
+void lb_cancel_free(lb_cancel *c);                            /* after the call that used it returned */
+int lb_gpu_index_search_ctx(lb_gpu_index *h, int64_t nq, const float *queries, int k, float *dist, int64_t *labels,
+                            const lb_cancel *ctx);
+int lb_gpu_index_search_device_ctx(lb_gpu_index *h, int64_t nq, const float *d_queries, int k, float *d_dist,
+                                   int64_t *d_labels, void *stream, const lb_cancel *ctx);
 
 /* Metadata predicate mask for filtered search (SURVEY f-3; byte-per-row 0/1 as
  * internal/query/filter_evaluator.go:79-115 produces).  mask has ntotal bytes;
@@ -168,6 +193,17 @@ int lb_simd_distance_batch_flat(int device, int metric, int order, const float *
 int lb_simd_distance_batch_flat_device(int device, int metric, int order, const float *d_query,
                                        const float *d_flat, int64_t n, int dims,
                                        float *d_results, void *stream);
+/* simd.EuclideanDistanceBatch / CosineDistanceBatch / DotProductBatch over a SLICE OF SLICES
+ * (internal/simd/batch_operations.go:29-60,131-157): vectors[i] points at vector i (host), lens[i] is its
+ * length.  Per-vector rules of the reference:
+ *   Euclidean  a nil or length-mismatched vector yields math.MaxFloat32 (batch_operations.go:39-42,51;
+ *              simd_amd64.go:217-220);
+ *   Cosine/Dot a nil vector is skipped -- results[i] keeps the value the caller put there (simd.go:241-267) --
+ *              and a length mismatch makes the reference's loop stop at that vector with the error swallowed
+ *              (batch_operations.go:140,155): results[i..] keep the caller's values.
+ * The valid vectors are packed into one pinned block, DMA'd and scored by the same kernel as the flat call. */
+int lb_simd_distance_batch(int device, int metric, int order, const float *query, int dims,
+                           const float *const *vectors, const int *lens, int64_t n, float *results);
 
 /* simd.MatchInt64 / simd.MatchFloat32 (internal/simd/simd.go:570-761): dst[i] = src[i] OP val ? 1 : 0,
  * and simd.AndBytes (simd.go:119-125): dst[i] &= src[i].  Host pointers. */
@@ -222,6 +258,14 @@ int lb_gpu_pq_search(lb_gpu_pq *p, int64_t nq, const float *queries, int k, floa
                      int64_t *labels);
 int lb_gpu_pq_search_device(lb_gpu_pq *p, int64_t nq, const float *d_queries, int k,
                             float *d_dist, int64_t *d_labels, void *stream);
+/* the same with a cancellation context, polled between the queries of the batch and the launches of one query */
+int lb_gpu_pq_search_ctx(lb_gpu_pq *p, int64_t nq, const float *queries, int k, float *dist, int64_t *labels,
+                         const lb_cancel *ctx);
+int lb_gpu_pq_search_device_ctx(lb_gpu_pq *p, int64_t nq, const float *d_queries, int k, float *d_dist,
+                                int64_t *d_labels, void *stream, const lb_cancel *ctx);
+/* 1 (default): the search runs the byte-table prefilter + exact survivors; 0: the exact f32-table
+ * pass over every row.  Results are bit-identical; the switch exists for A/B timing and for the parity tests. */
+int lb_gpu_pq_set_prefilter(lb_gpu_pq *p, int enable);
 
 /* instrumentation (bench.py): HIP-event times of the most recent profiled search on this handle, recorded on the
  * search stream: ms[0] = the pass over the codes of the LAST query (prefilter kernel, or the exact kernel when

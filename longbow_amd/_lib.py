@@ -14,7 +14,7 @@ SO_PATH = os.environ.get("LB_GPU_SO") or os.path.join(_HERE, "liblongbow_gpu.so"
 LB_OK = 0
 STATUS = {0: "ok", 1: "invalid argument", 2: "index is closed", 3: "GPU not available",
           4: "HIP runtime error", 5: "out of device memory", 6: "unsupported configuration",
-          7: "internal error"}
+          7: "internal error", 8: "context canceled", 9: "context deadline exceeded"}
 
 
 class LongbowGPUError(RuntimeError):
@@ -25,6 +25,14 @@ class LongbowGPUError(RuntimeError):
 
 class GPUNotAvailable(LongbowGPUError):
     """internal/gpu/stub.go:10 ErrGPUNotAvailable"""
+
+
+class Canceled(LongbowGPUError):
+    """context.Canceled: the call's Cancel fired (internal/store/adaptive_index.go:182 returns ctx.Err())"""
+
+
+class DeadlineExceeded(LongbowGPUError):
+    """context.DeadlineExceeded"""
 
 
 _lib = None
@@ -43,6 +51,18 @@ SIGNATURES = [
     ("lb_gpu_index_set_candidate_mode", _i, [_vp, _i]),
     ("lb_gpu_index_ntotal", _i64, [_vp]),
     ("lb_gpu_index_dim", _i, [_vp]),
+    ("lb_gpu_index_device", _i, [_vp]),
+    ("lb_cancel_new", _vp, []),
+    ("lb_cancel_fire", None, [_vp]),
+    ("lb_cancel_set_deadline_ms", None, [_vp, _i64]),
+    ("lb_cancel_state", _i, [_vp]),
+    ("lb_cancel_free", None, [_vp]),
+    ("lb_gpu_index_search_ctx", _i, [_vp, _i64, _vp, _i, _vp, _vp, _vp]),
+    ("lb_gpu_index_search_device_ctx", _i, [_vp, _i64, _vp, _i, _vp, _vp, _vp, _vp]),
+    ("lb_simd_distance_batch", _i, [_i, _i, _i, _vp, _i, _vp, _vp, _i64, _vp]),
+    ("lb_gpu_pq_search_ctx", _i, [_vp, _i64, _vp, _i, _vp, _vp, _vp]),
+    ("lb_gpu_pq_search_device_ctx", _i, [_vp, _i64, _vp, _i, _vp, _vp, _vp, _vp]),
+    ("lb_gpu_pq_set_prefilter", _i, [_vp, _i]),
     ("lb_gpu_index_reserve", _i, [_vp, _i64]),
     ("lb_gpu_index_add", _i, [_vp, _i64, _vp, _vp]),
     ("lb_gpu_index_add_device", _i, [_vp, _i64, _vp, _vp]),
@@ -111,25 +131,49 @@ SIGNATURES = [
 ]
 
 
+def _bind(path, extra=()):
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: build it with `python -m longbow_amd.build{' --diag' if extra else ''}` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, res, args in list(SIGNATURES) + list(extra):
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
 def load():
     """dlopen the HIP library and bind every declared symbol (no GPU needed for this).
 
     Note for processes that also use PyTorch-ROCm (bench.py, sharded search): import torch BEFORE
     the first call here.  torch ships its own HIP runtime and must initialise first."""
     global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(SO_PATH):
-        raise RuntimeError(
-            f"{SO_PATH} is missing: build it with `python -m longbow_amd.build` "
-            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
-    lib = C.CDLL(SO_PATH)
-    for name, res, args in SIGNATURES:
-        fn = getattr(lib, name)  # AttributeError if the library does not export it
-        fn.restype = res
-        fn.argtypes = args
-    _lib = lib
-    return lib
+    if _lib is None:
+        _lib = _bind(SO_PATH)
+    return _lib
+
+
+# Test hooks and timing-only ablations exist ONLY in the diagnostic build (liblongbow_gpu_diag.so, -DLB_DIAG):
+# tests that force a fallback path create their handles on this library (Index(cfg, lib=load_diag())).
+DIAG_SO_PATH = os.path.join(_HERE, "liblongbow_gpu_diag.so")
+DIAG_SIGNATURES = [
+    ("lb_debug_set_sample_tau", None, [_i]),
+    ("lb_debug_vmm_fail_next", None, [_i]),
+    ("lb_debug_fused_fail_next", None, [_i]),
+    ("lb_debug_search_fail_next", None, [_i]),
+    ("lb_debug_set_add_register_min", None, [C.c_longlong]),
+    ("lb_debug_sample_plan", None, [C.c_longlong, _i, C.c_uint, C.c_uint, C.POINTER(C.c_longlong)]),
+]
+_diag = None
+
+
+def load_diag():
+    global _diag
+    if _diag is None:
+        _diag = _bind(DIAG_SO_PATH, DIAG_SIGNATURES)
+    return _diag
 
 
 def require_gpu(device=0):
@@ -140,14 +184,18 @@ def require_gpu(device=0):
     return lib
 
 
-def check(rc, handle=None, pq=False):
+def check(rc, handle=None, pq=False, lib=None):
     if rc == LB_OK:
         return
     msg = ""
     if handle:
-        lib = load()
+        lib = lib or load()
         raw = lib.lb_gpu_pq_last_error(handle) if pq else lib.lb_gpu_last_error(handle)
         msg = raw.decode() if raw else ""
     if rc == 3:
         raise GPUNotAvailable(rc, msg)
+    if rc == 8:
+        raise Canceled(rc, msg)
+    if rc == 9:
+        raise DeadlineExceeded(rc, msg)
     raise LongbowGPUError(rc, msg)

@@ -41,6 +41,8 @@ struct Rccl {
     int (*CommInitAll)(NcclComm *, int, const int *) = nullptr;
     int (*CommDestroy)(NcclComm) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, NcclComm, hipStream_t) = nullptr;
+    int (*Send)(const void *, size_t, int, int, NcclComm, hipStream_t) = nullptr; // optional (point-to-point)
+    int (*Recv)(void *, size_t, int, int, NcclComm, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
@@ -63,6 +65,8 @@ Rccl &rccl()
         r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(dlsym(r.so, "ncclCommInitAll"));
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.so, "ncclCommDestroy"));
         r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.so, "ncclAllGather"));
+        r.Send = reinterpret_cast<decltype(r.Send)>(dlsym(r.so, "ncclSend"));
+        r.Recv = reinterpret_cast<decltype(r.Recv)>(dlsym(r.so, "ncclRecv"));
         r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(r.so, "ncclGroupStart"));
         r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(r.so, "ncclGroupEnd"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.so, "ncclGetErrorString"));
@@ -76,6 +80,12 @@ inline size_t block_bytes(int64_t nq, int k)
     const int64_t nk = nq * k;
     return (size_t)(nk * 8 + ((nk * 4 + 7) / 8) * 8);
 }
+
+// What travels per rank: the packed block (lb_gpu_merge_topk_packed_device's layout) + one 8-byte status word
+// (0 = the rank's shard search succeeded).  A rank whose local search fails still takes part in the exchange, with
+// the canonical empty block (label -1 / FLT_MAX) and its lb_status in the word, so no peer is left waiting in the
+// collective and every rank reports the failure.
+constexpr size_t kStatusBytes = 8;
 
 // per-device state of a communicator (one entry for init_rank / init_host, ndev entries for init_all)
 struct Peer {
@@ -115,7 +125,7 @@ void set_err(lb_gpu_comm *c, const char *what, int code)
 
 void ensure_blocks(Peer &p, int nranks, int64_t nq, int k)
 {
-    const size_t bb = block_bytes(nq, k);
+    const size_t bb = block_bytes(nq, k) + kStatusBytes;
     if (p.mine_bytes < bb) {
         if (p.d_mine) (void)hipFree(p.d_mine);
         p.d_mine = nullptr;
@@ -258,52 +268,88 @@ int lb_gpu_comm_search_device(lb_gpu_comm *c, lb_gpu_index *h, int64_t nq, const
     if (!c || !h || nq < 0 || k <= 0 || (nq > 0 && (!d_queries || !d_dist || !d_labels))) return LB_ERR_INVALID_ARG;
     if (c->mode == 2) return LB_ERR_INVALID_ARG; // use lb_gpu_comm_search_all
     if (nq == 0) return LB_OK;
+    // (argument errors that every rank sees alike may return before the exchange; anything that can differ from
+    // rank to rank -- a failed shard search, an allocation -- must not: the peers would wait in the all-gather forever)
     if ((int64_t)c->nranks * k > 16384) { c->last_error = "nranks * k exceeds 16384"; return LB_ERR_INVALID_ARG; }
+    if (k > 2048) { c->last_error = "k exceeds the supported maximum 2048"; return LB_ERR_UNSUPPORTED; }
     std::lock_guard<std::mutex> g(c->mu);
     Peer &p = c->peers[0];
+    int local_rc = LB_OK;
     try {
         LB_HIP(hipSetDevice(p.device));
         hipStream_t s = stream ? (hipStream_t)stream : p.stream;
-        ensure_blocks(p, c->nranks, nq, k);
         const int64_t nk = nq * k;
-        const size_t bb = block_bytes(nq, k);
+        const size_t bb = block_bytes(nq, k), bs = bb + kStatusBytes;
+        try {
+            ensure_blocks(p, c->nranks, nq, k);
+        } catch (const HipErr &e) {
+            // no room for the exchange buffers: this rank cannot take part at all.  The peers' all-gather will
+            // fail or time out at the transport level; nothing here can repair that.
+            (void)hipGetLastError();
+            c->last_error = std::string("HIP error in ") + e.what + " (exchange buffers)";
+            return e.e == hipErrorOutOfMemory ? LB_ERR_OOM : LB_ERR_HIP;
+        }
         char *mine = static_cast<char *>(p.d_mine);
         // local shard: labels | distances written straight into this rank's packed block
-        int rc = lb_gpu_index_search_device(h, nq, d_queries, k, reinterpret_cast<float *>(mine + nk * 8),
-                                            reinterpret_cast<int64_t *>(mine), s);
-        if (rc != LB_OK) { c->last_error = lb_gpu_last_error(h); return rc; }
+        local_rc = lb_gpu_index_search_device(h, nq, d_queries, k, reinterpret_cast<float *>(mine + nk * 8),
+                                              reinterpret_cast<int64_t *>(mine), s);
+        if (local_rc != LB_OK) {
+            // still take part in the exchange, with the canonical empty block and the status word set
+            c->last_error = lb_gpu_last_error(h);
+            launch_fill_empty(reinterpret_cast<float *>(mine + nk * 8), reinterpret_cast<int64_t *>(mine), nk, s);
+        }
+        const uint64_t status = (uint64_t)(uint32_t)local_rc;
+        LB_HIP(hipMemcpyAsync(mine + bb, &status, sizeof status, hipMemcpyHostToDevice, s));
         if (c->nranks == 1) {
-            LB_HIP(hipMemcpyAsync(p.d_all, p.d_mine, bb, hipMemcpyDeviceToDevice, s));
+            LB_HIP(hipMemcpyAsync(p.d_all, p.d_mine, bs, hipMemcpyDeviceToDevice, s));
         } else if (c->mode == 0) { // RCCL over xGMI: the one exchange step of the path
-            const int nrc = rccl().AllGather(p.d_mine, p.d_all, bb, kNcclChar, p.comm, s);
+            const int nrc = rccl().AllGather(p.d_mine, p.d_all, bs, kNcclChar, p.comm, s);
             if (nrc != kNcclSuccess) { set_err(c, "ncclAllGather", nrc); return LB_ERR_HIP; }
         } else { // host transport: D2H, the host's all-gather, H2D
-            if (c->h_send_bytes < bb) {
+            if (c->h_send_bytes < bs) {
                 if (c->h_send) (void)hipHostFree(c->h_send);
                 c->h_send = nullptr;
                 c->h_send_bytes = 0;
-                LB_HIP(hipHostMalloc(&c->h_send, bb, hipHostMallocDefault));
-                c->h_send_bytes = bb;
+                LB_HIP(hipHostMalloc(&c->h_send, bs, hipHostMallocDefault));
+                c->h_send_bytes = bs;
             }
-            if (c->h_recv_bytes < bb * c->nranks) {
+            if (c->h_recv_bytes < bs * c->nranks) {
                 if (c->h_recv) (void)hipHostFree(c->h_recv);
                 c->h_recv = nullptr;
                 c->h_recv_bytes = 0;
-                LB_HIP(hipHostMalloc(&c->h_recv, bb * c->nranks, hipHostMallocDefault));
-                c->h_recv_bytes = bb * c->nranks;
+                LB_HIP(hipHostMalloc(&c->h_recv, bs * c->nranks, hipHostMallocDefault));
+                c->h_recv_bytes = bs * c->nranks;
             }
-            LB_HIP(hipMemcpyAsync(c->h_send, p.d_mine, bb, hipMemcpyDeviceToHost, s));
+            LB_HIP(hipMemcpyAsync(c->h_send, p.d_mine, bs, hipMemcpyDeviceToHost, s));
             LB_HIP(hipStreamSynchronize(s));
-            const int frc = c->fn(c->fn_ctx, c->h_send, c->h_recv, bb);
+            const int frc = c->fn(c->fn_ctx, c->h_send, c->h_recv, bs);
             if (frc != 0) { set_err(c, "host all-gather callback", frc); return LB_ERR_INTERNAL; }
-            LB_HIP(hipMemcpyAsync(p.d_all, c->h_recv, bb * c->nranks, hipMemcpyHostToDevice, s));
+            LB_HIP(hipMemcpyAsync(p.d_all, c->h_recv, bs * c->nranks, hipMemcpyHostToDevice, s));
         }
-        rc = lb_gpu_merge_topk_packed_device(p.device, c->nranks, nq, k, p.d_all, d_dist, d_labels, s);
-        if (rc != LB_OK) return rc;
+        const char *all = static_cast<const char *>(p.d_all);
+        launch_merge_topk(c->nranks, nq, k, reinterpret_cast<const float *>(all + nk * 8), reinterpret_cast<const int64_t *>(all),
+                          (int64_t)(bs / 4), (int64_t)(bs / 8), d_dist, d_labels, s);
+        LB_LAUNCH_CHECK();
+        // every rank's status word: a failure anywhere fails the search everywhere (results would lack a shard)
+        std::vector<uint64_t> st((size_t)c->nranks, 0);
+        LB_HIP(hipMemcpy2DAsync(st.data(), sizeof(uint64_t), all + bb, bs, sizeof(uint64_t), (size_t)c->nranks,
+                                hipMemcpyDeviceToHost, s));
+        LB_HIP(hipStreamSynchronize(s));
+        if (local_rc != LB_OK) return local_rc;
+        for (int r = 0; r < c->nranks; r++)
+            if (st[(size_t)r] != 0) {
+                char buf[96];
+                snprintf(buf, sizeof buf, "shard search failed on rank %d (status %d)", r, (int)st[(size_t)r]);
+                c->last_error = buf;
+                return (int)st[(size_t)r];
+            }
     } catch (const HipErr &e) {
         (void)hipGetLastError();
         c->last_error = std::string("HIP error in ") + e.what;
         return e.e == hipErrorOutOfMemory ? LB_ERR_OOM : LB_ERR_HIP;
+    } catch (...) {
+        c->last_error = "internal error (exception)";
+        return LB_ERR_INTERNAL;
     }
     return LB_OK;
 }
@@ -316,61 +362,93 @@ int lb_gpu_comm_search_all(lb_gpu_comm *c, lb_gpu_index *const *shards, int64_t 
     if (nq == 0) return LB_OK;
     const int nd = c->nranks;
     if ((int64_t)nd * k > 16384) { c->last_error = "ndev * k exceeds 16384"; return LB_ERR_INVALID_ARG; }
+    if (k > 2048) { c->last_error = "k exceeds the supported maximum 2048"; return LB_ERR_UNSUPPORTED; }
     for (int i = 0; i < nd; i++)
         if (!shards[i]) return LB_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> g(c->mu);
     const int dim = lb_gpu_index_dim(shards[0]);
+    for (int i = 0; i < nd; i++) { // shard i must live on the communicator's i-th device and share the dimension
+        if (lb_gpu_index_device(shards[i]) != c->peers[(size_t)i].device) {
+            char buf[128];
+            snprintf(buf, sizeof buf, "shard %d lives on device %d, the communicator's rank %d is device %d", i,
+                     lb_gpu_index_device(shards[i]), i, c->peers[(size_t)i].device);
+            c->last_error = buf;
+            return LB_ERR_INVALID_ARG;
+        }
+        if (lb_gpu_index_dim(shards[i]) != dim) { c->last_error = "shards differ in dimension"; return LB_ERR_INVALID_ARG; }
+    }
     const int64_t nk = nq * k;
     const size_t bb = block_bytes(nq, k);
     const size_t qb = (size_t)nq * dim * sizeof(float);
     std::vector<int> rcs((size_t)nd, LB_OK);
-    // one host thread per device: upload the queries, search the shard into its packed block
-    auto local = [&](int i) {
-        Peer &p = c->peers[(size_t)i];
-        try {
-            LB_HIP(hipSetDevice(p.device));
-            ensure_blocks(p, nd, nq, k);
-            if (p.q_bytes < qb) {
-                if (p.d_q) (void)hipFree(p.d_q);
-                p.d_q = nullptr;
-                p.q_bytes = 0;
-                LB_HIP(hipMalloc(&p.d_q, qb));
-                p.q_bytes = qb;
-            }
-            LB_HIP(hipMemcpyAsync(p.d_q, queries, qb, hipMemcpyHostToDevice, p.stream));
-            char *mine = static_cast<char *>(p.d_mine);
-            rcs[(size_t)i] = lb_gpu_index_search_device(shards[i], nq, p.d_q, k, reinterpret_cast<float *>(mine + nk * 8),
-                                                        reinterpret_cast<int64_t *>(mine), p.stream);
-        } catch (const HipErr &e) {
-            (void)hipGetLastError();
-            rcs[(size_t)i] = e.e == hipErrorOutOfMemory ? LB_ERR_OOM : LB_ERR_HIP;
-        }
-    };
-    {
-        std::vector<std::thread> th;
-        for (int i = 1; i < nd; i++) th.emplace_back(local, i);
-        local(0);
-        for (auto &t : th) t.join();
-    }
-    for (int i = 0; i < nd; i++)
-        if (rcs[(size_t)i] != LB_OK) { c->last_error = "shard search failed"; return rcs[(size_t)i]; }
     try {
+        // one host thread per device: upload the queries, search the shard into its packed block
+        auto local = [&](int i) {
+            Peer &p = c->peers[(size_t)i];
+            try {
+                LB_HIP(hipSetDevice(p.device));
+                ensure_blocks(p, i == 0 ? nd : 1, nq, k); // only the merging device holds every block
+                if (p.q_bytes < qb) {
+                    if (p.d_q) (void)hipFree(p.d_q);
+                    p.d_q = nullptr;
+                    p.q_bytes = 0;
+                    LB_HIP(hipMalloc(&p.d_q, qb));
+                    p.q_bytes = qb;
+                }
+                LB_HIP(hipMemcpyAsync(p.d_q, queries, qb, hipMemcpyHostToDevice, p.stream));
+                char *mine = static_cast<char *>(p.d_mine);
+                rcs[(size_t)i] = lb_gpu_index_search_device(shards[i], nq, p.d_q, k, reinterpret_cast<float *>(mine + nk * 8),
+                                                            reinterpret_cast<int64_t *>(mine), p.stream);
+            } catch (const HipErr &e) {
+                (void)hipGetLastError();
+                rcs[(size_t)i] = e.e == hipErrorOutOfMemory ? LB_ERR_OOM : LB_ERR_HIP;
+            } catch (...) {
+                rcs[(size_t)i] = LB_ERR_INTERNAL;
+            }
+        };
+        {
+            std::vector<std::thread> th;
+            for (int i = 1; i < nd; i++) th.emplace_back(local, i);
+            local(0);
+            for (auto &t : th) t.join();
+        }
+        // all shard searches are host-synchronous and this one process drives every device: a failure is known HERE,
+        // before anything collective has been issued, so returning now strands nobody
+        for (int i = 0; i < nd; i++)
+            if (rcs[(size_t)i] != LB_OK) {
+                c->last_error = std::string("shard search failed: ") + lb_gpu_last_error(shards[i]);
+                return rcs[(size_t)i];
+            }
         Peer &p0 = c->peers[0];
-        if (nd == 1) {
-            LB_HIP(hipSetDevice(p0.device));
-            LB_HIP(hipMemcpyAsync(p0.d_all, p0.d_mine, bb, hipMemcpyDeviceToDevice, p0.stream));
-        } else {
-            // one grouped all-gather over the node's xGMI links
+        LB_HIP(hipSetDevice(p0.device));
+        const size_t bs = bb + kStatusBytes; // (block stride of d_all, as in search_device; the status words stay unused)
+        LB_HIP(hipMemcpyAsync(p0.d_all, p0.d_mine, bb, hipMemcpyDeviceToDevice, p0.stream));
+        if (nd > 1) {
+            // The answer is needed on ONE device (host results out), so the blocks are gathered to it and nowhere else:
+            // grouped ncclSend / ncclRecv over xGMI, (nd - 1) x nq*k*12 bytes in all (an all-gather would move nd times
+            // that and leave nd - 1 copies unread).  RCCL builds without point-to-point: the all-gather.
             int nrc = rccl().GroupStart();
-            for (int i = 0; i < nd && nrc == kNcclSuccess; i++) {
-                Peer &p = c->peers[(size_t)i];
-                nrc = rccl().AllGather(p.d_mine, p.d_all, bb, kNcclChar, p.comm, p.stream);
+            if (rccl().Send && rccl().Recv) {
+                for (int i = 1; i < nd && nrc == kNcclSuccess; i++) {
+                    Peer &p = c->peers[(size_t)i];
+                    nrc = rccl().Send(p.d_mine, bb, kNcclChar, 0, p.comm, p.stream);
+                    if (nrc == kNcclSuccess)
+                        nrc = rccl().Recv(static_cast<char *>(p0.d_all) + (size_t)i * bs, bb, kNcclChar, i, p0.comm, p0.stream);
+                }
+            } else {
+                for (int i = 0; i < nd && nrc == kNcclSuccess; i++) {
+                    Peer &p = c->peers[(size_t)i];
+                    if (i != 0) { // every device needs room for every block in this form
+                        LB_HIP(hipSetDevice(p.device));
+                        ensure_blocks(p, nd, nq, k);
+                    }
+                    nrc = rccl().AllGather(p.d_mine, p.d_all, bs, kNcclChar, p.comm, p.stream);
+                }
+                LB_HIP(hipSetDevice(p0.device));
             }
             const int erc = rccl().GroupEnd();
-            if (nrc != kNcclSuccess || erc != kNcclSuccess) { set_err(c, "ncclAllGather", nrc != kNcclSuccess ? nrc : erc); return LB_ERR_HIP; }
+            if (nrc != kNcclSuccess || erc != kNcclSuccess) { set_err(c, "RCCL gather", nrc != kNcclSuccess ? nrc : erc); return LB_ERR_HIP; }
         }
-        // the merge runs where the answer is needed: device 0
-        LB_HIP(hipSetDevice(p0.device));
         if (p0.out_n < (size_t)nk) {
             if (p0.d_dist) (void)hipFree(p0.d_dist);
             if (p0.d_lab) (void)hipFree(p0.d_lab);
@@ -381,10 +459,13 @@ int lb_gpu_comm_search_all(lb_gpu_comm *c, lb_gpu_index *const *shards, int64_t 
             LB_HIP(hipMalloc(&p0.d_lab, (size_t)nk * sizeof(int64_t)));
             p0.out_n = (size_t)nk;
         }
-        const int rc = lb_gpu_merge_topk_packed_device(p0.device, nd, nq, k, p0.d_all, p0.d_dist, p0.d_lab, p0.stream);
-        if (rc != LB_OK) return rc;
-        LB_HIP(hipMemcpy(dist, p0.d_dist, (size_t)nk * sizeof(float), hipMemcpyDeviceToHost));
-        LB_HIP(hipMemcpy(labels, p0.d_lab, (size_t)nk * sizeof(int64_t), hipMemcpyDeviceToHost));
+        const char *all = static_cast<const char *>(p0.d_all);
+        launch_merge_topk(nd, nq, k, reinterpret_cast<const float *>(all + nk * 8), reinterpret_cast<const int64_t *>(all),
+                          (int64_t)(bs / 4), (int64_t)(bs / 8), p0.d_dist, p0.d_lab, p0.stream);
+        LB_LAUNCH_CHECK();
+        LB_HIP(hipMemcpyAsync(dist, p0.d_dist, (size_t)nk * sizeof(float), hipMemcpyDeviceToHost, p0.stream));
+        LB_HIP(hipMemcpyAsync(labels, p0.d_lab, (size_t)nk * sizeof(int64_t), hipMemcpyDeviceToHost, p0.stream));
+        LB_HIP(hipStreamSynchronize(p0.stream));
         for (int i = 1; i < nd; i++) { // leave no work in flight on the other devices
             LB_HIP(hipSetDevice(c->peers[(size_t)i].device));
             LB_HIP(hipStreamSynchronize(c->peers[(size_t)i].stream));
@@ -393,6 +474,9 @@ int lb_gpu_comm_search_all(lb_gpu_comm *c, lb_gpu_index *const *shards, int64_t 
         (void)hipGetLastError();
         c->last_error = std::string("HIP error in ") + e.what;
         return e.e == hipErrorOutOfMemory ? LB_ERR_OOM : LB_ERR_HIP;
+    } catch (...) {
+        c->last_error = "internal error (exception)";
+        return LB_ERR_INTERNAL;
     }
     return LB_OK;
 }

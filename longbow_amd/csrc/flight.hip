@@ -21,6 +21,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -144,9 +145,13 @@ struct Field {
     std::vector<Field> children;
 };
 
-bool parse_field(const Table &f, Field &out, int depth)
+// `budget`: Field nodes this schema may still create.  FlatBuffers offsets may alias (every children vector can point
+// at the same table), so per-level caps alone bound neither the work nor the memory: 64 children x depth 8 from a
+// 3 KB message would be 64^8 nodes.  The total is capped instead.
+constexpr int kMaxSchemaNodes = 4096;
+bool parse_field(const Table &f, Field &out, int depth, int &budget)
 {
-    if (!f.ok || depth > 8) return false;
+    if (!f.ok || depth > 8 || --budget < 0) return false;
     (void)str(f, 0, out.name);
     out.type = f.scalar<uint8_t>(2, 0);
     const Table ty = subtable(f, 3);
@@ -168,7 +173,7 @@ bool parse_field(const Table &f, Field &out, int depth)
             size_t tgt = 0;
             if (!indirect(f.buf, first + 4 * (size_t)i, tgt)) return false;
             Field c;
-            if (!parse_field(table_at(f.buf, tgt), c, depth + 1)) return false;
+            if (!parse_field(table_at(f.buf, tgt), c, depth + 1, budget)) return false;
             out.children.push_back(std::move(c));
         }
     }
@@ -237,11 +242,12 @@ Status parse_schema(const Table &schema, std::vector<Field> &fields)
     uint32_t n = 0;
     size_t first = 0;
     if (!vec(schema, 1, n, first)) return err(GRPC_INTERNAL, "failed to create record reader: schema without fields");
-    if (n > 4096) return err(GRPC_INTERNAL, "failed to create record reader: too many fields");
+    if (n > (uint32_t)kMaxSchemaNodes) return err(GRPC_INTERNAL, "failed to create record reader: too many fields");
+    int budget = kMaxSchemaNodes;
     for (uint32_t i = 0; i < n; i++) {
         size_t tgt = 0;
         Field f;
-        if (!indirect(schema.buf, first + 4 * (size_t)i, tgt) || !parse_field(table_at(schema.buf, tgt), f, 0))
+        if (!indirect(schema.buf, first + 4 * (size_t)i, tgt) || !parse_field(table_at(schema.buf, tgt), f, 0, budget))
             return err(GRPC_INTERNAL, "failed to create record reader: bad field %u", i);
         fields.push_back(std::move(f));
     }
@@ -325,11 +331,19 @@ bool locate(const std::vector<Field> &fields, const char *name, const Field *&f,
     return false;
 }
 
+// buffer i of the batch if it holds at least need_bytes (>= 0) bytes, else null.  parse_batch has checked that
+// [off, off + len) lies inside the message body.
 const uint8_t *buf_ptr(const Batch &b, size_t i, int64_t need_bytes)
 {
-    if (i >= b.bufs.size() || b.bufs[i].len < need_bytes) return nullptr;
+    if (need_bytes < 0 || i >= b.bufs.size() || b.bufs[i].len < need_bytes) return nullptr;
     return b.body.p + b.bufs[i].off;
 }
+// a * b with both factors >= 0, false on overflow (byte counts computed from untrusted 64-bit lengths)
+bool mul_i64(int64_t a, int64_t b, int64_t &out)
+{
+    return a >= 0 && b >= 0 && !__builtin_mul_overflow(a, b, &out);
+}
+int64_t node_len(const Batch &b, size_t i) { return i < b.nodes.size() ? b.nodes[i].len : -1; }
 
 // ---- FlatBuffers builder (back to front) -----------------------------------------------------------
 struct Fbb {
@@ -557,37 +571,56 @@ int finish(const Status &st, char *errbuf, size_t errcap)
 
 extern "C" {
 
-lb_flight_datasets *lb_flight_datasets_new(void) { return new (std::nothrow) lb_flight_datasets(); }
+lb_flight_datasets *lb_flight_datasets_new(void)
+{
+    try {
+        return new (std::nothrow) lb_flight_datasets();
+    } catch (...) {
+        return nullptr;
+    }
+}
 
 void lb_flight_datasets_free(lb_flight_datasets *r) { delete r; }
 
 int lb_flight_datasets_put(lb_flight_datasets *r, const char *name, lb_gpu_index *h)
 {
     if (!r || !name) return LB_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> g(r->mu);
-    if (h) r->sets[name] = h;
-    else r->sets.erase(name);
+    try {
+        std::lock_guard<std::mutex> g(r->mu);
+        if (h) r->sets[name] = h;
+        else r->sets.erase(name);
+    } catch (...) {
+        return LB_ERR_OOM;
+    }
     return LB_OK;
 }
 
 void lb_flight_free_buffer(uint8_t *p) { std::free(p); }
 
+// No C++ exception may cross the C ABI (in a cgo or ctypes host that is std::terminate): every entry point below
+// runs its body inside a catch-all and reports allocation failures / anything unexpected as a status.
 int lb_flight_encode_results(const int64_t *ids, const float *scores, int64_t n, uint8_t **ipc_out, size_t *len_out)
 {
     if (n < 0 || (n > 0 && (!ids || !scores)) || !ipc_out || !len_out) return LB_ERR_INVALID_ARG;
-    while (n > 0 && ids[n - 1] < 0) n--; // fewer than k hits: the reference returns min(k, N) rows
-    std::vector<uint8_t> out;
-    encode_results(ids, scores, n, out);
-    uint8_t *p = static_cast<uint8_t *>(std::malloc(out.size() ? out.size() : 1));
-    if (!p) return LB_ERR_OOM;
-    std::memcpy(p, out.data(), out.size());
-    *ipc_out = p;
-    *len_out = out.size();
+    try {
+        while (n > 0 && ids[n - 1] < 0) n--; // fewer than k hits: the reference returns min(k, N) rows
+        std::vector<uint8_t> out;
+        encode_results(ids, scores, n, out);
+        uint8_t *p = static_cast<uint8_t *>(std::malloc(out.size() ? out.size() : 1));
+        if (!p) return LB_ERR_OOM;
+        std::memcpy(p, out.data(), out.size());
+        *ipc_out = p;
+        *len_out = out.size();
+    } catch (const std::bad_alloc &) {
+        return LB_ERR_OOM;
+    } catch (...) {
+        return LB_ERR_INTERNAL;
+    }
     return LB_OK;
 }
 
-int lb_flight_vector_search_exchange(lb_flight_datasets *reg, const uint8_t *ipc_in, size_t len_in, uint8_t **ipc_out,
-                                     size_t *len_out, char *errbuf, size_t errcap)
+static int exchange_body(lb_flight_datasets *reg, const uint8_t *ipc_in, size_t len_in, uint8_t **ipc_out,
+                         size_t *len_out, char *errbuf, size_t errcap)
 {
     if (errbuf && errcap) errbuf[0] = 0;
     if (!reg || !ipc_out || !len_out || (!ipc_in && len_in))
@@ -619,6 +652,7 @@ int lb_flight_vector_search_exchange(lb_flight_datasets *reg, const uint8_t *ipc
     if (!have_schema) return finish(err(GRPC_INTERNAL, "failed to create record reader: no schema message"), errbuf, errcap);
     if (!have_batch) return finish(err(GRPC_INVALID_ARGUMENT, "empty search request"), errbuf, errcap);
     if (batch.rows == 0) return finish(err(GRPC_INVALID_ARGUMENT, "empty search request parameters"), errbuf, errcap);
+    if (batch.rows < 0) return finish(err(GRPC_INTERNAL, "failed to read record: bad row count"), errbuf, errcap);
 
     const Field *f = nullptr;
     ColPos pos;
@@ -634,8 +668,9 @@ int lb_flight_vector_search_exchange(lb_flight_datasets *reg, const uint8_t *ipc
         int32_t a = 0, b2 = 0;
         std::memcpy(&a, offs, 4);
         std::memcpy(&b2, offs + 4, 4);
+        if (a < 0 || b2 < a) return finish(err(GRPC_INTERNAL, "failed to read record: bad 'dataset' value"), errbuf, errcap);
         const uint8_t *data = buf_ptr(batch, pos.buf + 2, b2);
-        if (a < 0 || b2 < a || (!data && b2 > 0)) return finish(err(GRPC_INTERNAL, "failed to read record: bad 'dataset' value"), errbuf, errcap);
+        if (!data && b2 > 0) return finish(err(GRPC_INTERNAL, "failed to read record: bad 'dataset' value"), errbuf, errcap);
         if (b2 > a) name.assign(reinterpret_cast<const char *>(data + a), (size_t)(b2 - a));
     } else if (f->type == T_LARGEUTF8 || f->type == T_LARGEBINARY) {
         const uint8_t *offs = buf_ptr(batch, pos.buf + 1, 16);
@@ -643,8 +678,10 @@ int lb_flight_vector_search_exchange(lb_flight_datasets *reg, const uint8_t *ipc
         int64_t a = 0, b2 = 0;
         std::memcpy(&a, offs, 8);
         std::memcpy(&b2, offs + 8, 8);
+        if (a < 0 || b2 < a || b2 - a > (int64_t)1 << 20) // (a dataset name; never megabytes)
+            return finish(err(GRPC_INTERNAL, "failed to read record: bad 'dataset' value"), errbuf, errcap);
         const uint8_t *data = buf_ptr(batch, pos.buf + 2, b2);
-        if (a < 0 || b2 < a || (!data && b2 > 0)) return finish(err(GRPC_INTERNAL, "failed to read record: bad 'dataset' value"), errbuf, errcap);
+        if (!data && b2 > 0) return finish(err(GRPC_INTERNAL, "failed to read record: bad 'dataset' value"), errbuf, errcap);
         if (b2 > a) name.assign(reinterpret_cast<const char *>(data + a), (size_t)(b2 - a));
     } else {
         return finish(err(GRPC_INVALID_ARGUMENT, "'dataset' must be a string column"), errbuf, errcap);
@@ -657,7 +694,7 @@ int lb_flight_vector_search_exchange(lb_flight_datasets *reg, const uint8_t *ipc
         const uint8_t *d = buf_ptr(batch, pos.buf + 1, f->bit_width / 8);
         if (!d) return finish(err(GRPC_INTERNAL, "failed to read record: bad 'k' buffer"), errbuf, errcap);
         if (f->bit_width == 32) { int32_t v; std::memcpy(&v, d, 4); k = v; }
-        else { int64_t v; std::memcpy(&v, d, 8); k = (int)v; }
+        else { int64_t v; std::memcpy(&v, d, 8); k = v < 1 ? 0 : (v > (int64_t)LB_MAX_K + 1 ? LB_MAX_K + 1 : (int)v); }
     }
     // query_vector, row 0
     if (!locate(fields, "query_vector", f, pos, layout_ok))
@@ -668,9 +705,10 @@ int lb_flight_vector_search_exchange(lb_flight_datasets *reg, const uint8_t *ipc
     const bool child_f32 = f->children.size() == 1 && f->children[0].type == T_FLOAT && f->children[0].precision == 1;
     if (f->type == T_FSLIST && child_f32) {
         qlen = f->list_size;
-        // buffers: [list validity][child validity][child values]
+        // buffers: [list validity][child validity][child values]; row 0 = the first list_size values
+        if (qlen <= 0 || qlen > LB_MAX_DIM) return finish(err(GRPC_INTERNAL, "invalid fixed size list length"), errbuf, errcap);
         const uint8_t *vals = buf_ptr(batch, pos.buf + 2, qlen * 4);
-        if (!vals || qlen <= 0) return finish(err(GRPC_INTERNAL, "invalid fixed size list length"), errbuf, errcap);
+        if (!vals) return finish(err(GRPC_INTERNAL, "invalid fixed size list length"), errbuf, errcap);
         q = reinterpret_cast<const float *>(vals);
     } else if ((f->type == T_LIST || f->type == T_LARGELIST) && child_f32) {
         // buffers: [list validity][offsets][child validity][child values]
@@ -688,8 +726,14 @@ int lb_flight_vector_search_exchange(lb_flight_datasets *reg, const uint8_t *ipc
             std::memcpy(&a, offs, 8);
             std::memcpy(&b2, offs + 8, 8);
         }
+        // 0 <= a <= b2 <= child length, where the child length is what the child's FieldNode declares AND what its
+        // values buffer holds; all compared as element counts, so no byte count can overflow
+        const int64_t child_vals = pos.buf + 3 < batch.bufs.size() ? batch.bufs[pos.buf + 3].len / 4 : -1;
+        const int64_t child_node = node_len(batch, pos.node + 1);
+        if (a < 0 || b2 < a || b2 > child_vals || (child_node >= 0 && b2 > child_node) || b2 - a > LB_MAX_DIM)
+            return finish(err(GRPC_INTERNAL, "invalid list length"), errbuf, errcap);
         const uint8_t *vals = buf_ptr(batch, pos.buf + 3, b2 * 4);
-        if (a < 0 || b2 < a || !vals) return finish(err(GRPC_INTERNAL, "invalid list length"), errbuf, errcap);
+        if (!vals) return finish(err(GRPC_INTERNAL, "invalid list length"), errbuf, errcap);
         q = reinterpret_cast<const float *>(vals) + a;
         qlen = b2 - a;
     } else {
@@ -706,6 +750,9 @@ int lb_flight_vector_search_exchange(lb_flight_datasets *reg, const uint8_t *ipc
     const int dim = lb_gpu_index_dim(h);
     if (qlen != dim) return finish(err(GRPC_INVALID_ARGUMENT, "dimension mismatch: expected %d, got %lld", dim, (long long)qlen), errbuf, errcap);
     if (k < 1) return finish(err(GRPC_INVALID_ARGUMENT, "k must be at least 1"), errbuf, errcap);
+    // (the reference has no cap and would allocate k results; the library's search tops out at LB_MAX_K, and an
+    // untrusted k must not size any buffer before it is checked)
+    if (k > LB_MAX_K) return finish(err(GRPC_INVALID_ARGUMENT, "k must be at most %d", LB_MAX_K), errbuf, errcap);
     std::vector<float> qa((size_t)qlen); // (the values buffer is only as aligned as the caller's bytes)
     std::memcpy(qa.data(), reinterpret_cast<const void *>(q), (size_t)qlen * sizeof(float));
     std::vector<float> dist((size_t)k);
@@ -718,7 +765,19 @@ int lb_flight_vector_search_exchange(lb_flight_datasets *reg, const uint8_t *ipc
     return GRPC_OK;
 }
 
-int lb_flight_index_add_ipc(lb_gpu_index *h, const uint8_t *ipc, size_t len, int64_t *rows_added, char *errbuf, size_t errcap)
+int lb_flight_vector_search_exchange(lb_flight_datasets *reg, const uint8_t *ipc_in, size_t len_in, uint8_t **ipc_out,
+                                     size_t *len_out, char *errbuf, size_t errcap)
+{
+    try {
+        return exchange_body(reg, ipc_in, len_in, ipc_out, len_out, errbuf, errcap);
+    } catch (const std::bad_alloc &) {
+        return finish(err(GRPC_INTERNAL, "out of memory while handling the request"), errbuf, errcap);
+    } catch (...) {
+        return finish(err(GRPC_INTERNAL, "internal error while handling the request"), errbuf, errcap);
+    }
+}
+
+static int add_ipc_body(lb_gpu_index *h, const uint8_t *ipc, size_t len, int64_t *rows_added, char *errbuf, size_t errcap)
 {
     if (errbuf && errcap) errbuf[0] = 0;
     if (rows_added) *rows_added = 0;
@@ -743,6 +802,7 @@ int lb_flight_index_add_ipc(lb_gpu_index *h, const uint8_t *ipc, size_t len, int
         const Status s = parse_batch(m, b);
         if (s.code != GRPC_OK) return s;
         if (b.rows == 0) return {};
+        if (b.rows < 0 || b.rows > (int64_t)0xffffffffll) return err(GRPC_INTERNAL, "failed to read record: bad row count");
         const Field *f = nullptr;
         ColPos pos;
         bool layout_ok = true;
@@ -754,14 +814,21 @@ int lb_flight_index_add_ipc(lb_gpu_index *h, const uint8_t *ipc, size_t len, int
         if (f->children[0].type != T_FLOAT || f->children[0].precision != 1)
             return err(GRPC_INVALID_ARGUMENT, "'vector' elements must be float32 in this entry point");
         if (pos.node < b.nodes.size() && b.nodes[pos.node].nulls != 0) return err(GRPC_INVALID_ARGUMENT, "null vectors are not supported");
-        const uint8_t *vals = buf_ptr(b, pos.buf + 2, b.rows * (int64_t)dim * 4);
+        // the column's FieldNodes must agree with the batch: `rows` lists, rows * dim child values
+        int64_t nvals = 0, vbytes = 0;
+        if (!mul_i64(b.rows, dim, nvals) || !mul_i64(nvals, 4, vbytes)) return err(GRPC_INTERNAL, "'vector' values buffer is too short");
+        if ((node_len(b, pos.node) >= 0 && node_len(b, pos.node) != b.rows) ||
+            (node_len(b, pos.node + 1) >= 0 && node_len(b, pos.node + 1) != nvals))
+            return err(GRPC_INTERNAL, "failed to read record: 'vector' lengths disagree with the batch");
+        const uint8_t *vals = buf_ptr(b, pos.buf + 2, vbytes);
         if (!vals) return err(GRPC_INTERNAL, "'vector' values buffer is too short");
         std::vector<int64_t> ids;
         const Field *fi = nullptr;
         ColPos pi;
         if (locate(fields, "id", fi, pi, layout_ok) && fi->type == T_INT && (fi->bit_width == 64 || (fi->bit_width == 32 && !fi->is_signed))) {
             const int w = fi->bit_width / 8;
-            const uint8_t *d = buf_ptr(b, pi.buf + 1, b.rows * w);
+            int64_t idbytes = 0;
+            const uint8_t *d = mul_i64(b.rows, w, idbytes) ? buf_ptr(b, pi.buf + 1, idbytes) : nullptr;
             if (!d) return err(GRPC_INTERNAL, "'id' buffer is too short");
             ids.resize((size_t)b.rows);
             for (int64_t i = 0; i < b.rows; i++) {
@@ -784,6 +851,17 @@ int lb_flight_index_add_ipc(lb_gpu_index *h, const uint8_t *ipc, size_t len, int
     if (rows_added) *rows_added = added;
     if (st.code == GRPC_OK && !have_schema) st = err(GRPC_INTERNAL, "no schema message");
     return finish(st, errbuf, errcap);
+}
+
+int lb_flight_index_add_ipc(lb_gpu_index *h, const uint8_t *ipc, size_t len, int64_t *rows_added, char *errbuf, size_t errcap)
+{
+    try {
+        return add_ipc_body(h, ipc, len, rows_added, errbuf, errcap);
+    } catch (const std::bad_alloc &) {
+        return finish(err(GRPC_INTERNAL, "out of memory while reading the stream"), errbuf, errcap);
+    } catch (...) {
+        return finish(err(GRPC_INTERNAL, "internal error while reading the stream"), errbuf, errcap);
+    }
 }
 
 } // extern "C"

@@ -68,6 +68,7 @@ struct Workspace {
     size_t d_out_n = 0;
     std::vector<Event> events;
     size_t ev_used = 0;
+    const lb_cancel *ctx = nullptr; // the running call's cancellation context (or null)
 
     ~Workspace()
     {
@@ -237,7 +238,7 @@ struct lb_gpu_index {
     uint32_t smap_count = 0, smap_cap = 0;
     bool smap_valid = false;
     // optional split-bf16 image of the corpus for the 3x-bf16 candidate contraction (same byte shape as d_X)
-    std::atomic<int> cand_mode{0};
+    std::atomic<int> cand_mode{LB_CAND_AUTO};
     float *d_Xs = nullptr;
     int64_t xs_rows = 0; // rows of d_X already mirrored in d_Xs
 
@@ -399,6 +400,7 @@ struct SamplePlan {
 };
 std::atomic<int> g_sample_tau{lb_tunable("LB_SAMPLE_TAU", 1)};
 std::atomic<int> g_fused_fail_next{0}; // test hook: treat the next fused launch as one whose waits gave up
+std::atomic<int> g_search_fail_next{0}; // test hook (diagnostic build): the next search on this process fails with LB_ERR_INTERNAL
 // Add batches of at least this many bytes pin the caller's buffer instead of staging it (0 = never)
 std::atomic<long long> g_add_register_min{(long long)lb_tunable("LB_ADD_REGISTER_MIN_MB", 64) << 20};
 static SamplePlan sample_plan(int64_t n, int keep, uint32_t cap, uint32_t count_max = 8192u)
@@ -443,6 +445,7 @@ bool run_scan_path(lb_gpu_index *h, Workspace *w, hipStream_t s, const float *d_
     const SamplePlan sp = mode == 0 ? sample_plan(n, kkeep, w->cap, scan_count) : SamplePlan{};
     if (!sp.on) launch_init_cand(w->cs, d_sel, nsel, s);
     for (int g0 = 0; g0 < nsel; g0 += kScanMaxQ) {
+        ctx_check(w->ctx);
         const int gn = std::min(kScanMaxQ, nsel - g0);
         const int *use_sel = d_sel + g0; // d_sel is always an explicit slot list here
         int64_t pos = 0;
@@ -474,6 +477,7 @@ bool run_scan_path(lb_gpu_index *h, Workspace *w, hipStream_t s, const float *d_
             launch_query_norms(order, d_q, use_sel, gn, h->dim, w->d_qna, s);
         }
         while (pos < n) {
+            ctx_check(w->ctx);
             const int64_t end = chunk_end_host(step, pos, n, kkeep, w->cap, safe, /*big_boot=*/true);
             const bool boot = step == 0;
             {
@@ -546,6 +550,85 @@ void scan_with_retry(lb_gpu_index *h, Workspace *w, hipStream_t s, const float *
     }
 }
 
+// ---- which kernel generates the candidates of a batch ----------------------------------------------------------
+// Every route is exact (re-rank + containment proof, else the exact scan redoes the query), so this is a cost choice.
+//   NARROW32 / NARROW64  256 x 32 or 128 x 64 tile, operands split to bf16 in registers: one HBM-bound corpus pass per
+//                        32 / 64 queries (kernels_gemm_narrow.hip)
+//   TALL                 256-row tiles on the split contraction (kernels_gemm_tall.hip): corpus image (split 1) or f32
+//                        corpus split in registers (split 2)
+//   WIDE                 128 x 128 tile (kernels_gemm.hip): f32 MFMA (split 0: the strict mode's route beyond 384
+//                        queries), or the split contraction where the tall tile cannot run
+// Candidate modes (lb_gpu_index_set_candidate_mode):
+//   LB_CAND_AUTO (default)    the cheapest route by the cost model below -- beyond the narrow tiles that is the tall tile
+//                             with the corpus split in registers (no second copy of the corpus), at every batch size
+//   LB_CAND_F32_MFMA          as AUTO up to 384 queries, the f32-MFMA 128 x 128 tile beyond (rounds 1-2 default)
+//   LB_CAND_SPLIT_BF16        corpus image for everything beyond the narrow tiles
+//   LB_CAND_SPLIT_BF16_INREG  in-register split for everything beyond the narrow tiles
+// Cost model: a pass over `n` positions of dimension D costs  n * (alpha * D + beta) [+ gamma]  per query tile, with
+// the constants measured per kernel on MI355X over D in {128 .. 1536} x n in {100k .. 10M} (tools/route_grid.py; the
+// GPU test test_route_choice_is_near_the_best_forced_route checks the choice against every forced route).
+enum RouteKind { ROUTE_NARROW32 = 1, ROUTE_NARROW64 = 2, ROUTE_TALL = 3, ROUTE_WIDE = 4 };
+struct Route {
+    int kind = ROUTE_WIDE;
+    int split = 0;
+    double cost_ms = 0;
+};
+struct RouteCost { // ms = 1e-9 * n * (alpha * D + beta) * tiles + gamma
+    double alpha, beta, gamma;
+};
+// (1M x 768: narrow passes 0.50 / 0.48 ms; tall in-register 0.27 + 0.535 per 128-query tile; image 0.23 + 0.49;
+//  f32 wide 1.49 per 128-query tile)
+constexpr RouteCost kCostNarrow32{0.000651, 0.0, 0.0};
+constexpr RouteCost kCostNarrow64{0.000625, 0.0, 0.0};
+constexpr RouteCost kCostTallInreg{0.000697, 0.0, 0.0};
+constexpr RouteCost kCostTallImage{0.000638, 0.0, 0.0};
+constexpr RouteCost kCostWideF32{0.00194, 0.0, 0.0};
+constexpr double kTallFirstTile = 0.000352; // the first query tile of a tall pass also waits for the corpus stream
+inline double route_ms(const RouteCost &c, int64_t n, int D, int tiles)
+{
+    return 1e-9 * (double)n * (c.alpha * (double)D + c.beta) * (double)tiles + c.gamma;
+}
+
+static Route choose_route(int nq, int64_t n, int D, int cmode, bool narrow_ok, bool have_image)
+{
+    static const int narrow_max = lb_tunable("LB_NARROW_MAXQ", 384);
+    static const bool nsplit_on = lb_tunable("LB_NARROW_SPLIT", 1) != 0;
+    static const int tall_on = lb_tunable("LB_TALL", 1);
+    const int tiles32 = (nq + 31) / 32, tiles64 = (nq + 63) / 64, tiles128 = (nq + 127) / 128;
+    // (tall tiles only with enough of them to fill the chip a few times over: 512 workgroups run at once, and at 125k
+    // visible rows x 256 queries the 978 tall tiles came out 5 % behind the 3908 smaller ones)
+    const bool tall_fills = (n / 256) * tiles128 >= 2048;
+    Route cand[5];
+    int nc = 0;
+    auto add = [&](int kind, int split, double ms) { cand[nc].kind = kind; cand[nc].split = split; cand[nc].cost_ms = ms; nc++; };
+    const bool image = cmode == LB_CAND_SPLIT_BF16 && have_image;
+    if (narrow_ok && !image && (cmode == LB_CAND_AUTO || nq <= narrow_max)) {
+        const int nsp = nsplit_on ? 2 : 0;
+        if (nq <= 32 || tiles32 <= 10) add(ROUTE_NARROW32, nsp, route_ms(kCostNarrow32, n, D, tiles32));
+        if (nq > 32) add(ROUTE_NARROW64, nsp, route_ms(kCostNarrow64, n, D, tiles64));
+    }
+    if (narrow_ok && tall_on) {
+        if (image) add(ROUTE_TALL, 1, route_ms(kCostTallImage, n, D, tiles128) + 1e-9 * (double)n * D * kTallFirstTile * 0.85);
+        else if (nsplit_on && (tall_fills || cmode == LB_CAND_SPLIT_BF16_INREG) &&
+                 (cmode != LB_CAND_F32_MFMA || nq <= narrow_max))
+            add(ROUTE_TALL, 2, route_ms(kCostTallInreg, n, D, tiles128) + 1e-9 * (double)n * D * kTallFirstTile);
+    }
+    if (image && !tall_on) add(ROUTE_WIDE, 1, route_ms(kCostWideF32, n, D, tiles128) * 0.4);
+    else if (cmode == LB_CAND_F32_MFMA || cmode == LB_CAND_AUTO || nc == 0) add(ROUTE_WIDE, 0, route_ms(kCostWideF32, n, D, tiles128));
+#ifdef LB_DIAG
+    { // A/B (tools/route_grid.py): force a route when it is available for this batch
+        const int force = lb_tunable("LB_FORCE_ROUTE", 0);
+        for (int i = 0; i < nc; i++)
+            if (cand[i].kind == force) return cand[i];
+    }
+#endif
+    if (nq <= 32 && nc > 0 && cand[0].kind == ROUTE_NARROW32) return cand[0]; // one pass of the 32-query tile: nothing is cheaper
+    int best = 0;
+    for (int i = 1; i < nc; i++)
+        if (cand[i].cost_ms < cand[best].cost_ms) best = i;
+    return cand[best];
+}
+
 int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, const float *d_q, int k,
                         float *d_dist, int64_t *d_lab, int kc, bool prof, int64_t &fallbacks)
 {
@@ -553,6 +636,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     const RowView rv = row_view(h);
     const int64_t n = rv.n; // positions to walk: corpus rows, or the visible-row list under a selective filter
     const uint8_t *mask = rv.mask;
+    ctx_check(w->ctx);
     ProfScope whole(w, s, prof, 4);
 
     // Path selection (measured at 1M x 768 on MI355X, tools/bench_sweep.py): <= 4 queries exact scan
@@ -575,15 +659,23 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     // up to 8 queries the sample is scored by the wave-per-row kernel (candidate keys; 22-28 us against
     // 44 us for 8192 rows through the 32-workgroup MFMA launch); larger batches sample through the MFMA
     // kernel itself.  Up to 64 queries the exact query norms ride in the threshold launch.
-    // candidate contraction: exact f32 MFMA, or 3 x bf16 MFMA on the split images
+    // candidate contraction: exact f32 MFMA, or 3 x bf16 MFMA on split operands (choose_route)
     const int cmode = h->cand_mode.load();
-    // 1: pre-split bf16 image of the corpus; 2: f32 operands split in registers (no image)
-    const int split = (cmode == 1 && h->d_Xs != nullptr && h->xs_rows == h->n && h->dim % 32 == 0) ? 1
-                      : (cmode == 2 && narrow_ok) ? 2 : 0;
+    const bool have_image = h->d_Xs != nullptr && h->xs_rows == h->n && h->dim % 32 == 0;
+    const Route route = choose_route(nq, n, h->dim, cmode, narrow_ok, have_image);
+    const int split = route.split;                 // of the operands handed to the kernel: 0 f32, 1 images, 2 f32 split in registers
+    const bool use_narrow = route.kind == ROUTE_NARROW32 || route.kind == ROUTE_NARROW64;
+    const bool tile64 = route.kind == ROUTE_NARROW64;
+    const bool nsplit = use_narrow && route.split == 2;
+    const bool use_tall = route.kind == ROUTE_TALL;
+    const int wsplit = use_narrow ? 0 : route.split;
     const float *gx = h->d_X, *gq = d_q;
     const float u24 = 5.9604645e-8f;
-    float gamma = 1.05f * (float)(h->dim + 8) * u24; // k-ordered f32 fma chain of length D
-    if (split == 2) gamma = 1.05f * ((float)(3 * h->dim / 16 + 24) * u24 + 3.0f * 3.8146973e-6f);
+    // rounding-error bound of the candidate inner products, per unit of ||q|| ||x||: a k-ordered f32 fma chain of
+    // length D, or (split contraction) 3D/16 MFMA accumulations + <=16-term block sums plus the dropped lo*lo /
+    // residual terms
+    const float gamma = route.split == 0 ? 1.05f * (float)(h->dim + 8) * u24
+                                         : 1.05f * ((float)(3 * h->dim / 16 + 24) * u24 + 3.0f * 3.8146973e-6f);
     auto split_queries = [&]() { // hi / lo bf16 image of the batch (same bytes as the f32 rows)
         const size_t need = (size_t)nq * h->dim * sizeof(float);
         if (w->d_qs_bytes < need) {
@@ -595,49 +687,11 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         }
         launch_split_bf16(d_q, w->d_qs, nq, h->dim, s);
     };
-    if (split == 1) {
-        split_queries();
+    if (!use_narrow && route.split != 0) split_queries(); // the tall / wide split kernels take the batch as an image
+    if (!use_narrow && route.split == 1) {
         gx = h->d_Xs;
         gq = w->d_qs;
-        // 3D/16 MFMA accumulations + <=16-term block sums, plus the dropped lo*lo / residual terms
-        gamma = 1.05f * ((float)(3 * h->dim / 16 + 24) * u24 + 3.0f * 3.8146973e-6f);
     }
-    // Tile choice by padded work.  The 32- and 64-query tiles run the contraction as 3 x bf16 MFMA on operands
-    // split in registers (kernels_gemm_narrow.hip, SPLIT): both are HBM streams (one corpus pass each), so a
-    // batch takes ceil(nq / 64) passes of the 64-query tile or one pass of the 32-query tile; the 128-query
-    // f32 tile (1.49 ms per pass at 1M x 768, MFMA-bound) takes over where its padded cost is lower.
-    // Costs in ms per corpus pass at 1M x 768 (only their ratios matter).
-    static const int force64 = lb_tunable("LB_NARROW_TILE64", -1);
-    static const bool nsplit_on = lb_tunable("LB_NARROW_SPLIT", 1) != 0;
-    static const double kCost32 = lb_tunable("LB_COST32_US", nsplit_on ? 500 : 430) * 1e-3;
-    static const double kCost64 = lb_tunable("LB_COST64_US", nsplit_on ? 480 : 800) * 1e-3;
-    const int tiles_n = (nq + 31) / 32, tiles_64 = (nq + 63) / 64, tiles_w = (nq + 127) / 128;
-    const double c32 = (nq <= 32 || tiles_n <= 10) ? kCost32 * tiles_n : 1e9, c64 = kCost64 * tiles_64, cw = 1.49 * tiles_w;
-    const bool narrow_allowed = split != 1 && narrow_ok && nq <= narrow_max;
-    bool use_narrow = narrow_allowed && (nq <= 32 || std::min(c32, c64) < cw);
-    bool tile64 = use_narrow && nq > 32 && c64 <= c32;
-    if (force64 == 0) { tile64 = false; use_narrow = narrow_allowed && (nq <= 32 || c32 < cw); }
-    if (force64 == 1 && narrow_allowed && nq > 32) { use_narrow = true; tile64 = true; }
-    bool nsplit = use_narrow && nsplit_on;
-    // Between the 64-query tile's HBM-bound passes and the f32 tile: the 256-row x 128-query tile with the same split
-    // contraction, corpus operand split in registers (kernels_gemm_tall.hip; measured at 1M x 768: 0.83 ms for one
-    // query tile, 1.33 for two, 1.85 for three, against 0.48 per 64-query pass).
-    static const double kCostWS0 = lb_tunable("LB_COSTWS0_US", 270) * 1e-3, kCostWS = lb_tunable("LB_COSTWS_US", 535) * 1e-3;
-    int wsplit = split;
-    // (only with enough tiles to fill the chip a few times over: 512 workgroups run at once, and at 125k visible rows
-    // x 256 queries the 978 tall tiles came out 5 % behind the 3908 smaller ones)
-    const bool tall_fills = (n / 256) * tiles_w >= 2048;
-    if (nsplit && tile64 && split == 0 && tall_fills && kCostWS0 + kCostWS * tiles_w < c64) {
-        use_narrow = false;
-        nsplit = false;
-        wsplit = 2;
-    }
-    if (nsplit || wsplit == 2) gamma = 1.05f * ((float)(3 * h->dim / 16 + 24) * u24 + 3.0f * 3.8146973e-6f); // as the split image mode
-    // the split contraction beyond the narrow tiles runs on the 256-row tile (kernels_gemm_tall.hip): corpus image
-    // (wsplit 1) or f32 corpus split in registers (wsplit 2), queries as the split image either way
-    static const int tall_on = lb_tunable("LB_TALL", 1);
-    const bool use_tall = !use_narrow && wsplit != 0 && tall_on && narrow_ok;
-    if (use_tall && wsplit == 2) split_queries();
     // Up to 64 queries on the narrow split tiles the sample and its thresholds ride INSIDE the candidate launch (FUSED
     // in kernels_gemm_narrow.hip: 19-34 us of sample + 13 us of threshold kernel off the critical path).
     static const int fused_max = lb_tunable("LB_FUSED_SAMPLE_MAXQ", 32); // (33-64 queries, the 64-query tile: measured level)
@@ -650,6 +704,8 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     if (metric == LB_METRIC_COSINE && !norm_riders) launch_query_norms(order, d_q, nullptr, nq, h->dim, w->d_qna, s);
     static const bool sample_narrow = lb_tunable("LB_TALL_SAMPLE_NARROW", 1) != 0;
     auto candidates = [&](int64_t b, int64_t e, const uint32_t *rowmap, bool boot) {
+        if (w->ctx && !boot) LB_HIP(hipStreamSynchronize(s)); // a cancellable call waits for the work in front of every corpus pass
+        ctx_check(w->ctx);
         ProfScope p(w, s, prof, 0);
         if (use_narrow)
             launch_gemm_filter_narrow(metric, gx, h->d_norm2, h->d_rnorm, b, e, h->dim, gq, nq, mask, rowmap,
@@ -774,6 +830,16 @@ __global__ void fill_empty_kernel(float *dist, int64_t *lab, int64_t n)
         lab[i] = -1;
     }
 }
+} // namespace
+namespace lb {
+// the canonical "no result" block: label -1 / distance FLT_MAX (also what comm.hip ships for a failed shard)
+void launch_fill_empty(float *dist, int64_t *lab, int64_t n, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(fill_empty_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dist, lab, n);
+}
+} // namespace lb
+namespace {
 
 // candidate rows (int64 positions) -> u32 row map for the mapped scan; rows outside the corpus read row 0
 // and are overwritten afterwards
@@ -977,9 +1043,9 @@ void finish_add(lb_gpu_index *h, int64_t n, const int64_t *ids_src, bool ids_on_
     h->n += n; // the rows are committed from here on: nothing below may fail the call (a retry would duplicate them)
     try {
         sync_split_image(h);
-    } catch (const HipErr &) { // no room for the bf16 mirror: searches use the f32 contraction
+    } catch (const HipErr &) { // no room for the bf16 mirror: back to the default routes
         (void)hipGetLastError();
-        h->cand_mode.store(0);
+        h->cand_mode.store(LB_CAND_AUTO);
         if (h->d_Xs) { (void)hipFree(h->d_Xs); h->d_Xs = nullptr; h->xs_rows = 0; }
     }
     try {
@@ -1107,6 +1173,8 @@ const char *lb_gpu_status_string(int status)
     case LB_ERR_HIP: return "HIP runtime error";
     case LB_ERR_OOM: return "out of device memory";
     case LB_ERR_UNSUPPORTED: return "unsupported configuration";
+    case LB_ERR_CANCELLED: return "context canceled";
+    case LB_ERR_DEADLINE: return "context deadline exceeded";
     default: return "internal error";
     }
 }
@@ -1188,10 +1256,10 @@ int lb_gpu_index_set_order(lb_gpu_index *h, int order)
 
 int lb_gpu_index_set_candidate_mode(lb_gpu_index *h, int mode)
 {
-    if (!h || (mode != 0 && mode != 1 && mode != 2)) return LB_ERR_INVALID_ARG;
+    if (!h || mode < LB_CAND_F32_MFMA || mode > LB_CAND_AUTO) return LB_ERR_INVALID_ARG;
     std::unique_lock<std::shared_mutex> g(h->mu);
     if (h->closed) return LB_ERR_CLOSED;
-    if (mode != 0 && h->dim % 32 != 0) {
+    if ((mode == LB_CAND_SPLIT_BF16 || mode == LB_CAND_SPLIT_BF16_INREG) && h->dim % 32 != 0) {
         h->set_error("split-bf16 candidates need dim %% 32 == 0 (dim = %d)", h->dim);
         return LB_ERR_UNSUPPORTED;
     }
@@ -1201,7 +1269,7 @@ int lb_gpu_index_set_candidate_mode(lb_gpu_index *h, int mode)
         if (mode == 1) sync_split_image(h);
         else if (h->d_Xs) { (void)hipFree(h->d_Xs); h->d_Xs = nullptr; h->xs_rows = 0; }
     } catch (const HipErr &e) {
-        h->cand_mode.store(0);
+        h->cand_mode.store(LB_CAND_AUTO);
         return fail_hip(h, e);
     }
     return LB_OK;
@@ -1209,6 +1277,7 @@ int lb_gpu_index_set_candidate_mode(lb_gpu_index *h, int mode)
 
 int64_t lb_gpu_index_ntotal(const lb_gpu_index *h) { return h ? h->n : 0; }
 int lb_gpu_index_dim(const lb_gpu_index *h) { return h ? h->dim : 0; }
+int lb_gpu_index_device(const lb_gpu_index *h) { return h ? h->device : -1; }
 
 int lb_gpu_index_reserve(lb_gpu_index *h, int64_t n_total)
 {
@@ -1361,49 +1430,91 @@ int lb_simd_and_bytes(int device, uint8_t *dst, const uint8_t *src, int64_t n)
 
 int64_t lb_gpu_index_last_fallbacks(const lb_gpu_index *h) { return h ? h->last_fallbacks.load() : 0; }
 
-int lb_gpu_index_search_device(lb_gpu_index *h, int64_t nq, const float *d_queries, int k, float *d_dist,
-                               int64_t *d_labels, void *stream)
+int lb_gpu_index_search_device_ctx(lb_gpu_index *h, int64_t nq, const float *d_queries, int k, float *d_dist,
+                                   int64_t *d_labels, void *stream, const lb_cancel *ctx)
 {
     if (!h || nq < 0 || k <= 0 || (nq > 0 && (!d_queries || !d_dist || !d_labels))) return LB_ERR_INVALID_ARG;
     std::shared_lock<std::shared_mutex> g(h->mu);
     if (h->closed) { h->set_error("index is closed"); return LB_ERR_CLOSED; }
     if (nq == 0) return LB_OK;
-    if (k > 2048) { h->set_error("k=%d exceeds the supported maximum 2048", k); return LB_ERR_UNSUPPORTED; }
+    if (k > LB_MAX_K) { h->set_error("k=%d exceeds the supported maximum %d", k, LB_MAX_K); return LB_ERR_UNSUPPORTED; }
+    if (const int st = ctx_state(ctx)) { h->set_error(st == LB_ERR_CANCELLED ? "context canceled" : "context deadline exceeded"); return st; }
+#ifdef LB_DIAG
+    if (g_search_fail_next.exchange(0) != 0) { h->set_error("search failure forced by lb_debug_search_fail_next"); return LB_ERR_INTERNAL; }
+#endif
     std::unique_ptr<Workspace> w;
+    hipStream_t s = nullptr;
     try {
         LB_HIP(hipSetDevice(h->device));
         int kc;
         uint32_t cap;
         cand_geometry(k, kc, cap);
         w = acquire_ws(h, (int)std::min<int64_t>(nq, kMaxBatch), cap);
-        hipStream_t s = stream ? (hipStream_t)stream : w->stream;
+        s = stream ? (hipStream_t)stream : w->stream;
         const bool prof = h->profiling.load() != 0;
         w->ev_used = 0;
+        w->ctx = ctx;
         int64_t fallbacks = 0;
         if (h->n == 0) {
-            const int64_t tot = nq * k;
-            hipLaunchKernelGGL(fill_empty_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, d_dist,
-                               d_labels, tot);
+            launch_fill_empty(d_dist, d_labels, nq * k, s);
         } else {
             for (int64_t q0 = 0; q0 < nq; q0 += kMaxBatch) {
                 const int bq = (int)std::min<int64_t>(kMaxBatch, nq - q0);
                 int rc = search_batch_device(h, w.get(), s, bq, d_queries + (size_t)q0 * h->dim, k,
                                              d_dist + (size_t)q0 * k, d_labels + (size_t)q0 * k, kc, prof, fallbacks);
-                if (rc != LB_OK) { release_ws(h, std::move(w)); return rc; }
+                if (rc != LB_OK) { w->ctx = nullptr; release_ws(h, std::move(w)); return rc; }
             }
         }
         LB_LAUNCH_CHECK();
         LB_HIP(hipStreamSynchronize(s));
         h->last_fallbacks.store(fallbacks);
         if (prof) finish_profile(h, w.get());
+        w->ctx = nullptr;
         release_ws(h, std::move(w));
     } catch (const HipErr &e) {
         return fail_hip(h, e);
+    } catch (const CtxErr &c) {
+        // stop enqueuing, let what is already on the stream finish (it writes into the caller's buffers), report.
+        // The output buffers hold unspecified values, as after any failed call.
+        (void)hipStreamSynchronize(s);
+        (void)hipGetLastError();
+        if (w) {
+            w->ctx = nullptr;
+            w->ev_used = 0;
+            // a fused launch may have been skipped between its host-side bookkeeping and the device: re-base the ticket
+            (void)hipMemsetAsync(w->d_fsync, 0, sizeof(uint32_t), s);
+            (void)hipStreamSynchronize(s);
+            w->fs_base = 0;
+            release_ws(h, std::move(w));
+        }
+        h->set_error(c.code == LB_ERR_CANCELLED ? "context canceled" : "context deadline exceeded");
+        return c.code;
     }
     return LB_OK;
 }
 
-int lb_gpu_index_search(lb_gpu_index *h, int64_t nq, const float *queries, int k, float *dist, int64_t *labels)
+int lb_gpu_index_search_device(lb_gpu_index *h, int64_t nq, const float *d_queries, int k, float *d_dist,
+                               int64_t *d_labels, void *stream)
+{
+    return lb_gpu_index_search_device_ctx(h, nq, d_queries, k, d_dist, d_labels, stream, nullptr);
+}
+
+lb_cancel *lb_cancel_new(void) { return new (std::nothrow) lb_cancel(); }
+void lb_cancel_free(lb_cancel *c) { delete c; }
+void lb_cancel_fire(lb_cancel *c) { if (c) c->fired.store(1); }
+void lb_cancel_set_deadline_ms(lb_cancel *c, int64_t ms_from_now)
+{
+    if (!c) return;
+    if (ms_from_now < 0) { c->deadline_ns.store(0); return; }
+    const long long now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    long long d = now + (long long)ms_from_now * 1000000ll;
+    if (d == 0) d = 1;
+    c->deadline_ns.store(d);
+}
+int lb_cancel_state(const lb_cancel *c) { return ctx_state(c); }
+
+int lb_gpu_index_search_ctx(lb_gpu_index *h, int64_t nq, const float *queries, int k, float *dist, int64_t *labels,
+                            const lb_cancel *ctx)
 {
     if (!h || nq < 0 || k <= 0 || (nq > 0 && (!queries || !dist || !labels))) return LB_ERR_INVALID_ARG;
     if (nq == 0) return LB_OK;
@@ -1411,6 +1522,9 @@ int lb_gpu_index_search(lb_gpu_index *h, int64_t nq, const float *queries, int k
         std::shared_lock<std::shared_mutex> g(h->mu);
         if (h->closed) { h->set_error("index is closed"); return LB_ERR_CLOSED; }
     }
+    // (before any staging is sized: nq * k * 12 bytes of pinned + device memory per call)
+    if (k > LB_MAX_K) { h->set_error("k=%d exceeds the supported maximum %d", k, LB_MAX_K); return LB_ERR_UNSUPPORTED; }
+    if (nq > ((int64_t)1 << 40) / ((int64_t)h->dim + 3 * (int64_t)k)) { h->set_error("batch too large"); return LB_ERR_INVALID_ARG; }
     // borrowed host buffers -> pooled pinned slab -> HBM (async DMA on the call's own stream), and back
     const size_t qb = (size_t)nq * h->dim * sizeof(float);
     const size_t db = (((size_t)nq * k * sizeof(float)) + 15) & ~(size_t)15;
@@ -1440,9 +1554,9 @@ int lb_gpu_index_search(lb_gpu_index *h, int64_t nq, const float *queries, int k
         char *hb = static_cast<char *>(st->h_buf), *dbuf = static_cast<char *>(st->d_buf);
         std::memcpy(hb + qoff, queries, qb);
         LB_HIP(hipMemcpyAsync(dbuf + qoff, hb + qoff, qb, hipMemcpyHostToDevice, st->stream));
-        rc = lb_gpu_index_search_device(h, nq, reinterpret_cast<const float *>(dbuf + qoff), k,
-                                        reinterpret_cast<float *>(dbuf + doff), reinterpret_cast<int64_t *>(dbuf + loff),
-                                        st->stream);
+        rc = lb_gpu_index_search_device_ctx(h, nq, reinterpret_cast<const float *>(dbuf + qoff), k,
+                                            reinterpret_cast<float *>(dbuf + doff), reinterpret_cast<int64_t *>(dbuf + loff),
+                                            st->stream, ctx);
         if (rc == LB_OK) {
             LB_HIP(hipMemcpyAsync(hb + doff, dbuf + doff, db + lb_, hipMemcpyDeviceToHost, st->stream));
             LB_HIP(hipStreamSynchronize(st->stream));
@@ -1453,8 +1567,16 @@ int lb_gpu_index_search(lb_gpu_index *h, int64_t nq, const float *queries, int k
         if (h->hs_free.size() < 8) h->hs_free.push_back(std::move(st));
     } catch (const HipErr &e) {
         rc = fail_hip(h, e);
+    } catch (...) {
+        h->set_error("internal error (exception)");
+        rc = LB_ERR_INTERNAL;
     }
     return rc;
+}
+
+int lb_gpu_index_search(lb_gpu_index *h, int64_t nq, const float *queries, int k, float *dist, int64_t *labels)
+{
+    return lb_gpu_index_search_ctx(h, nq, queries, k, dist, labels, nullptr);
 }
 
 int lb_gpu_index_set_profiling(lb_gpu_index *h, int enable)
@@ -1473,10 +1595,14 @@ int lb_gpu_index_last_timing(const lb_gpu_index *hc, float ms[5], int n_launch[5
     return LB_OK;
 }
 
+#ifdef LB_DIAG
+// Diagnostic build only (python -m longbow_amd.build --diag -> liblongbow_gpu_diag.so; the tests that force a
+// fallback path load that library): none of these symbols exists in liblongbow_gpu.so.
 // Test hooks (both settings are exact; they only choose between two schedules / expose host logic).
 void lb_debug_set_sample_tau(int v) { g_sample_tau.store(v); } // 0: classic bootstrap schedule only
 void lb_debug_vmm_fail_next(int v) { g_vmm_fail_next.store(v); } // the next in-place growth is refused (-> hipMalloc + copy)
 void lb_debug_fused_fail_next(int v) { g_fused_fail_next.store(v); } // the next fused sample launch counts as timed out (-> exact path for the batch)
+void lb_debug_search_fail_next(int v) { g_search_fail_next.store(v); } // the next search in this process returns LB_ERR_INTERNAL
 void lb_debug_set_add_register_min(long long bytes) { g_add_register_min.store(bytes); } // ingest A/B (tools/bench_add.py)
 // host-only: the sampled-threshold plan for a view of n rows (tests check its invariants without a GPU);
 // out = {on, span, count, m}
@@ -1488,9 +1614,7 @@ void lb_debug_sample_plan(long long n, int keep, unsigned cap, unsigned count_ma
     out[2] = p.count;
     out[3] = p.m;
 }
-#ifdef LB_DIAG
-// Diagnostic build only (python -m longbow_amd.build --diag): timing-only ablations whose results are
-// wrong by design, the in-kernel clock probe, staging A/B.  None of this exists in liblongbow_gpu.so.
+// timing-only ablations whose results are wrong by design, the in-kernel clock probe, staging A/B
 void lb_debug_set_gemm_ablation(int v) { lb::g_gemm_ablation = v; }
 void lb_debug_set_gemm_glds(int v) { lb::g_gemm_glds = v; }
 void lb_debug_set_adc_ablation(int v) { lb::g_adc_ablation = v; }
@@ -1609,6 +1733,62 @@ int lb_simd_distance_batch_flat(int device, int metric, int order, const float *
         LB_HIP(hipMemcpy(results, dr.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     } catch (const HipErr &e) {
         return e.e == hipErrorOutOfMemory ? LB_ERR_OOM : LB_ERR_HIP;
+    }
+    return LB_OK;
+}
+
+// simd.EuclideanDistanceBatch / CosineDistanceBatch / DotProductBatch over [][]float32
+// (internal/simd/batch_operations.go:29-60,131-157; per-vector rules in include/longbow_gpu.h)
+int lb_simd_distance_batch(int device, int metric, int order, const float *query, int dims, const float *const *vectors,
+                           const int *lens, int64_t n, float *results)
+{
+    if (metric < 0 || metric > 2 || (order != 0 && order != 1) || n < 0 || dims < 0) return LB_ERR_INVALID_ARG;
+    if (n == 0) return LB_OK; // batch_operations.go:33-35,132-134
+    if (!vectors || !lens || !results || (dims > 0 && !query)) return LB_ERR_INVALID_ARG;
+    if (dims > LB_MAX_DIM) return LB_ERR_UNSUPPORTED;
+    // which vectors are scored
+    std::vector<int64_t> live;
+    try {
+        live.reserve((size_t)n);
+        for (int64_t i = 0; i < n; i++) {
+            const bool ok = vectors[i] != nullptr && lens[i] == dims;
+            if (metric == LB_METRIC_EUCLIDEAN) {
+                if (ok) live.push_back(i);
+                else results[i] = FLT_MAX; // math.MaxFloat32 (batch_operations.go:39-42,51)
+            } else {
+                if (vectors[i] == nullptr) continue; // skipped: results[i] keeps the caller's value (simd.go:243-245,256-258)
+                if (lens[i] != dims) break;          // the loop returns its error here and the wrapper swallows it (:140,155)
+                live.push_back(i);
+            }
+        }
+    } catch (...) {
+        return LB_ERR_OOM;
+    }
+    const int64_t m = (int64_t)live.size();
+    if (m == 0) return LB_OK;
+    if (dims == 0) { // len 0: 0 (Euclidean, dot) / 1.0 (cosine)  (simd.go:131-163)
+        for (int64_t i : live) results[i] = metric == LB_METRIC_COSINE ? 1.0f : 0.0f;
+        return LB_OK;
+    }
+    if (!device_ok(device)) return LB_ERR_NO_DEVICE;
+    try {
+        LB_HIP(hipSetDevice(device));
+        const size_t row = (size_t)dims * 4;
+        Lease hx(device, (size_t)m * row, true), dq(device, row), dx(device, (size_t)m * row), dr(device, (size_t)m * 4),
+            hr(device, (size_t)m * 4, true);
+        for (int64_t j = 0; j < m; j++) std::memcpy(hx.as<char>() + (size_t)j * row, vectors[live[(size_t)j]], row);
+        LB_HIP(hipMemcpy(dq.p, query, row, hipMemcpyHostToDevice));
+        LB_HIP(hipMemcpy(dx.p, hx.p, (size_t)m * row, hipMemcpyHostToDevice));
+        const int rc = lb_simd_distance_batch_flat_device(device, metric, order, dq.as<float>(), dx.as<float>(), m, dims,
+                                                          dr.as<float>(), nullptr);
+        if (rc != LB_OK) return rc;
+        LB_HIP(hipMemcpy(hr.p, dr.p, (size_t)m * 4, hipMemcpyDeviceToHost));
+        for (int64_t j = 0; j < m; j++) results[live[(size_t)j]] = hr.as<float>()[j];
+    } catch (const HipErr &e) {
+        (void)hipGetLastError();
+        return e.e == hipErrorOutOfMemory ? LB_ERR_OOM : LB_ERR_HIP;
+    } catch (...) {
+        return LB_ERR_INTERNAL;
     }
     return LB_OK;
 }

@@ -248,6 +248,8 @@ void launch_emit_lists(CandState cs, const int *qsel, int nsel, int k, const int
                        float *out_dist, int64_t *out_labels, uint32_t *flags_host, hipStream_t s);
 
 void launch_init_cand(CandState cs, const int *qsel, int nsel, hipStream_t s);
+// dist[0..n) = FLT_MAX, lab[0..n) = -1 (index.hip)
+void launch_fill_empty(float *dist, int64_t *lab, int64_t n, hipStream_t s);
 
 // shard s's [nq][k] blocks start at dist_in + s*dist_stride and lab_in + s*lab_stride (elements)
 void launch_merge_topk(int nshards, int64_t nq, int k, const float *dist_in, const int64_t *lab_in,

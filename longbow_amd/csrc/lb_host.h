@@ -8,6 +8,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <chrono>
 #include <cstddef>
 #include <cstdint>
 #include <mutex>
@@ -147,6 +149,37 @@ struct Lease {
     template <typename T>
     T *as() const { return static_cast<T *>(p); }
 };
+
+} // namespace lb
+
+// context.Context's cancellation half for ONE call (include/longbow_gpu.h: lb_cancel_*).  The reference checks
+// ctx.Err() every 1000 rows of its scan (internal/store/adaptive_index.go:182); here the host checks before every
+// kernel launch of a search (a launch covers at most one pass over <= 2.5M rows / one PQ query), stops enqueuing,
+// drains the stream and returns LB_ERR_CANCELLED / LB_ERR_DEADLINE.
+struct lb_cancel {
+    std::atomic<int> fired{0};
+    std::atomic<long long> deadline_ns{0}; // steady clock; 0 = none
+};
+
+namespace lb {
+
+struct CtxErr {
+    int code;
+};
+inline int ctx_state(const lb_cancel *c)
+{
+    if (!c) return 0;
+    if (c->fired.load(std::memory_order_relaxed)) return 8; // LB_ERR_CANCELLED
+    const long long d = c->deadline_ns.load(std::memory_order_relaxed);
+    if (d != 0 && std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() >= d)
+        return 9; // LB_ERR_DEADLINE
+    return 0;
+}
+inline void ctx_check(const lb_cancel *c)
+{
+    const int st = ctx_state(c);
+    if (st) throw CtxErr{st};
+}
 
 inline bool device_ok(int device)
 {

@@ -49,6 +49,7 @@ struct lb_gpu_pq {
     std::string last_error;
     // instrumentation (bench.py): HIP events around the main code pass and the whole search of the last query
     std::atomic<int> profiling{0};
+    std::atomic<int> prefilter{1}; // 0 = exact f32-table pass only (lb_gpu_pq_set_prefilter; both are exact)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float prof_ms[2] = {0.f, 0.f};
     void set_error(const char *fmt, ...)
@@ -181,12 +182,9 @@ void release_scratch(lb_gpu_pq *p, std::unique_ptr<PqScratch> sc)
     if (p->sc_free.size() < 4) p->sc_free.push_back(std::move(sc));
 }
 
-std::atomic<int> g_adc_prefilter{1}; // test hook: 0 = exact f32 pass only (both are exact)
 } // namespace
 
 extern "C" {
-
-void lb_debug_set_adc_prefilter(int v) { g_adc_prefilter.store(v); }
 
 lb_gpu_pq *lb_gpu_pq_new(int device, const uint8_t *blob, size_t len, int *out_status)
 {
@@ -495,11 +493,19 @@ int lb_gpu_pq_last_timing(const lb_gpu_pq *p, float ms[2])
 }
 
 // ---- search ----------------------------------------------------------------------------
-int lb_gpu_pq_search_device(lb_gpu_pq *p, int64_t nq, const float *d_queries, int k, float *d_dist,
-                            int64_t *d_labels, void *stream)
+int lb_gpu_pq_set_prefilter(lb_gpu_pq *p, int enable)
+{
+    if (!p) return LB_ERR_INVALID_ARG;
+    p->prefilter.store(enable ? 1 : 0);
+    return LB_OK;
+}
+
+int lb_gpu_pq_search_device_ctx(lb_gpu_pq *p, int64_t nq, const float *d_queries, int k, float *d_dist,
+                                int64_t *d_labels, void *stream, const lb_cancel *ctx)
 {
     if (!p || nq < 0 || k <= 0 || (nq > 0 && (!d_queries || !d_dist || !d_labels))) return LB_ERR_INVALID_ARG;
     if (nq == 0) return LB_OK;
+    if (const int st = ctx_state(ctx)) { p->set_error(st == LB_ERR_CANCELLED ? "context canceled" : "context deadline exceeded"); return st; }
     if (k > 4096) { p->set_error("k=%d exceeds the supported maximum 4096", k); return LB_ERR_UNSUPPORTED; }
     if (nq > 65536) { p->set_error("nq=%lld exceeds 65536 queries per call", (long long)nq); return LB_ERR_UNSUPPORTED; }
     std::shared_lock<std::shared_mutex> g(p->mu);
@@ -533,7 +539,7 @@ int lb_gpu_pq_search_device(lb_gpu_pq *p, int64_t nq, const float *d_queries, in
         }
         scp = acquire_scratch(p, nqi, cap, samp_count);
         PqScratch &sc = *scp;
-        const bool prefilter = samp_count != 0 && g_adc_prefilter.load() != 0;
+        const bool prefilter = samp_count != 0 && p->prefilter.load() != 0;
         const bool prof = p->profiling.load() != 0;
         if (prof) {
             for (auto &e : p->ev)
@@ -588,7 +594,17 @@ int lb_gpu_pq_search_device(lb_gpu_pq *p, int64_t nq, const float *d_queries, in
             }
             if (p->n == 0) launch_emit_lists(sc.cs, sc.d_slots + q, 1, k, nullptr, d_dist, d_labels, nullptr, s);
         };
-        for (int q = 0; q < nqi; q++) scan_query(q, 0);
+        for (int q = 0; q < nqi; q++) {
+            if (ctx && q > 0) { // a cancellable call waits for each query's pass before it enqueues the next (~10 us each)
+                LBP_HIP(hipStreamSynchronize(s));
+                if (const int st = ctx_state(ctx)) {
+                    release_scratch(p, std::move(scp));
+                    p->set_error(st == LB_ERR_CANCELLED ? "context canceled" : "context deadline exceeded");
+                    return st;
+                }
+            }
+            scan_query(q, 0);
+        }
         auto read_flags = [&]() {
             LBP_HIP(hipMemcpyAsync(sc.h_flags, sc.cs.flags, (size_t)nqi * 4, hipMemcpyDeviceToHost, s));
             LBP_HIP(hipStreamSynchronize(s));
@@ -620,16 +636,30 @@ int lb_gpu_pq_search_device(lb_gpu_pq *p, int64_t nq, const float *d_queries, in
     return LB_OK;
 }
 
+int lb_gpu_pq_search_device(lb_gpu_pq *p, int64_t nq, const float *d_queries, int k, float *d_dist,
+                            int64_t *d_labels, void *stream)
+{
+    return lb_gpu_pq_search_device_ctx(p, nq, d_queries, k, d_dist, d_labels, stream, nullptr);
+}
+
 int lb_gpu_pq_search(lb_gpu_pq *p, int64_t nq, const float *queries, int k, float *dist, int64_t *labels)
+{
+    return lb_gpu_pq_search_ctx(p, nq, queries, k, dist, labels, nullptr);
+}
+
+int lb_gpu_pq_search_ctx(lb_gpu_pq *p, int64_t nq, const float *queries, int k, float *dist, int64_t *labels,
+                         const lb_cancel *ctx)
 {
     if (!p || nq < 0 || k <= 0 || (nq > 0 && (!queries || !dist || !labels))) return LB_ERR_INVALID_ARG;
     if (nq == 0) return LB_OK;
+    if (k > 4096) { p->set_error("k=%d exceeds the supported maximum 4096", k); return LB_ERR_UNSUPPORTED; }
+    if (nq > 65536) { p->set_error("nq=%lld exceeds 65536 queries per call", (long long)nq); return LB_ERR_UNSUPPORTED; }
     int rc = LB_OK;
     try {
         LBP_HIP(hipSetDevice(p->device));
         Lease dq(p->device, (size_t)nq * p->dims * 4), dd(p->device, (size_t)nq * k * 4), dl(p->device, (size_t)nq * k * 8);
         LBP_HIP(hipMemcpy(dq.p, queries, (size_t)nq * p->dims * 4, hipMemcpyHostToDevice));
-        rc = lb_gpu_pq_search_device(p, nq, dq.as<float>(), k, dd.as<float>(), dl.as<int64_t>(), nullptr);
+        rc = lb_gpu_pq_search_device_ctx(p, nq, dq.as<float>(), k, dd.as<float>(), dl.as<int64_t>(), nullptr, ctx);
         if (rc == LB_OK) {
             LBP_HIP(hipMemcpy(dist, dd.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
             LBP_HIP(hipMemcpy(labels, dl.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost));

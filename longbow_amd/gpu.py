@@ -10,7 +10,7 @@ import threading
 import numpy as np
 
 from . import _lib
-from ._lib import GPUNotAvailable, LongbowGPUError  # noqa: F401
+from ._lib import Canceled, DeadlineExceeded, GPUNotAvailable, LongbowGPUError  # noqa: F401
 from .simd import MetricType, Order
 
 ErrGPUNotAvailable = GPUNotAvailable
@@ -23,13 +23,48 @@ class GPUConfig:
         self.Metric = Metric
 
 
+class Cancel:
+    """The cancellation half of a context.Context for ONE search call (lb_cancel): fire() from any thread, or
+    set a deadline; pass as ctx= to Search / SearchBatch / search_device."""
+
+    def __init__(self, deadline_ms=None, lib=None):
+        self._lib = lib or _lib.load()
+        self._h = C.c_void_p(self._lib.lb_cancel_new())
+        if deadline_ms is not None:
+            self.set_deadline_ms(deadline_ms)
+
+    def fire(self):
+        self._lib.lb_cancel_fire(self._h)
+
+    def set_deadline_ms(self, ms):
+        self._lib.lb_cancel_set_deadline_ms(self._h, int(ms))
+
+    @property
+    def state(self):
+        return int(self._lib.lb_cancel_state(self._h))
+
+    def close(self):
+        if self._h:
+            self._lib.lb_cancel_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Index:
     """gpu.Index backed by lb_gpu_index (HIP)."""
 
-    def __init__(self, cfg: GPUConfig):
+    def __init__(self, cfg: GPUConfig, lib=None):
         if cfg.Dimension <= 0:
             raise ValueError(f"dimension must be positive, got {cfg.Dimension}")  # faiss_gpu.go:46-48
-        lib = _lib.require_gpu(cfg.DeviceID)
+        if lib is None:
+            lib = _lib.require_gpu(cfg.DeviceID)
+        elif lib.lb_gpu_device_count() <= cfg.DeviceID:
+            raise GPUNotAvailable(3, f"device {cfg.DeviceID} requested")
         st = C.c_int(0)
         h = lib.lb_gpu_index_new(cfg.DeviceID, cfg.Dimension, int(cfg.Metric), C.byref(st))
         if not h:
@@ -56,15 +91,15 @@ class Index:
             if ids.size != n:
                 raise ValueError(f"id count {ids.size} does not match vector count {n}")
             idp = ids.ctypes.data
-        _lib.check(self._lib.lb_gpu_index_add(self._h, n, vectors.ctypes.data, idp), self._h)
+        _lib.check(self._lib.lb_gpu_index_add(self._h, n, vectors.ctypes.data, idp), self._h, lib=self._lib)
 
-    def Search(self, vector, k):
+    def Search(self, vector, k, ctx=None):
         """Search(vector []float32, k int) (ids []int64, distances []float32, err)  (faiss_gpu.go:107-144)"""
         self._live()
         vector = np.ascontiguousarray(vector, np.float32).reshape(-1)
         if vector.size != self.dim:
             raise ValueError(f"query vector dimension {vector.size} does not match index dimension {self.dim}")
-        ids, dist = self.SearchBatch(vector[None, :], k)
+        ids, dist = self.SearchBatch(vector[None, :], k, ctx=ctx)
         return ids[0], dist[0]
 
     def Close(self):
@@ -77,7 +112,7 @@ class Index:
             self._lib.lb_gpu_index_free(h)
 
     # -- superset ----------------------------------------------------------------
-    def SearchBatch(self, queries, k):
+    def SearchBatch(self, queries, k, ctx=None):
         self._live()
         queries = np.ascontiguousarray(queries, np.float32)
         if queries.ndim != 2 or queries.shape[1] != self.dim:
@@ -85,8 +120,8 @@ class Index:
         nq = queries.shape[0]
         dist = np.empty((nq, k), np.float32)
         labels = np.empty((nq, k), np.int64)
-        _lib.check(self._lib.lb_gpu_index_search(self._h, nq, queries.ctypes.data, k, dist.ctypes.data,
-                                                 labels.ctypes.data), self._h)
+        _lib.check(self._lib.lb_gpu_index_search_ctx(self._h, nq, queries.ctypes.data, k, dist.ctypes.data,
+                                                     labels.ctypes.data, ctx._h if ctx is not None else None), self._h, lib=self._lib)
         return labels, dist
 
     def Rerank(self, query, rows, order=Order.Unroll4, want_score=True):
@@ -102,43 +137,44 @@ class Index:
         score = np.empty(rows.size, np.float32) if want_score else None
         _lib.check(self._lib.lb_gpu_index_rerank(self._h, query.ctypes.data, rows.ctypes.data, rows.size,
                                                  -1 if order is None else int(Order(order)), dist.ctypes.data,
-                                                 score.ctypes.data if want_score else None), self._h)
+                                                 score.ctypes.data if want_score else None), self._h, lib=self._lib)
         return (dist, score) if want_score else dist
 
     def rerank_device(self, d_query, d_rows, n, d_dist, d_score=None, order=Order.Unroll4, stream=None):
         self._live()
         _lib.check(self._lib.lb_gpu_index_rerank_device(self._h, d_query, d_rows, n, -1 if order is None else int(Order(order)),
-                                                        d_dist, d_score, stream), self._h)
+                                                        d_dist, d_score, stream), self._h, lib=self._lib)
 
     def add_device(self, n, d_vectors, d_ids=None):
         self._live()
-        _lib.check(self._lib.lb_gpu_index_add_device(self._h, n, d_vectors, d_ids), self._h)
+        _lib.check(self._lib.lb_gpu_index_add_device(self._h, n, d_vectors, d_ids), self._h, lib=self._lib)
 
-    def search_device(self, nq, d_queries, k, d_dist, d_labels, stream=None):
+    def search_device(self, nq, d_queries, k, d_dist, d_labels, stream=None, ctx=None):
         self._live()
-        _lib.check(self._lib.lb_gpu_index_search_device(self._h, nq, d_queries, k, d_dist, d_labels, stream),
-                   self._h)
+        _lib.check(self._lib.lb_gpu_index_search_device_ctx(self._h, nq, d_queries, k, d_dist, d_labels, stream,
+                                                            ctx._h if ctx is not None else None), self._h, lib=self._lib)
 
     def reserve(self, n_total):
         self._live()
-        _lib.check(self._lib.lb_gpu_index_reserve(self._h, n_total), self._h)
+        _lib.check(self._lib.lb_gpu_index_reserve(self._h, n_total), self._h, lib=self._lib)
 
     def set_order(self, order):
         self._live()
-        _lib.check(self._lib.lb_gpu_index_set_order(self._h, int(Order(order))), self._h)
+        _lib.check(self._lib.lb_gpu_index_set_order(self._h, int(Order(order))), self._h, lib=self._lib)
 
     def set_candidate_mode(self, mode):
-        """0 = f32 MFMA candidates (default), 1 = split-bf16 (3 x bf16 MFMA) candidates; results identical"""
+        """lb_candidate_mode: 3 = AUTO (default: cheapest exact route), 0 = strict f32 MFMA beyond 384 queries,
+        1 = split-bf16 corpus image, 2 = split in registers; results identical in every mode"""
         self._live()
-        _lib.check(self._lib.lb_gpu_index_set_candidate_mode(self._h, int(mode)), self._h)
+        _lib.check(self._lib.lb_gpu_index_set_candidate_mode(self._h, int(mode)), self._h, lib=self._lib)
 
     def set_filter(self, mask):
         self._live()
         if mask is None:
-            _lib.check(self._lib.lb_gpu_index_set_filter(self._h, None, 0), self._h)
+            _lib.check(self._lib.lb_gpu_index_set_filter(self._h, None, 0), self._h, lib=self._lib)
             return
         mask = np.ascontiguousarray(mask, np.uint8)
-        _lib.check(self._lib.lb_gpu_index_set_filter(self._h, mask.ctypes.data, mask.size), self._h)
+        _lib.check(self._lib.lb_gpu_index_set_filter(self._h, mask.ctypes.data, mask.size), self._h, lib=self._lib)
 
     def filter_column(self, column, operator, value, validity=None, validity_offset=0, combine=False):
         """Evaluate `column OP value` on the device into the row mask (query.Filter semantics,
@@ -160,18 +196,18 @@ class Index:
                                                        vptr, validity_offset, 1 if combine else 0)
         else:
             raise TypeError(f"unsupported filter column type {column.dtype} (int64 / float32)")
-        _lib.check(rc, self._h)
+        _lib.check(rc, self._h, lib=self._lib)
 
     def set_profiling(self, on):
         self._live()
-        _lib.check(self._lib.lb_gpu_index_set_profiling(self._h, 1 if on else 0), self._h)
+        _lib.check(self._lib.lb_gpu_index_set_profiling(self._h, 1 if on else 0), self._h, lib=self._lib)
 
     def last_timing(self):
         """{class: (ms, launches)} of the last search: gemm, select, rerank, scan, total"""
         self._live()
         ms = (C.c_float * 5)()
         n = (C.c_int * 5)()
-        _lib.check(self._lib.lb_gpu_index_last_timing(self._h, ms, n), self._h)
+        _lib.check(self._lib.lb_gpu_index_last_timing(self._h, ms, n), self._h, lib=self._lib)
         names = ["gemm", "select", "rerank", "scan", "total"]
         return {names[i]: (float(ms[i]), int(n[i])) for i in range(5)}
 
@@ -207,6 +243,7 @@ def NewIndex():
     return NewIndexWithConfig(GPUConfig(DeviceID=0, Dimension=128))
 
 
-def NewIndexWithConfig(cfg: GPUConfig):
-    """gpu.NewIndexWithConfig (gpu_enabled.go:17-21).  Raises ErrGPUNotAvailable without a device."""
-    return Index(cfg)
+def NewIndexWithConfig(cfg: GPUConfig, lib=None):
+    """gpu.NewIndexWithConfig (gpu_enabled.go:17-21).  Raises ErrGPUNotAvailable without a device.
+    lib: another build of the library (tests: _lib.load_diag())."""
+    return Index(cfg, lib=lib)

@@ -222,14 +222,14 @@ class CommSearcher:
     transport "rccl": ncclCommInitRank inside liblongbow_gpu.so, the unique id travels over `group`;
     transport "host": the exchange is `group`'s all_gather between host buffers (gloo), staged by the library."""
 
-    def __init__(self, index, rank, world_size, device_index=0, transport="rccl", group=None):
+    def __init__(self, index, rank, world_size, device_index=0, transport="rccl", group=None, lib=None):
         import ctypes as C
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.C = torch, dist, C
         self.index, self.rank, self.world, self.group = index, rank, world_size, group
         self.device_index = device_index
-        lib = _lib.require_gpu(device_index)
+        lib = lib or _lib.require_gpu(device_index)
         self._lib = lib
         st = C.c_int(0)
         self._cb = None

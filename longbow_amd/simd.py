@@ -51,29 +51,56 @@ def EuclideanDistanceBatchFlat(query, flatVectors, numVectors, dims, results, or
     _batch_flat(MetricType.Euclidean, query, flatVectors, numVectors, dims, results, order, device)
 
 
+def _is_ragged(vectors):
+    """a Go [][]float32 with nil or odd-length members, as opposed to a rectangular 2-D array"""
+    if isinstance(vectors, np.ndarray) and vectors.dtype != object:
+        return False
+    return any(v is None for v in vectors) or len({len(v) for v in vectors if v is not None}) > 1
+
+
+def _batch_slices(metric, query, vectors, results, order, device):
+    """[][]float32 form through lb_simd_distance_batch: nil / length-mismatched members follow the reference's
+    per-vector rules (batch_operations.go:39-42,51; simd.go:241-267)."""
+    lib = _lib.require_gpu(device)
+    query = np.ascontiguousarray(query, np.float32).reshape(-1)
+    n = len(vectors)
+    keep = [None if v is None else np.ascontiguousarray(v, np.float32).reshape(-1) for v in vectors]
+    ptrs = (C.c_void_p * n)(*[None if v is None else v.ctypes.data for v in keep])
+    lens = (C.c_int * n)(*[0 if v is None else v.size for v in keep])
+    if results.dtype != np.float32 or not results.flags.c_contiguous:
+        raise ValueError("simd: results must be contiguous float32")
+    _lib.check(lib.lb_simd_distance_batch(device, int(metric), int(order), query.ctypes.data, query.size, ptrs, lens, n,
+                                          results.ctypes.data))
+
+
 def _batch(metric, query, vectors, results, order, device):
-    vectors = np.ascontiguousarray(vectors, np.float32)
-    if vectors.size == 0:
+    if len(vectors) == 0:
         return
-    n, dims = vectors.shape
-    if results.shape[0] < n:
+    if results.shape[0] < len(vectors):
         raise ValueError("simd: results slice too small")  # batch_operations.go:135-137
+    if _is_ragged(vectors) or np.asarray(query).size != np.asarray(vectors[0]).size:
+        return _batch_slices(metric, query, vectors, results, order, device)
+    vectors = np.ascontiguousarray(vectors, np.float32)
+    n, dims = vectors.shape
     _batch_flat(metric, query, vectors, n, dims, results[:n], order, device)
 
 
 def EuclideanDistanceBatch(query, vectors, results, order=Order.Seq, device=0):
-    vectors = np.ascontiguousarray(vectors, np.float32)
-    if vectors.shape[0] != results.shape[0]:
+    """simd.EuclideanDistanceBatch (batch_operations.go:29-60): `vectors` is a 2-D array or a list of vectors; a None
+    or length-mismatched member yields math.MaxFloat32 in its slot."""
+    if len(vectors) != results.shape[0]:
         raise ValueError("simd: vectors and results length mismatch")  # batch_operations.go:30-32
     _batch(MetricType.Euclidean, query, vectors, results, order, device)
 
 
 def CosineDistanceBatch(query, vectors, results, order=Order.Seq, device=0):
+    """simd.CosineDistanceBatch (batch_operations.go:131-143): None members are skipped (their slot keeps its value);
+    a length mismatch stops the batch at that member, error swallowed, as the reference does."""
     _batch(MetricType.Cosine, query, vectors, results, order, device)
 
 
 def DotProductBatch(query, vectors, results, order=Order.Seq, device=0):
-    """raw dot products (not negated), as simd.DotProductBatch"""
+    """raw dot products (not negated), as simd.DotProductBatch; member rules as CosineDistanceBatch"""
     _batch(MetricType.DotProduct, query, vectors, results, order, device)
 
 

@@ -12,11 +12,21 @@ def gpu_or_skip():
     return lib
 
 
-def new_index(dim, metric=0, order=0, device=0):
+def new_index(dim, metric=0, order=0, device=0, lib=None):
+    """lib: another build of the library -- tests that force a fallback path pass diag_lib()"""
     from longbow_amd import gpu
-    idx = gpu.NewIndexWithConfig(gpu.GPUConfig(DeviceID=device, Dimension=dim, Metric=metric))
+    idx = gpu.NewIndexWithConfig(gpu.GPUConfig(DeviceID=device, Dimension=dim, Metric=metric), lib=lib)
     idx.set_order(order)
     return idx
+
+
+def diag_lib():
+    """liblongbow_gpu_diag.so (-DLB_DIAG): the only build that exports the lb_debug_* test hooks"""
+    from longbow_amd import _lib
+    lib = _lib.load_diag()
+    if lib.lb_gpu_device_count() <= 0:
+        pytest.skip("no MI355X visible")
+    return lib
 
 
 def assert_same(gpu_labels, gpu_dist, oi, od, ctx=""):

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     src = open(os.path.join(ROOT, "include", "longbow_gpu.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(lb_(?:gpu|simd|flight)_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(lb_(?:gpu|simd|flight|cancel)_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_library_builds_and_exports_every_declared_symbol():
@@ -27,6 +27,11 @@ def test_library_builds_and_exports_every_declared_symbol():
     bound = {s[0] for s in _lib.SIGNATURES}
     assert bound == set(declared), (bound ^ set(declared))
     _lib.load()
+    # the product library carries no test hook / ablation switch: those live in the -DLB_DIAG build only
+    out = __import__("subprocess").run(["nm", "-D", "--defined-only", _lib.SO_PATH], capture_output=True, text=True).stdout
+    assert "lb_debug" not in out, [l for l in out.splitlines() if "lb_debug" in l]
+    build.build(diag=True)
+    _lib.load_diag()
 
 
 def test_version_and_status_strings():

@@ -134,16 +134,13 @@ def test_config4_100m_pq_adc(oracle):
     assert lib.lb_gpu_fill_uniform_device(0, Q.data_ptr(), Q.numel(), 42, 0, None) == 0
     od = torch.empty((4, K4), device="cuda")
     ol = torch.empty((4, K4), dtype=torch.int64, device="cuda")
-    lib.lb_debug_set_adc_prefilter.argtypes = [C.c_int]
     enc.search_device(4, Q.data_ptr(), K4, od.data_ptr(), ol.data_ptr())
     lab, dist = ol.cpu().numpy(), od.cpu().numpy()
     assert np.all(np.diff(dist, axis=1) >= 0) and lab.min() >= 0 and lab.max() < n
     assert all(len(np.unique(r)) == K4 for r in lab)
-    try:  # the exact full pass (no byte-table prefilter) returns the same lists
-        lib.lb_debug_set_adc_prefilter(0)
-        enc.search_device(2, Q.data_ptr(), K4, od.data_ptr(), ol.data_ptr())
-    finally:
-        lib.lb_debug_set_adc_prefilter(1)
+    enc.set_prefilter(False)  # the exact full pass (no byte-table prefilter) returns the same lists
+    enc.search_device(2, Q.data_ptr(), K4, od.data_ptr(), ol.data_ptr())
+    enc.set_prefilter(True)
     assert np.array_equal(ol.cpu().numpy()[:2], lab[:2]) and np.array_equal(od.cpu().numpy()[:2], dist[:2])
     # re-rank of the reported rows reproduces the reported distances (gathered codes, same arithmetic)
     Qh = Q.cpu().numpy()

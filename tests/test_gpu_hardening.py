@@ -1,0 +1,265 @@
+"""What a Go server links against: cancellation (the ctx of SearchVectors, internal/store/adaptive_index.go:182), the
+slice-of-slices batch entry with the reference's per-vector rules (internal/simd/batch_operations.go:29-60,131-157),
+argument caps that are checked before any staging is sized, the default candidate mode, and a communicator in which a
+failing rank still takes part in the exchange."""
+import os
+import socket
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from tests.gpu_util import assert_same, gpu_or_skip, new_index
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+FLT_MAX = np.finfo(F).max
+
+
+def test_default_mode_is_auto_and_large_batches_take_the_split_route(oracle):
+    """a fresh index answers 512 / 1024-query batches on the split contraction (no f32-MFMA cliff beyond 384 queries) with
+    results bit-equal to the strict mode and to the oracle; per-query cost must not jump between 384 and 512 queries"""
+    gpu_or_skip()
+    rng = np.random.default_rng(5)
+    n, d, k = 200_000, 128, 30
+    X = rng.random((n, d), dtype=F)
+    Q = rng.random((1024, d), dtype=F)
+    idx = new_index(d, 1)
+    idx.Add(None, X)
+    oi, od = oracle.search_batch(1, Q[:48], X, k, nthreads=8)
+    per_query = {}
+    res = {}
+    for nq in (384, 512, 1024):
+        lab, dist = idx.SearchBatch(Q[:nq], k)      # default = LB_CAND_AUTO
+        assert_same(lab[:48], dist[:48], oi, od, f"auto nq={nq}")
+        res[nq] = (lab, dist)
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            idx.SearchBatch(Q[:nq], k)
+            ts.append(time.perf_counter() - t0)
+        per_query[nq] = sorted(ts)[2] / nq
+    idx.set_candidate_mode(0)                        # strict: f32 MFMA beyond 384 queries
+    for nq in (512, 1024):
+        lab, dist = idx.SearchBatch(Q[:nq], k)
+        assert np.array_equal(lab, res[nq][0]) and np.array_equal(dist, res[nq][1])
+    assert per_query[512] < 1.5 * per_query[384], per_query
+    assert per_query[1024] < 1.5 * per_query[384], per_query
+    idx.Close()
+
+
+def test_cancel_and_deadline(oracle):
+    gpu_or_skip()
+    from longbow_amd import gpu
+    rng = np.random.default_rng(8)
+    n, d, k = 300_000, 256, 10
+    X = rng.random((n, d), dtype=F)
+    Q = rng.random((2048, d), dtype=F)
+    idx = new_index(d, 0)
+    idx.Add(None, X)
+    want = idx.SearchBatch(Q[:64], k)
+    # fired before the call: nothing runs
+    c = gpu.Cancel()
+    c.fire()
+    with pytest.raises(gpu.Canceled):
+        idx.SearchBatch(Q[:64], k, ctx=c)
+    assert c.state == 8
+    # a deadline that has passed
+    c2 = gpu.Cancel(deadline_ms=0)
+    time.sleep(0.002)
+    with pytest.raises(gpu.DeadlineExceeded):
+        idx.Search(Q[0], k, ctx=c2)
+    # a live context changes nothing
+    c3 = gpu.Cancel(deadline_ms=60_000)
+    lab, dist = idx.SearchBatch(Q[:64], k, ctx=c3)
+    assert np.array_equal(lab, want[0]) and np.array_equal(dist, want[1])
+    # fired from another thread while a long series of searches runs: the series ends early with Canceled, and
+    # the index keeps answering (workspaces, fused-launch tickets and streams are left consistent)
+    c4 = gpu.Cancel()
+    threading.Timer(0.05, c4.fire).start()
+    t0 = time.perf_counter()
+    with pytest.raises(gpu.Canceled):
+        for _ in range(2000):
+            idx.SearchBatch(Q, k, ctx=c4)
+            idx.SearchBatch(Q[:9], k, ctx=c4)        # (the fused launch)
+    assert time.perf_counter() - t0 < 5.0
+    for nq in (1, 9, 64):
+        lab, dist = idx.SearchBatch(Q[:nq], k)
+        assert np.array_equal(lab, want[0][:nq]) and np.array_equal(dist, want[1][:nq])
+    for c_ in (c, c2, c3, c4):
+        c_.close()
+    idx.Close()
+
+
+def test_pq_search_cancel(oracle):
+    gpu_or_skip()
+    from longbow_amd import gpu, pq
+    rng = np.random.default_rng(9)
+    M, dims, n = 8, 64, 200_000
+    cb = rng.random((M, 256, dims // M), dtype=F)
+    enc = pq.PQEncoder(pq.serialize_codebooks(cb))
+    enc.add_codes(rng.integers(0, 256, (n, M), dtype=np.uint8))
+    Q = rng.random((6, dims), dtype=F)
+    want = enc.Search(Q, 10)
+    c = gpu.Cancel()
+    lab, dist = enc.Search(Q, 10, ctx=c)
+    assert np.array_equal(lab, want[0]) and np.array_equal(dist, want[1])
+    c.fire()
+    with pytest.raises(gpu.Canceled):
+        enc.Search(Q, 10, ctx=c)
+    lab, dist = enc.Search(Q, 10)
+    assert np.array_equal(lab, want[0])
+    c.close()
+    enc.Close()
+
+
+def test_k_is_checked_before_any_staging_is_sized():
+    """k = INT32_MAX used to size a pinned slab and a device buffer of nq*k*12 bytes before being rejected"""
+    lib = gpu_or_skip()
+    idx = new_index(16, 0)
+    idx.Add(None, np.zeros((10, 16), F))
+    q = np.zeros((1, 16), F)
+    out_d, out_l = np.zeros(4, F), np.zeros(4, np.int64)
+    import torch
+    free0, _ = torch.cuda.mem_get_info(0)
+    rc = lib.lb_gpu_index_search(idx._h, 1, q.ctypes.data, 2**31 - 1, out_d.ctypes.data, out_l.ctypes.data)
+    assert rc == 6  # LB_ERR_UNSUPPORTED
+    rc = lib.lb_gpu_index_search(idx._h, 1, q.ctypes.data, 2049, out_d.ctypes.data, out_l.ctypes.data)
+    assert rc == 6
+    free1, _ = torch.cuda.mem_get_info(0)
+    assert free0 - free1 < (64 << 20)
+    idx.Close()
+
+
+@pytest.mark.parametrize("order", [0, 1])
+def test_batch_over_slices_follows_the_reference_per_vector_rules(oracle, order):
+    gpu_or_skip()
+    from longbow_amd import simd
+    rng = np.random.default_rng(21 + order)
+    d = 48
+    q = rng.standard_normal(d).astype(F)
+    vecs = [rng.standard_normal(d).astype(F) for _ in range(9)]
+    ragged = list(vecs)
+    ragged[2] = None                                  # nil
+    ragged[5] = rng.standard_normal(d - 1).astype(F)  # length mismatch
+    full = np.stack(vecs)
+    want = {m: oracle.batch_flat(m, q, full, order) for m in (0, 1, 2)}
+    # Euclidean: nil / mismatched -> math.MaxFloat32, everything else computed (batch_operations.go:39-42,51)
+    r = np.full(9, -7.0, F)
+    simd.EuclideanDistanceBatch(q, ragged, r, order=order)
+    exp = want[0].copy()
+    exp[[2, 5]] = FLT_MAX
+    assert np.array_equal(r, exp)
+    # Cosine / Dot: nil skipped (slot untouched); the mismatch stops the loop there, error swallowed (simd.go:241-267)
+    for m, fn in ((1, simd.CosineDistanceBatch), (2, simd.DotProductBatch)):
+        r = np.full(9, -7.0, F)
+        fn(q, ragged, r, order=order)
+        exp = np.full(9, -7.0, F)
+        exp[[0, 1, 3, 4]] = want[m][[0, 1, 3, 4]]
+        assert np.array_equal(r, exp), (m, r, exp)
+    # a rectangular list of vectors equals the flat call
+    r = np.empty(9, F)
+    simd.EuclideanDistanceBatch(q, vecs, r, order=order)
+    assert np.array_equal(r, want[0])
+    with pytest.raises(ValueError):
+        simd.EuclideanDistanceBatch(q, vecs, np.empty(8, F))
+
+
+def test_literal_batches_of_the_reference_through_the_rerank_entry(oracle):
+    """internal/simd/parallel_reduction_test.go:13-68,116-165: the 8-dim literal batches and the 768-dim 10-vector
+    batch, answered from RESIDENT rows by lb_gpu_index_rerank (processChunkInternal's distance step)"""
+    gpu_or_skip()
+    q8 = np.array([1, 2, 3, 4, 5, 6, 7, 8], F)
+    V8 = np.array([[1, 2, 3, 4, 5, 6, 7, 8], [8, 7, 6, 5, 4, 3, 2, 1], [1, 1, 1, 1, 1, 1, 1, 1], [0, 0, 0, 0, 0, 0, 0, 1]], F)
+    for metric in (0, 1, 2):
+        idx = new_index(8, metric)
+        idx.Add(None, V8)
+        for order in (0, 1):
+            d, sc = idx.Rerank(q8, np.arange(4), order=order)
+            w = oracle.batch_flat(metric, q8, V8, order)
+            w = -w if metric == 2 else w                 # the index ranks by the negated dot
+            assert np.array_equal(d, w.astype(F))
+        idx.Close()
+    # dot literals: 204, 120, 36, 8 (parallel_reduction_test.go:44-68); cosine of identical vectors 0
+    idx = new_index(8, 2)
+    idx.Add(None, V8)
+    d, _ = idx.Rerank(q8, np.arange(4))
+    assert np.array_equal(-d, np.array([204, 120, 36, 8], F))
+    idx.Close()
+    # 768-dim, 10 vectors: v[i][j] = (i + j) * 0.001, query[j] = j * 0.001 (parallel_reduction_test.go:116-165)
+    dim = 768
+    q = (np.arange(dim) * 0.001).astype(F)
+    V = ((np.arange(10)[:, None] + np.arange(dim)[None, :]) * 0.001).astype(F)
+    for metric in (0, 1, 2):
+        idx = new_index(dim, metric)
+        idx.Add(None, V)
+        rows = np.array([9, 0, 3, 3, 7], np.int64)
+        d, sc = idx.Rerank(q, rows, order=1)
+        w = oracle.batch_flat(metric, q, V[rows], 1)
+        w = -w if metric == 2 else w
+        assert np.array_equal(d, w.astype(F))
+        assert np.array_equal(sc, (F(1) / (F(1) + d)).astype(F))
+        idx.Close()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _failing_rank_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    import torch.distributed as dist
+    from longbow_amd import _lib, gpu
+    from longbow_amd.sharded import CommSearcher
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lib = _lib.load_diag()                       # the forced failure is a diagnostic-build hook
+        rng = np.random.default_rng(4)
+        X = rng.random((20000, 32), dtype=np.float32)
+        Q = torch.from_numpy(rng.random((7, 32), dtype=np.float32)).cuda()
+        idx = gpu.NewIndexWithConfig(gpu.GPUConfig(DeviceID=0, Dimension=32, Metric=0), lib=lib)
+        idx.Add(None, X[rank::world])
+        cs = CommSearcher(idx, rank, world, device_index=0, transport="host", lib=lib)
+        lab0, _ = cs.search(Q, 5)                    # a healthy round first
+        if rank == 1:
+            lib.lb_debug_search_fail_next(1)         # THIS rank's shard search fails; rank 0's does not
+        code, msg = 0, ""
+        try:
+            cs.search(Q, 5)
+        except _lib.LongbowGPUError as e:
+            code, msg = e.code, str(e)
+        lab2, _ = cs.search(Q, 5)                    # and the communicator keeps working afterwards
+        q.put((rank, int(code), msg, bool(np.array_equal(lab0.cpu().numpy(), lab2.cpu().numpy()))))
+        cs.close()
+        idx.Close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_failing_rank_still_takes_part_in_the_exchange():
+    """rank 1's local search fails: it ships the canonical empty block + its status word instead of leaving the
+    collective, so rank 0 does not hang in the all-gather, and BOTH ranks report the failure (results without a shard
+    are never returned as if complete)"""
+    gpu_or_skip()
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, c0, m0, same0), (r1, c1, m1, same1) = res
+    assert c1 == 7 and c0 == 7, res                  # LB_ERR_INTERNAL on the failing rank AND on its peer
+    assert "rank 1" in m0, m0
+    assert same0 and same1

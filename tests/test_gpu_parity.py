@@ -6,7 +6,7 @@ import threading
 import numpy as np
 import pytest
 
-from tests.gpu_util import assert_same, gpu_or_skip, new_index
+from tests.gpu_util import assert_same, diag_lib, gpu_or_skip, new_index
 
 pytestmark = pytest.mark.gpu
 F = np.float32
@@ -216,7 +216,7 @@ def test_sampled_threshold_first_pass(oracle):
     """corpora >= 64k rows take a strided row sample's m-th best entry as admission threshold and walk
     the rows once; the classic bootstrap schedule is the fallback.  Both must equal the oracle on random,
     sorted (worst->best and best->worst), and heavily duplicated corpora, on every search path."""
-    lib = gpu_or_skip()
+    lib = diag_lib()  # lb_debug_set_sample_tau exists only in the diagnostic build
     rng = np.random.default_rng(2024)
     n, d = 150_000, 32
     base = rng.random((n, d), dtype=F)
@@ -233,7 +233,7 @@ def test_sampled_threshold_first_pass(oracle):
     try:
         for name, X in corpora.items():
             for metric in (0, 1, 2):
-                idx = new_index(d, metric)
+                idx = new_index(d, metric, lib=lib)
                 idx.Add(None, X)
                 want = {}
                 for nq in (1, 3, 8, 40, 200):
@@ -421,9 +421,12 @@ def test_split_bf16_candidates_give_identical_results(oracle, metric):
         labb, distb = idx.SearchBatch(big, k)
         assert np.array_equal(labb[:nq], lab) and np.array_equal(distb[:nq], dist)
         assert np.array_equal(labb[nq:2 * nq], lab[: min(nq, 400 - nq)]) if 2 * nq <= 400 else True
-        idx.set_candidate_mode(0)
-        lab0, dist0 = idx.SearchBatch(Q, k)
-        assert np.array_equal(lab0, lab) and np.array_equal(dist0, dist)
+        for mode in (0, 3):                # strict f32 beyond 384 queries; AUTO (the default)
+            idx.set_candidate_mode(mode)
+            lab0, dist0 = idx.SearchBatch(Q, k)
+            assert np.array_equal(lab0, lab) and np.array_equal(dist0, dist)
+            lab4, dist4 = idx.SearchBatch(big, k)
+            assert np.array_equal(lab4, labb) and np.array_equal(dist4, distb)
         assert fb <= nq // 4
         idx.Close()
     idx = new_index(48, metric)            # dim % 32 != 0 -> unsupported, index keeps working in f32 mode
@@ -449,7 +452,7 @@ def test_tall_tile_every_route(oracle, metric):
     want = {}
     for nq in (70, 200, 384, 512):
         want[nq] = oracle.search_batch(metric, Q[:nq], X, k, nthreads=8)
-    for mode in (0, 1, 2):
+    for mode in (3, 0, 1, 2):                     # 3 = AUTO, what a fresh index runs
         idx.set_candidate_mode(mode)
         for nq in (70, 200, 384, 512):            # 512 in mode 1: the 256-query tile
             lab, dist = idx.SearchBatch(Q[:nq], k)
@@ -458,10 +461,11 @@ def test_tall_tile_every_route(oracle, metric):
         mask = (rng.random(n) < frac).astype(np.uint8)
         idx.set_filter(mask)
         oi, od = oracle.search_batch(metric, Q[:130], X, k, mask=mask, nthreads=8)
-        for mode in (0, 1):
+        for mode in (3, 0, 1):
             idx.set_candidate_mode(mode)
-            lab, dist = idx.SearchBatch(Q[:130], k)
-            assert_same(lab, dist, oi, od, f"tall masked metric={metric} mode={mode} frac={frac}")
+            for nq in (130, 512):
+                lab, dist = idx.SearchBatch(Q[:nq], k)
+                assert_same(lab[:130], dist[:130], oi, od, f"tall masked metric={metric} mode={mode} frac={frac} nq={nq}")
     idx.set_filter(None)
     idx.Close()
 
@@ -495,17 +499,13 @@ def test_fused_sample_launch_and_its_give_up_path(oracle):
     threshold workgroups, corpus workgroups that pick the thresholds up).  Results equal the oracle; when a wait inside
     the launch gives up (forced here through the host hook) the whole batch is redone on the exact path and the next
     searches run fused again."""
-    gpu_or_skip()
-    import ctypes as C
-    from longbow_amd import _lib
-    lib = _lib.load()
-    lib.lb_debug_fused_fail_next.argtypes = [C.c_int]
+    lib = diag_lib()  # the give-up path is forced through a hook that only the diagnostic build exports
     rng = np.random.default_rng(99)
     n, d, k = 150_000, 64, 25
     X = rng.standard_normal((n, d)).astype(F)
     Q = rng.standard_normal((32, d)).astype(F)
     for metric in (0, 1, 2):
-        idx = new_index(d, metric)
+        idx = new_index(d, metric, lib=lib)
         idx.Add(None, X)
         want = {nq: oracle.search_batch(metric, Q[:nq], X, k, nthreads=8) for nq in (5, 9, 32)}
         for rep in range(3):
@@ -531,17 +531,13 @@ def test_fused_sample_launch_and_its_give_up_path(oracle):
 def test_growth_survives_a_refused_mapping(oracle):
     """the corpus grows in place through the virtual-memory API; when the driver refuses to extend the mapping
     (forced here) the rows move once into a hipMalloc buffer and the index keeps working, ids and all"""
-    gpu_or_skip()
-    import ctypes as C
-    from longbow_amd import _lib
-    lib = _lib.load()
-    lib.lb_debug_vmm_fail_next.argtypes = [C.c_int]
+    lib = diag_lib()
     rng = np.random.default_rng(31)
     d, k = 48, 15
     X = rng.random((9000, d), dtype=F)
     ids = np.arange(9000, dtype=np.int64) * 3 + 7
     Q = rng.random((6, d), dtype=F)
-    idx = new_index(d, 0)
+    idx = new_index(d, 0, lib=lib)
     idx.Add(ids[:1000], X[:1000])
     try:
         lib.lb_debug_vmm_fail_next(1)

@@ -180,14 +180,11 @@ def test_search_on_encoded_vectors_and_prefilter_equivalence(oracle):
     assert np.array_equal(codes_all[sub], codes_sub)
     assert np.array_equal(enc.get_codes(), codes_all) and np.array_equal(enc.get_codes(5000, 10), codes_all[5000:5010])
     Q = rng.random((3, dims), dtype=F)
-    lib.lb_debug_set_adc_prefilter.argtypes = [C.c_int]
-    try:
-        lib.lb_debug_set_adc_prefilter(1)
-        lab1, dist1 = enc.Search(Q, k)
-        lib.lb_debug_set_adc_prefilter(0)
-        lab0, dist0 = enc.Search(Q, k)
-    finally:
-        lib.lb_debug_set_adc_prefilter(1)
+    enc.set_prefilter(True)
+    lab1, dist1 = enc.Search(Q, k)
+    enc.set_prefilter(False)  # exact f32-table pass over every row
+    lab0, dist0 = enc.Search(Q, k)
+    enc.set_prefilter(True)
     assert np.array_equal(lab0, lab1) and np.array_equal(dist0, dist1)
     for b in range(3):
         d = oracle.adc_batch(oracle.build_adc_table(cb, Q[b]), codes_all)

@@ -63,11 +63,9 @@ def test_sample_plan_invariants():
     import math
     from longbow_amd import _lib
     try:
-        lib = _lib.load()
+        lib = _lib.load_diag()  # host-logic probes are exported by the diagnostic build only
     except (RuntimeError, OSError) as e:  # CPU-only checkout without the built library / ROCm runtime
-        pytest.skip(f"liblongbow_gpu.so not loadable here: {e}")
-    lib.lb_debug_sample_plan.argtypes = [C.c_longlong, C.c_int, C.c_uint, C.c_uint, C.POINTER(C.c_longlong)]
-    lib.lb_debug_sample_plan.restype = None
+        pytest.skip(f"liblongbow_gpu_diag.so not loadable here: {e}")
     out = (C.c_longlong * 4)()
     seen_on = 0
     for n in (1000, 65535, 65536, 10**5, 10**6, 2_500_000, 10**7, 10**8, 4 * 10**9):

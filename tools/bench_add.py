@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Ingest throughput of lb_gpu_index_add from pageable host memory (the Arrow values buffer): the caller's
 buffer pinned for the call (hipHostRegister, default for >= 64 MB batches) vs the double-buffered pinned slabs.
-usage: python tools/bench_add.py"""
+usage: LB_GPU_SO=longbow_amd/liblongbow_gpu_diag.so python tools/bench_add.py   (the A/B switch is a diagnostic-build hook)"""
 import ctypes as C, time, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

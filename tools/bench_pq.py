@@ -34,11 +34,9 @@ else:
 Q = torch.empty((nq, D), device="cuda")
 lib.lb_gpu_fill_uniform_device(0, Q.data_ptr(), Q.numel(), 42, 0, None)
 od = torch.empty((nq, K), device="cuda"); ol = torch.empty((nq, K), dtype=torch.int64, device="cuda")
-import ctypes as C
-lib.lb_debug_set_adc_prefilter.argtypes = [C.c_int]
 # codes either uniform random bytes (default) or PQ_REAL=1: encoded on the GPU from uniform vectors
 for pre, name in ((1, "byte-table prefilter + exact survivors (default)"), (0, "exact f32 table pass"), (1, "byte-table prefilter + exact survivors (default)")):
-  lib.lb_debug_set_adc_prefilter(pre)
+  enc.set_prefilter(bool(pre))
   ts = []
   for i in range(8):
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -49,6 +47,6 @@ for pre, name in ((1, "byte-table prefilter + exact survivors (default)"), (0, "
   if pre == 0: ref = res
   print(f"[{name}] N={N} nq={nq}: {t*1e3:.3f} ms per batch, {t*1e3/nq:.3f} ms/query, codes stream {N*M*nq/t/1e9:.0f} GB/s "
       f"({N*M*nq/t/8e12*100:.1f}% of 8 TB/s)", flush=True)
-lib.lb_debug_set_adc_prefilter(1)
+enc.set_prefilter(True)
 print("prefilter == exact pass:", bool(np.array_equal(res[0], ref[0]) and np.array_equal(res[1], ref[1])))
 print("top-3", ol[0, :3].tolist(), od[0, :3].tolist())

@@ -18,7 +18,6 @@ del buf
 Q = torch.empty((4, dims), device=dev)
 lib.lb_gpu_fill_uniform_device(0, Q.data_ptr(), Q.numel(), 42, 0, None)
 od = torch.empty((4, K), device=dev); ol = torch.empty((4, K), dtype=torch.int64, device=dev)
-lib.lb_debug_set_adc_prefilter.argtypes = [C.c_int]
 def run(nq, reps):
     ts = []
     for _ in range(reps):
@@ -28,9 +27,9 @@ def run(nq, reps):
     return ts
 print("prefilter B=1", run(1, 14), flush=True)
 print("prefilter B=4", run(4, 6), flush=True)
-lib.lb_debug_set_adc_prefilter(0)
+enc.set_prefilter(False)
 print("exact B=1", run(1, 8), flush=True)
-lib.lb_debug_set_adc_prefilter(1)
+enc.set_prefilter(True)
 print("prefilter B=1", run(1, 14), flush=True)
 time.sleep(3)
 print("prefilter B=1 after 3 s idle", run(1, 14), flush=True)
