@@ -145,6 +145,7 @@ def test_batch_over_slices_follows_the_reference_per_vector_rules(oracle, order)
     ragged[5] = rng.standard_normal(d - 1).astype(F)  # length mismatch
     full = np.stack(vecs)
     want = {m: oracle.batch_flat(m, q, full, order) for m in (0, 1, 2)}
+    want[2] = -want[2]  # the oracle reports the value the search ranks by (negated); simd.DotProductBatch is raw
     # Euclidean: nil / mismatched -> math.MaxFloat32, everything else computed (batch_operations.go:39-42,51)
     r = np.full(9, -7.0, F)
     simd.EuclideanDistanceBatch(q, ragged, r, order=order)
@@ -177,8 +178,7 @@ def test_literal_batches_of_the_reference_through_the_rerank_entry(oracle):
         idx.Add(None, V8)
         for order in (0, 1):
             d, sc = idx.Rerank(q8, np.arange(4), order=order)
-            w = oracle.batch_flat(metric, q8, V8, order)
-            w = -w if metric == 2 else w                 # the index ranks by the negated dot
+            w = oracle.batch_flat(metric, q8, V8, order)  # (dot: the negated value, what the index ranks by)
             assert np.array_equal(d, w.astype(F))
         idx.Close()
     # dot literals: 204, 120, 36, 8 (parallel_reduction_test.go:44-68); cosine of identical vectors 0
@@ -197,7 +197,6 @@ def test_literal_batches_of_the_reference_through_the_rerank_entry(oracle):
         rows = np.array([9, 0, 3, 3, 7], np.int64)
         d, sc = idx.Rerank(q, rows, order=1)
         w = oracle.batch_flat(metric, q, V[rows], 1)
-        w = -w if metric == 2 else w
         assert np.array_equal(d, w.astype(F))
         assert np.array_equal(sc, (F(1) / (F(1) + d)).astype(F))
         idx.Close()
