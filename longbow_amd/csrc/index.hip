@@ -27,7 +27,7 @@
 
 using namespace lb;
 
-namespace lb { extern int g_adc_ablation; extern int g_gemm_ablation; extern int g_gemm_glds; void read_clock_probe(unsigned long long out[8], bool reset); int debug_gemm_occupancy(); void read_fused_probe(unsigned long long out[8], bool reset); }
+namespace lb { extern int g_adc_ablation; extern int g_gemm_ablation; extern int g_gemm_glds; void read_clock_probe(unsigned long long out[8], bool reset); int debug_gemm_occupancy(); void read_fused_probe(unsigned long long out[8], bool reset); void read_tall2_probe(unsigned long long out[8], bool reset); }
 
 namespace {
 
@@ -292,17 +292,20 @@ std::unique_ptr<Workspace> acquire_ws(lb_gpu_index *h, int nq, uint32_t cap)
 {
     {
         std::lock_guard<std::mutex> g(h->ws_mu);
-        for (size_t i = 0; i < h->ws_free.size(); i++) {
-            if (h->ws_free[i]->nq_cap >= nq && h->ws_free[i]->cap == cap) {
-                auto w = std::move(h->ws_free[i]);
-                h->ws_free.erase(h->ws_free.begin() + (long)i);
-                return w;
-            }
+        size_t best = (size_t)-1;
+        for (size_t i = 0; i < h->ws_free.size(); i++)
+            if (h->ws_free[i]->nq_cap >= nq && h->ws_free[i]->cap == cap &&
+                (best == (size_t)-1 || h->ws_free[i]->nq_cap < h->ws_free[best]->nq_cap))
+                best = i;
+        if (best != (size_t)-1) {
+            auto w = std::move(h->ws_free[best]);
+            h->ws_free.erase(h->ws_free.begin() + (long)best);
+            return w;
         }
     }
     auto w = std::make_unique<Workspace>();
     w->device = h->device;
-    w->nq_cap = std::max(nq, 8);
+    w->nq_cap = (int)next_pow2_host((uint32_t)std::max(nq, 8)); // nearby batch sizes share a workspace
     w->cap = cap;
     w->cs.cap = cap;
     LB_HIP(hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking));
@@ -334,8 +337,25 @@ std::unique_ptr<Workspace> acquire_ws(lb_gpu_index *h, int nq, uint32_t cap)
 
 void release_ws(lb_gpu_index *h, std::unique_ptr<Workspace> w)
 {
-    std::lock_guard<std::mutex> g(h->ws_mu);
-    if (h->ws_free.size() < 8) h->ws_free.push_back(std::move(w));
+    std::unique_ptr<Workspace> drop; // (freed outside the lock: hipFree synchronises the device)
+    {
+        std::lock_guard<std::mutex> g(h->ws_mu);
+        if (h->ws_free.size() < 8) {
+            h->ws_free.push_back(std::move(w));
+            return;
+        }
+        // pool full: keep the LARGER workspaces.  (A pool that dropped the newcomer instead re-allocated the workspace of
+        // every batch size beyond the first eight on every call: +1.4 ms per search, tools/route_grid.py.)
+        size_t smallest = 0;
+        for (size_t i = 1; i < h->ws_free.size(); i++)
+            if (h->ws_free[i]->nq_cap < h->ws_free[smallest]->nq_cap) smallest = i;
+        if (h->ws_free[smallest]->nq_cap < w->nq_cap) {
+            drop = std::move(h->ws_free[smallest]);
+            h->ws_free[smallest] = std::move(w);
+        } else {
+            drop = std::move(w);
+        }
+    }
 }
 
 struct ProfScope {
@@ -400,6 +420,7 @@ struct SamplePlan {
 };
 std::atomic<int> g_sample_tau{lb_tunable("LB_SAMPLE_TAU", 1)};
 std::atomic<int> g_fused_fail_next{0}; // test hook: treat the next fused launch as one whose waits gave up
+std::atomic<int> g_last_route{0}; // diagnostic build: kind * 10 + split of the last batched search's route
 std::atomic<int> g_search_fail_next{0}; // test hook (diagnostic build): the next search on this process fails with LB_ERR_INTERNAL
 // Add batches of at least this many bytes pin the caller's buffer instead of staging it (0 = never)
 std::atomic<long long> g_add_register_min{(long long)lb_tunable("LB_ADD_REGISTER_MIN_MB", 64) << 20};
@@ -567,26 +588,35 @@ void scan_with_retry(lb_gpu_index *h, Workspace *w, hipStream_t s, const float *
 // Cost model: a pass over `n` positions of dimension D costs  n * (alpha * D + beta) [+ gamma]  per query tile, with
 // the constants measured per kernel on MI355X over D in {128 .. 1536} x n in {100k .. 10M} (tools/route_grid.py; the
 // GPU test test_route_choice_is_near_the_best_forced_route checks the choice against every forced route).
-enum RouteKind { ROUTE_NARROW32 = 1, ROUTE_NARROW64 = 2, ROUTE_TALL = 3, ROUTE_WIDE = 4 };
+enum RouteKind { ROUTE_NARROW32 = 1, ROUTE_NARROW64 = 2, ROUTE_TALL = 3, ROUTE_WIDE = 4, ROUTE_TALL2 = 5 };
 struct Route {
     int kind = ROUTE_WIDE;
     int split = 0;
     double cost_ms = 0;
 };
-struct RouteCost { // ms = 1e-9 * n * (alpha * D + beta) * tiles + gamma
-    double alpha, beta, gamma;
+// One pass of a route's kernel over n positions of dimension D with `tiles` query tiles costs
+//     ms = max(tiles * 1e-6 * n * (alpha * D + beta),  1e-6 * n * D * hbm)  +  1e-6 * n * D * first
+// alpha: the contraction (per position, dimension and query tile); beta: the per-position work that does not scale with
+// D (epilogue: key, admission test, side inputs); hbm: the corpus stream under that kernel (4 bytes per element at the
+// rate the kernel's staging reaches); first: what the first query tile of a multi-tile pass waits for the corpus.
+// Fitted to tools/route_grid.py on MI355X (D in {128, 384, 768, 1536} x n in {100k, 1M, 4M}), see DESIGN.md 3.2.
+struct RouteCost {
+    double alpha, beta, hbm, first;
 };
-// (1M x 768: narrow passes 0.50 / 0.48 ms; tall in-register 0.27 + 0.535 per 128-query tile; image 0.23 + 0.49;
-//  f32 wide 1.49 per 128-query tile)
-constexpr RouteCost kCostNarrow32{0.000651, 0.0, 0.0};
-constexpr RouteCost kCostNarrow64{0.000625, 0.0, 0.0};
-constexpr RouteCost kCostTallInreg{0.000697, 0.0, 0.0};
-constexpr RouteCost kCostTallImage{0.000638, 0.0, 0.0};
-constexpr RouteCost kCostWideF32{0.00194, 0.0, 0.0};
-constexpr double kTallFirstTile = 0.000352; // the first query tile of a tall pass also waits for the corpus stream
+// (narrow tiles: one launch, the corpus tile is read from HBM once and re-used from L2 by the other query tiles)
+constexpr RouteCost kCostNarrow32{0.000323, 0.0247, 0.000640, 0.000300};   // per 32-query tile: 1.09 ms at 4M x 768, 0.27 at 4M x 128
+constexpr RouteCost kCostNarrow64{0.000527, 0.0225, 0.000640, 0.000200};   // per 64-query tile: 1.71 ms at 4M x 768, 0.36 at 4M x 128
+constexpr RouteCost kCostTallInreg{0.000687, 0.0445, 0.000640, 0.000250};  // per 128-query tile: 2.29 ms at 4M x 768, 0.53 at 4M x 128
+constexpr RouteCost kCostTallImage{0.000630, 0.0445, 0.000640, 0.000220};
+constexpr RouteCost kCostTall2Inreg{0.001260, 0.1300, 0.000640, 0.000250}; // per 256-query tile: 3.9 ms at 4M x 768, 1.16 at 4M x 128
+constexpr RouteCost kCostTall2Image{0.001150, 0.1300, 0.000640, 0.000220};
+constexpr RouteCost kCostWideF32{0.001940, 0.0600, 0.000640, 0.0};
 inline double route_ms(const RouteCost &c, int64_t n, int D, int tiles)
 {
-    return 1e-9 * (double)n * (c.alpha * (double)D + c.beta) * (double)tiles + c.gamma;
+    const double nd = 1e-6 * (double)n;
+    const double compute = (double)tiles * nd * (c.alpha * (double)D + c.beta);
+    const double stream = nd * (double)D * c.hbm;
+    return (compute > stream ? compute : stream) + nd * (double)D * c.first;
 }
 
 static Route choose_route(int nq, int64_t n, int D, int cmode, bool narrow_ok, bool have_image)
@@ -594,11 +624,12 @@ static Route choose_route(int nq, int64_t n, int D, int cmode, bool narrow_ok, b
     static const int narrow_max = lb_tunable("LB_NARROW_MAXQ", 384);
     static const bool nsplit_on = lb_tunable("LB_NARROW_SPLIT", 1) != 0;
     static const int tall_on = lb_tunable("LB_TALL", 1);
-    const int tiles32 = (nq + 31) / 32, tiles64 = (nq + 63) / 64, tiles128 = (nq + 127) / 128;
+    const int tiles32 = (nq + 31) / 32, tiles64 = (nq + 63) / 64, tiles128 = (nq + 127) / 128, tiles256 = (nq + 255) / 256;
     // (tall tiles only with enough of them to fill the chip a few times over: 512 workgroups run at once, and at 125k
     // visible rows x 256 queries the 978 tall tiles came out 5 % behind the 3908 smaller ones)
     const bool tall_fills = (n / 256) * tiles128 >= 2048;
-    Route cand[5];
+    const bool tall2_fills = (n / 256) * tiles256 >= 1024; // (one workgroup per CU: 256 run at once)
+    Route cand[8];
     int nc = 0;
     auto add = [&](int kind, int split, double ms) { cand[nc].kind = kind; cand[nc].split = split; cand[nc].cost_ms = ms; nc++; };
     const bool image = cmode == LB_CAND_SPLIT_BF16 && have_image;
@@ -608,20 +639,26 @@ static Route choose_route(int nq, int64_t n, int D, int cmode, bool narrow_ok, b
         if (nq > 32) add(ROUTE_NARROW64, nsp, route_ms(kCostNarrow64, n, D, tiles64));
     }
     if (narrow_ok && tall_on) {
-        if (image) add(ROUTE_TALL, 1, route_ms(kCostTallImage, n, D, tiles128) + 1e-9 * (double)n * D * kTallFirstTile * 0.85);
-        else if (nsplit_on && (tall_fills || cmode == LB_CAND_SPLIT_BF16_INREG) &&
-                 (cmode != LB_CAND_F32_MFMA || nq <= narrow_max))
-            add(ROUTE_TALL, 2, route_ms(kCostTallInreg, n, D, tiles128) + 1e-9 * (double)n * D * kTallFirstTile);
+        if (image) {
+            add(ROUTE_TALL, 1, route_ms(kCostTallImage, n, D, tiles128));
+            if (nq > 128) add(ROUTE_TALL2, 1, route_ms(kCostTall2Image, n, D, tiles256));
+        } else if (nsplit_on && (cmode != LB_CAND_F32_MFMA || nq <= narrow_max)) {
+            const bool forced = cmode == LB_CAND_SPLIT_BF16_INREG;
+            if (tall_fills || forced) add(ROUTE_TALL, 2, route_ms(kCostTallInreg, n, D, tiles128));
+            if (nq > 128 && (tall2_fills || forced)) add(ROUTE_TALL2, 2, route_ms(kCostTall2Inreg, n, D, tiles256));
+        }
     }
     if (image && !tall_on) add(ROUTE_WIDE, 1, route_ms(kCostWideF32, n, D, tiles128) * 0.4);
     else if (cmode == LB_CAND_F32_MFMA || cmode == LB_CAND_AUTO || nc == 0) add(ROUTE_WIDE, 0, route_ms(kCostWideF32, n, D, tiles128));
 #ifdef LB_DIAG
-    { // A/B (tools/route_grid.py): force a route when it is available for this batch
-        const int force = lb_tunable("LB_FORCE_ROUTE", 0);
+    { // A/B (tools/route_grid.py): force a route when it is available for this batch (read per call: the tool flips it)
+        const char *e = getenv("LB_FORCE_ROUTE");
+        const int force = e ? atoi(e) : 0;
         for (int i = 0; i < nc; i++)
             if (cand[i].kind == force) return cand[i];
     }
 #endif
+    if (cmode == LB_CAND_F32_MFMA && nq > narrow_max) return cand[nc - 1]; // strict mode: the f32 tile beyond the narrow range
     if (nq <= 32 && nc > 0 && cand[0].kind == ROUTE_NARROW32) return cand[0]; // one pass of the 32-query tile: nothing is cheaper
     int best = 0;
     for (int i = 1; i < nc; i++)
@@ -663,11 +700,15 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     const int cmode = h->cand_mode.load();
     const bool have_image = h->d_Xs != nullptr && h->xs_rows == h->n && h->dim % 32 == 0;
     const Route route = choose_route(nq, n, h->dim, cmode, narrow_ok, have_image);
+#ifdef LB_DIAG
+    g_last_route.store(route.kind * 10 + route.split);
+#endif
     const int split = route.split;                 // of the operands handed to the kernel: 0 f32, 1 images, 2 f32 split in registers
     const bool use_narrow = route.kind == ROUTE_NARROW32 || route.kind == ROUTE_NARROW64;
     const bool tile64 = route.kind == ROUTE_NARROW64;
     const bool nsplit = use_narrow && route.split == 2;
-    const bool use_tall = route.kind == ROUTE_TALL;
+    const bool use_tall = route.kind == ROUTE_TALL || route.kind == ROUTE_TALL2;
+    const bool use_tall2 = route.kind == ROUTE_TALL2;
     const int wsplit = use_narrow ? 0 : route.split;
     const float *gx = h->d_X, *gq = d_q;
     const float u24 = 5.9604645e-8f;
@@ -715,6 +756,9 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
             // operands) gets through its 24 K-steps of 32 in 31-35 us, the tall tile through its 48 of 16 in 57
             launch_gemm_filter_narrow(metric, h->d_X, h->d_norm2, h->d_rnorm, b, e, h->dim, d_q, nq, mask, rowmap, w->cs,
                                       true, s, /*tile64=*/true, /*split=*/true);
+        else if (use_tall2)
+            launch_gemm_filter_tall2(metric, gx, h->d_norm2, h->d_rnorm, b, e, h->dim, w->d_qs, nq, mask, rowmap, w->cs,
+                                     boot, wsplit, s);
         else if (use_tall)
             launch_gemm_filter_tall(metric, gx, h->d_norm2, h->d_rnorm, b, e, h->dim, w->d_qs, nq, mask, rowmap, w->cs,
                                     boot, wsplit, s);
@@ -1602,6 +1646,7 @@ int lb_gpu_index_last_timing(const lb_gpu_index *hc, float ms[5], int n_launch[5
 void lb_debug_set_sample_tau(int v) { g_sample_tau.store(v); } // 0: classic bootstrap schedule only
 void lb_debug_vmm_fail_next(int v) { g_vmm_fail_next.store(v); } // the next in-place growth is refused (-> hipMalloc + copy)
 void lb_debug_fused_fail_next(int v) { g_fused_fail_next.store(v); } // the next fused sample launch counts as timed out (-> exact path for the batch)
+int lb_debug_last_route(void) { return g_last_route.load(); } // RouteKind * 10 + split of the most recent batched search
 void lb_debug_search_fail_next(int v) { g_search_fail_next.store(v); } // the next search in this process returns LB_ERR_INTERNAL
 void lb_debug_set_add_register_min(long long bytes) { g_add_register_min.store(bytes); } // ingest A/B (tools/bench_add.py)
 // host-only: the sampled-threshold plan for a view of n rows (tests check its invariants without a GPU);
@@ -1621,6 +1666,7 @@ void lb_debug_set_adc_ablation(int v) { lb::g_adc_ablation = v; }
 int lb_debug_gemm_occupancy(void) { return lb::debug_gemm_occupancy(); }
 void lb_debug_read_clock_probe(unsigned long long *out, int reset) { lb::read_clock_probe(out, reset != 0); }
 void lb_debug_read_fused_probe(unsigned long long *out, int reset) { lb::read_fused_probe(out, reset != 0); }
+void lb_debug_read_tall2_probe(unsigned long long *out, int reset) { lb::read_tall2_probe(out, reset != 0); }
 #endif
 
 // ---- candidate re-rank (processChunkInternal) ------------------------------------------

@@ -190,6 +190,11 @@ void launch_gemm_filter_tall(int metric, const float *X, const float *norm2, con
                              int64_t row_end, int D, const float *Qs, int nq, const uint8_t *mask, const uint32_t *rowmap,
                              CandState cs, bool boot, int asplit, hipStream_t s);
 
+// the same contraction on 256 x 256 tiles with whole 128-B lines per row and K-step (kernels_gemm_tall2.hip)
+void launch_gemm_filter_tall2(int metric, const float *X, const float *norm2, const float *rnorm, int64_t row_begin,
+                              int64_t row_end, int D, const float *Qs, int nq, const uint8_t *mask, const uint32_t *rowmap,
+                              CandState cs, bool boot, int asplit, hipStream_t s);
+
 // per query: sort the list, keep the best kc, tau = kc-th entry (or max), flag overflow.
 // qsel (nullable): only these query slots.  boot_rows > 0: the list was filled by a bootstrap
 // launch (one entry per row at index row - row_begin, no atomics; masked rows hold kEntryMax).
