@@ -284,27 +284,43 @@ struct AdcPreArgs {
     uint32_t *cand;      // candidate rows
     uint32_t cand_cap;
     uint32_t *cand_cnt;  // [0] = count (may exceed cand_cap -> overflow)
+    // second query of a two-query pass (NQ == 2): the code bytes are streamed ONCE for both
+    const uint8_t *qtab2 = nullptr;
+    const int *params2 = nullptr;
+    uint32_t *cand2 = nullptr;
+    uint32_t *cand_cnt2 = nullptr;
 };
 
 // Same streaming structure as adc_scan_dma_kernel: each wave DMAs its 64 rows (64*M contiguous bytes) into
 // a private LDS slot with M/16 direct-to-LDS loads of 1 KiB, reads its own row back, re-issues the DMA for
 // its next tile and then does the M byte gathers.  The byte table is 24 KB at M = 96, which leaves room
 // for 16 waves per CU (96 KB of code bytes in flight) instead of 8.
-template <int MCH, bool QW, int WAVES, int SLOTS, bool HYB = false>
+// NQ == 2: two queries per pass over the codes.  The pass is bound by the LDS gathers (2 per code byte then) and the code
+// stream together, not by the stream alone, so two queries cost ~1.3x one pass instead of 2x: the second table sits
+// M * 256 bytes behind the first and its gather uses the same address register with a larger instruction offset.
+template <int MCH, bool QW, int WAVES, int SLOTS, bool HYB = false, int NQ = 1>
 __global__ __launch_bounds__(WAVES * 64) void adc_prefilter_kernel(AdcPreArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_u8[];
     constexpr int M = MCH * 16;
     unsigned char *tab = smem_u8;
-    unsigned char *stage_all = smem_u8 + M * 256;
+    unsigned char *stage_all = smem_u8 + NQ * M * 256;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (a.params[1] == 0) return; // prefilter unusable for this query (uniform): the exact path runs instead
-    const int s_tau = a.params[0];
+    // prefilter unusable for a query (uniform; decided by adc_quantise_kernel): nothing of it is admitted here, the select
+    // then finds fewer than k entries, flags the query, and the host redoes it on the exact schedule
+    const int ok1 = a.params[1], ok2 = NQ == 2 ? a.params2[1] : 0;
+    if (ok1 == 0 && ok2 == 0) return;
+    const int s_tau = ok1 ? a.params[0] : -1;
+    const int s_tau2 = (NQ == 2 && ok2) ? a.params2[0] : -1;
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(a.qtab);
         uint4 *dst = reinterpret_cast<uint4 *>(tab);
         for (int i = tid; i < M * 16; i += WAVES * 64) dst[i] = src[i];
+        if (NQ == 2) {
+            const uint4 *src2 = reinterpret_cast<const uint4 *>(a.qtab2);
+            for (int i = tid; i < M * 16; i += WAVES * 64) dst[M * 16 + i] = src2[i];
+        }
     }
     __syncthreads();
     unsigned char *stage = stage_all + wave * (SLOTS * 64 * M);
@@ -357,7 +373,7 @@ __global__ __launch_bounds__(WAVES * 64) void adc_prefilter_kernel(AdcPreArgs a)
         // for every third sub-quantiser only (1.78 vs 1.80 ms: inside the noise, not the default).  Also
         // tried and slower: two DMA slots per wave (11 x 2: 1.87 ms), 16 gathers issued ahead of their adds
         // (1.91 ms), a third of the gathers through the vector cache instead of LDS (1.87-2.7 ms).
-        uint32_t S = 0;
+        uint32_t S = 0, S2 = 0;
 #pragma unroll
         for (int g = 0; g < MCH; g++) {
             const uint32_t w[4] = {c[g].x, c[g].y, c[g].z, c[g].w};
@@ -372,6 +388,7 @@ __global__ __launch_bounds__(WAVES * 64) void adc_prefilter_kernel(AdcPreArgs a)
                         S += __builtin_amdgcn_perm(qw.y, qw.x, code & 7u) & 0xffu;
                     } else {
                         S += tab[j * 256 + code];
+                        if (NQ == 2) S2 += tab[M * 256 + j * 256 + code];
                     }
                 }
         }
@@ -380,7 +397,110 @@ __global__ __launch_bounds__(WAVES * 64) void adc_prefilter_kernel(AdcPreArgs a)
             const uint32_t pos = atomicAdd(a.cand_cnt, 1u);
             if (pos < a.cand_cap) a.cand[pos] = (uint32_t)row;
         }
+        if (NQ == 2 && row < a.n && (int)S2 <= s_tau2) {
+            const uint32_t pos = atomicAdd(a.cand_cnt2, 1u);
+            if (pos < a.cand_cap) a.cand2[pos] = (uint32_t)row;
+        }
     }
+}
+
+// The same pass with the codes staged in REGISTERS, not LDS.  A wave's tile is 64 rows = 64 * M contiguous bytes; request i
+// of the wave loads bytes [1024 i, 1024 i + 1024) of it with one coalesced global_load_dwordx4 (nt), so lane l holds the
+// 16-byte chunk c = 64 i + l: sub-quantisers 16 (c % MCH) .. + 15 of row c / MCH (a chunk never straddles a row: M = 16 MCH).
+// Every lane gathers its chunk's 16 byte-table entries and leaves the partial sum in a wave-private LDS word; lane r then
+// adds the MCH words of row 64 tile + r.  Against the DMA variant above this takes the 6 KB of DMA writes and the 6 KB of
+// row reads per tile off the LDS (the unit that bounds the pass: 67 % array-busy + the DMA writes it also serves,
+// profiles/r02_pmc_pq.txt) for 2 x 1.5 KB of partial sums, and keeps TWO tiles of loads in flight per wave (the next
+// tile's registers are requested before the current one is gathered): 192 KB per CU instead of 96.
+// Which sub-table a lane's chunk belongs to depends on (64 i + l) % MCH only -- the same for every tile -- so the per-lane
+// table bases are computed once.
+template <int MCH, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void adc_prefilter_reg_kernel(AdcPreArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_u8[];
+    constexpr int M = MCH * 16;
+    unsigned char *tab = smem_u8;
+    uint32_t *part_all = reinterpret_cast<uint32_t *>(smem_u8 + M * 256); // [WAVES][MCH * 64] partial sums
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (a.params[1] == 0) return; // prefilter unusable for this query (uniform): the exact path runs instead
+    const int s_tau = a.params[0];
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.qtab);
+        uint4 *dst = reinterpret_cast<uint4 *>(tab);
+        for (int i = tid; i < M * 16; i += WAVES * 64) dst[i] = src[i];
+    }
+    __syncthreads();
+    uint32_t *part = part_all + wave * (MCH * 64);
+    const int64_t ntiles = (a.n + 63) / 64;
+    const int64_t tstride = (int64_t)gridDim.x * WAVES;
+    const unsigned char *last16 = a.codes + a.n * (int64_t)M - 16;
+    uint32_t base[MCH]; // byte offset of the first of this lane's 16 sub-tables, per request
+#pragma unroll
+    for (int i = 0; i < MCH; i++) base[i] = (uint32_t)(((i * 64 + lane) % MCH) * 16 * 256);
+
+    auto load = [&](int64_t tile, uint4 (&c)[MCH]) {
+        const unsigned char *src0 = a.codes + tile * 64 * (int64_t)M + lane * 16;
+#pragma unroll
+        for (int i = 0; i < MCH; i++) {
+            const unsigned char *src = src0 + i * 1024;
+            if (src > last16) src = last16; // tail tile: stay inside the buffer (rows past the end are discarded)
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src));
+            c[i] = make_uint4(v.x, v.y, v.z, v.w);
+        }
+    };
+    uint4 cur[MCH], nxt[MCH];
+    int64_t tile = (int64_t)blockIdx.x * WAVES + wave;
+    if (tile < ntiles) load(tile, cur);
+    for (; tile < ntiles; tile += tstride) {
+        const bool more = tile + tstride < ntiles;
+        if (more) load(tile + tstride, nxt);
+#pragma unroll
+        for (int i = 0; i < MCH; i++) {
+            const uint32_t w[4] = {cur[i].x, cur[i].y, cur[i].z, cur[i].w};
+            const unsigned char *tb = tab + base[i];
+            uint32_t S = 0;
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) S += tb[(t * 4 + b) * 256 + ((w[t] >> (8 * b)) & 0xffu)];
+            part[i * 64 + lane] = S;
+        }
+        // the words are read back by OTHER lanes of this wave: LDS operations of one wave complete in order, the compiler
+        // only has to keep them in order
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint32_t total = 0;
+#pragma unroll
+        for (int p = 0; p < MCH; p++) total += part[lane * MCH + p];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier(); // (the next tile's partial sums overwrite these words)
+        const int64_t row = tile * 64 + lane;
+        if (row < a.n && (int)total <= s_tau) {
+            const uint32_t pos = atomicAdd(a.cand_cnt, 1u);
+            if (pos < a.cand_cap) a.cand[pos] = (uint32_t)row;
+        }
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < MCH; i++) cur[i] = nxt[i];
+        }
+    }
+}
+
+template <int MCH, int WAVES>
+static bool try_prefilter_reg(const AdcPreArgs &a, hipStream_t s, int wg_per_cu = 1)
+{
+    const size_t shmem = (size_t)(MCH * 16) * 256 + (size_t)WAVES * MCH * 64 * sizeof(uint32_t);
+    if (shmem * wg_per_cu > 160 * 1024) return false;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(adc_prefilter_reg_kernel<MCH, WAVES>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    const int64_t ntiles = (a.n + 63) / 64;
+    int64_t blocks = (ntiles + WAVES - 1) / WAVES;
+    if (blocks > 256 * wg_per_cu) blocks = 256 * wg_per_cu;
+    hipLaunchKernelGGL((adc_prefilter_reg_kernel<MCH, WAVES>), dim3((unsigned)blocks), dim3(WAVES * 64), shmem, s, a);
+    return true;
 }
 
 // any M (or misaligned codes): lane = row straight from global memory
@@ -402,18 +522,38 @@ __global__ __launch_bounds__(1024) void adc_prefilter_generic_kernel(AdcPreArgs 
     }
 }
 
-template <int MCH, bool QW, int WAVES, int SLOTS, bool HYB = false>
+template <int MCH, bool QW, int WAVES, int SLOTS, bool HYB = false, int NQ = 1>
 static bool try_prefilter(const AdcPreArgs &a, hipStream_t s)
 {
-    const size_t shmem = (size_t)(MCH * 16) * 256 + (size_t)WAVES * SLOTS * 64 * (MCH * 16);
+    const size_t shmem = (size_t)NQ * (MCH * 16) * 256 + (size_t)WAVES * SLOTS * 64 * (MCH * 16);
     if (shmem > 160 * 1024) return false;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(adc_prefilter_kernel<MCH, QW, WAVES, SLOTS, HYB>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(adc_prefilter_kernel<MCH, QW, WAVES, SLOTS, HYB, NQ>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     const int64_t ntiles = (a.n + 63) / 64;
     int64_t blocks = (ntiles + WAVES - 1) / WAVES;
     if (blocks > 256) blocks = 256;
-    hipLaunchKernelGGL((adc_prefilter_kernel<MCH, QW, WAVES, SLOTS, HYB>), dim3((unsigned)blocks), dim3(WAVES * 64), shmem, s, a);
+    hipLaunchKernelGGL((adc_prefilter_kernel<MCH, QW, WAVES, SLOTS, HYB, NQ>), dim3((unsigned)blocks), dim3(WAVES * 64), shmem, s, a);
     return true;
+}
+
+// two queries per pass (see the kernel); false = no two-query form for this M (the caller runs two single passes)
+bool launch_adc_prefilter2(const uint8_t *qtab, const int *params, uint32_t *cand, uint32_t *cand_cnt, const uint8_t *qtab2,
+                           const int *params2, uint32_t *cand2, uint32_t *cand_cnt2, int M, const uint8_t *codes, int64_t n,
+                           uint32_t cand_cap, hipStream_t s)
+{
+    if (n < 4096) return false;
+    AdcPreArgs a{qtab, params, codes, n, cand, cand_cap, cand_cnt, qtab2, params2, cand2, cand_cnt2};
+    const bool vec = (M % 16 == 0) && ((reinterpret_cast<uintptr_t>(codes) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(qtab) & 15) == 0) && ((reinterpret_cast<uintptr_t>(qtab2) & 15) == 0);
+    if (!vec) return false;
+    switch (M / 16) {
+    case 1: return try_prefilter<1, false, 16, 1, false, 2>(a, s);
+    case 2: return try_prefilter<2, false, 16, 1, false, 2>(a, s);
+    case 3: return try_prefilter<3, false, 16, 1, false, 2>(a, s);
+    case 4: return try_prefilter<4, false, 16, 1, false, 2>(a, s);
+    case 6: return try_prefilter<6, false, 16, 1, false, 2>(a, s);
+    default: return false; // (M = 128: two 32 KB tables + 10 slots of 8 KB do not fit beside each other usefully)
+    }
 }
 
 bool launch_adc_prefilter(const uint8_t *qtab, const int *params, int M, const uint8_t *codes, int64_t n,
@@ -435,7 +575,13 @@ bool launch_adc_prefilter(const uint8_t *qtab, const int *params, int M, const u
         case 4: ok = try_prefilter<4, false, 16, 1>(a, s); break;
         case 6:
 #ifdef LB_DIAG
-            if (cfg == 1) ok = try_prefilter<6, false, 11, 2>(a, s);
+            if (cfg == 10) ok = try_prefilter_reg<6, 16>(a, s);
+            else if (cfg == 11) ok = try_prefilter_reg<6, 12>(a, s);
+            else if (cfg == 12) ok = try_prefilter_reg<6, 8>(a, s);
+            else if (cfg == 13) ok = try_prefilter_reg<6, 12>(a, s, 2);
+            else if (cfg == 14) ok = try_prefilter_reg<6, 8>(a, s, 3);
+            else if (cfg == 15) ok = try_prefilter_reg<6, 14>(a, s, 2);
+            else if (cfg == 1) ok = try_prefilter<6, false, 11, 2>(a, s);
             else if (cfg == 2) ok = try_prefilter<6, false, 8, 2>(a, s);
             else if (cfg == 3) ok = try_prefilter<6, false, 12, 1>(a, s);
             else if (cfg == 4) ok = try_prefilter<6, true, 16, 1>(a, s);

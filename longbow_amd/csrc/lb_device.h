@@ -294,6 +294,10 @@ void launch_adc_quantise(const float *table, const float *minrng, int M, const u
 // rows whose lower bound can still pass the slot's threshold -> cand[0..*cand_cnt) (false: M too large for LDS)
 bool launch_adc_prefilter(const uint8_t *qtab, const int *params, int M, const uint8_t *codes, int64_t n,
                           uint32_t *cand, uint32_t cand_cap, uint32_t *cand_cnt, hipStream_t s);
+// two queries in ONE pass over the codes (false: no such form for this M -- run two single passes)
+bool launch_adc_prefilter2(const uint8_t *qtab, const int *params, uint32_t *cand, uint32_t *cand_cnt, const uint8_t *qtab2,
+                           const int *params2, uint32_t *cand2, uint32_t *cand_cnt2, int M, const uint8_t *codes, int64_t n,
+                           uint32_t cand_cap, hipStream_t s);
 void launch_adc_exact_candidates(const float *table, int M, const uint8_t *codes, const uint32_t *cand,
                                  const uint32_t *cand_cnt, uint32_t cand_cap, const int *params, int slot, CandState cs,
                                  hipStream_t s);

@@ -50,6 +50,7 @@ struct lb_gpu_pq {
     // instrumentation (bench.py): HIP events around the main code pass and the whole search of the last query
     std::atomic<int> profiling{0};
     std::atomic<int> prefilter{1}; // 0 = exact f32-table pass only (lb_gpu_pq_set_prefilter; both are exact)
+    std::atomic<int> pair_pass{1}; // 0 = one query per pass over the codes even in batches (A/B, diagnostic build)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float prof_ms[2] = {0.f, 0.f};
     void set_error(const char *fmt, ...)
@@ -105,7 +106,7 @@ struct PqScratch {
     uint8_t *d_qtabs = nullptr;  // [nq][M*256] u8
     float *d_minrng = nullptr;   // [nq][M][4]: subtable minimum, range, bad flag
     int *d_params = nullptr;     // [nq][4]
-    uint32_t *d_cand = nullptr;  // [kCandCap] survivors of the query in flight
+    uint32_t *d_cand = nullptr;  // [2][kCandCap] survivors of the (up to two) queries in flight
     uint32_t *d_cand_cnt = nullptr; // [nq]
     int *d_slots = nullptr;      // 0..nq-1
     uint64_t *d_samp = nullptr;  // ADC entries of the sampled rows
@@ -158,7 +159,7 @@ std::unique_ptr<PqScratch> acquire_scratch(lb_gpu_pq *p, int nq, uint32_t cap, s
         LBP_HIP(hipMalloc(&sc->d_qtabs, nqc * p->M * 256));
         LBP_HIP(hipMalloc(&sc->d_minrng, nqc * p->M * 4 * sizeof(float)));
         LBP_HIP(hipMalloc(&sc->d_params, nqc * 4 * sizeof(int)));
-        LBP_HIP(hipMalloc(&sc->d_cand, (size_t)kCandCap * 4));
+        LBP_HIP(hipMalloc(&sc->d_cand, (size_t)2 * kCandCap * 4));
         LBP_HIP(hipMalloc(&sc->d_cand_cnt, nqc * 4));
         LBP_HIP(hipMalloc(&sc->d_slots, nqc * sizeof(int)));
         LBP_HIP(hipHostMalloc(&sc->h_flags, nqc * 4, hipHostMallocDefault));
@@ -548,20 +549,27 @@ int lb_gpu_pq_search_device_ctx(lb_gpu_pq *p, int64_t nq, const float *d_queries
         }
         launch_build_adc_table(p->d_codebooks, p->M, p->K, p->sub, d_queries, nqi, sc.d_tables, s, prefilter ? sc.d_minrng : nullptr,
                                sc.cs.flags, prefilter ? sc.d_cand_cnt : nullptr); // (also clears the slots' status words)
-        const EmitArgs em{k, nullptr, d_dist, d_labels, nullptr};
+        // the search's last select writes the k results AND the slot's status word into pinned host memory (no D2H copy)
+        const EmitArgs em{k, nullptr, d_dist, d_labels, sc.h_flags};
+        // sampled threshold of one query: sample -> m-th best -> tau (cnt = 0); false = no sampled pass for this search
+        auto threshold = [&](int q) -> bool {
+            const float *tab = sc.d_tables + (size_t)q * p->M * 256;
+            launch_adc_sample(tab, p->M, p->d_codes, p->n, samp_count, sc.d_samp, s);
+            const uint32_t groups = launch_sample_topm(sc.d_samp, samp_count, samp_m, sc.cs, q, s);
+            if (!groups) return false;
+            launch_sample_tau(sc.cs, sc.d_slots + q, 1, groups * (uint32_t)samp_m, samp_m, false, s); // sets tau, cnt = 0
+            return true;
+        };
         // mode 0: sampled threshold (+ byte-table prefilter), 1: bootstrap chunks, 2: chunks that cannot overflow
         auto scan_query = [&](int q, int mode) {
             const float *tab = sc.d_tables + (size_t)q * p->M * 256;
             if (mode == 0 && samp_count) {
-                launch_adc_sample(tab, p->M, p->d_codes, p->n, samp_count, sc.d_samp, s);
-                const uint32_t groups = launch_sample_topm(sc.d_samp, samp_count, samp_m, sc.cs, q, s);
-                if (groups) {
-                    launch_sample_tau(sc.cs, sc.d_slots + q, 1, groups * (uint32_t)samp_m, samp_m, false, s); // sets tau, cnt = 0
-                    const int *skip = nullptr;
+                if (threshold(q)) {
                     if (prefilter) {
                         // rows whose byte-table lower bound cannot pass tau are dropped; the survivors are scored
-                        // exactly.  params.ok == 0 (decided on the device): neither kernel does anything and the
-                        // exact full pass below runs instead.
+                        // exactly.  params.ok == 0 (decided on the device: a table with NaN / negative / infinite
+                        // entries): nothing is admitted, the select below flags the query (fewer than k entries) and
+                        // the host redoes it on the exact schedule.
                         int *prm = sc.d_params + q * 4;
                         uint8_t *qtab = sc.d_qtabs + (size_t)q * p->M * 256;
                         launch_adc_quantise(tab, sc.d_minrng + (size_t)q * p->M * 4, p->M, sc.cs.tau + q, qtab, prm, s);
@@ -570,11 +578,11 @@ int lb_gpu_pq_search_device_ctx(lb_gpu_pq *p, int64_t nq, const float *d_queries
                         if (prof && q == nqi - 1) (void)hipEventRecord(p->ev[3], s);
                         launch_adc_exact_candidates(tab, p->M, p->d_codes, sc.d_cand, sc.d_cand_cnt + q, kCandCap, prm, q,
                                                     sc.cs, s);
-                        skip = prm;
+                    } else {
+                        if (prof && q == nqi - 1) (void)hipEventRecord(p->ev[2], s);
+                        launch_adc_scan(tab, p->M, p->d_codes, 0, p->n, q, nullptr, sc.cs, false, nullptr, 0, s, nullptr);
+                        if (prof && q == nqi - 1) (void)hipEventRecord(p->ev[3], s);
                     }
-                    if (prof && q == nqi - 1 && !prefilter) (void)hipEventRecord(p->ev[2], s);
-                    launch_adc_scan(tab, p->M, p->d_codes, 0, p->n, q, nullptr, sc.cs, false, nullptr, 0, s, skip);
-                    if (prof && q == nqi - 1 && !prefilter) (void)hipEventRecord(p->ev[3], s);
                     // the search's last select also writes the k results (redone queries overwrite them below)
                     launch_select(sc.cs, sc.d_slots + q, 1, k, 0u, s, false, (uint32_t)std::min<int64_t>(k, p->n), &em);
                     return;
@@ -592,10 +600,42 @@ int lb_gpu_pq_search_device_ctx(lb_gpu_pq *p, int64_t nq, const float *d_queries
                 pos = end;
                 step++;
             }
-            if (p->n == 0) launch_emit_lists(sc.cs, sc.d_slots + q, 1, k, nullptr, d_dist, d_labels, nullptr, s);
+            if (p->n == 0) launch_emit_lists(sc.cs, sc.d_slots + q, 1, k, nullptr, d_dist, d_labels, sc.h_flags, s);
+        };
+        // two queries share ONE pass over the codes: thresholds and byte tables for both, then the two-query
+        // prefilter, then the exact survivors and the select of each.  false = not applicable (run them one by one)
+        auto scan_pair = [&](int q) -> bool {
+            if (!prefilter || !samp_count) return false;
+            int *prm[2];
+            uint8_t *qtab[2];
+            for (int j = 0; j < 2; j++) {
+                const int qq = q + j;
+                const float *tab = sc.d_tables + (size_t)qq * p->M * 256;
+                if (!threshold(qq)) return false; // (never after the first of the pair succeeded: same counts)
+                prm[j] = sc.d_params + qq * 4;
+                qtab[j] = sc.d_qtabs + (size_t)qq * p->M * 256;
+                launch_adc_quantise(tab, sc.d_minrng + (size_t)qq * p->M * 4, p->M, sc.cs.tau + qq, qtab[j], prm[j], s);
+            }
+            const bool last = q + 1 == nqi - 1;
+            if (prof && last) (void)hipEventRecord(p->ev[2], s);
+            if (!launch_adc_prefilter2(qtab[0], prm[0], sc.d_cand, sc.d_cand_cnt + q, qtab[1], prm[1], sc.d_cand + kCandCap,
+                                       sc.d_cand_cnt + q + 1, p->M, p->d_codes, p->n, kCandCap, s)) {
+                for (int j = 0; j < 2; j++)
+                    launch_adc_prefilter(qtab[j], prm[j], p->M, p->d_codes, p->n, sc.d_cand + (size_t)j * kCandCap, kCandCap,
+                                         sc.d_cand_cnt + q + j, s);
+            }
+            if (prof && last) (void)hipEventRecord(p->ev[3], s);
+            for (int j = 0; j < 2; j++) {
+                const int qq = q + j;
+                const float *tab = sc.d_tables + (size_t)qq * p->M * 256;
+                launch_adc_exact_candidates(tab, p->M, p->d_codes, sc.d_cand + (size_t)j * kCandCap, sc.d_cand_cnt + qq, kCandCap,
+                                            prm[j], qq, sc.cs, s);
+                launch_select(sc.cs, sc.d_slots + qq, 1, k, 0u, s, false, (uint32_t)std::min<int64_t>(k, p->n), &em);
+            }
+            return true;
         };
         for (int q = 0; q < nqi; q++) {
-            if (ctx && q > 0) { // a cancellable call waits for each query's pass before it enqueues the next (~10 us each)
+            if (ctx && q > 0) { // a cancellable call waits for each pass before it enqueues the next (~10 us each)
                 LBP_HIP(hipStreamSynchronize(s));
                 if (const int st = ctx_state(ctx)) {
                     release_scratch(p, std::move(scp));
@@ -603,10 +643,13 @@ int lb_gpu_pq_search_device_ctx(lb_gpu_pq *p, int64_t nq, const float *d_queries
                     return st;
                 }
             }
+            if (q + 1 < nqi && p->pair_pass.load() != 0 && scan_pair(q)) {
+                q++;
+                continue;
+            }
             scan_query(q, 0);
         }
-        auto read_flags = [&]() {
-            LBP_HIP(hipMemcpyAsync(sc.h_flags, sc.cs.flags, (size_t)nqi * 4, hipMemcpyDeviceToHost, s));
+        auto read_flags = [&]() { // (each query's last select wrote its status word into the pinned h_flags)
             LBP_HIP(hipStreamSynchronize(s));
         };
         read_flags();

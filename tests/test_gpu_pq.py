@@ -221,3 +221,34 @@ def test_prefilter_degenerate_tables(oracle):
     oi, od, cnt = oracle.topk_canonical(d, k)
     assert np.array_equal(lab[1], oi)
     enc.Close()
+
+
+def test_two_queries_per_code_pass_equal_single_passes(oracle):
+    """batches run the byte-table prefilter for TWO queries per pass over the codes; every query's result must equal its
+    own single-query search (and the oracle), for even and odd batch sizes"""
+    gpu_or_skip()
+    from longbow_amd import pq
+    rng = np.random.default_rng(123)
+    M, dims, n, k = 16, 128, 300_000, 20
+    cb = rng.random((M, 256, dims // M), dtype=F)
+    codes = rng.integers(0, 256, (n, M), dtype=np.uint8)
+    enc = pq.PQEncoder(pq.serialize_codebooks(cb))
+    enc.add_codes(codes)
+    Q = rng.random((5, dims), dtype=F)
+    single = [enc.Search(Q[i:i + 1], k) for i in range(5)]
+    for nq in (2, 3, 4, 5):
+        lab, dist = enc.Search(Q[:nq], k)
+        for i in range(nq):
+            assert np.array_equal(lab[i], single[i][0][0]) and np.array_equal(dist[i], single[i][1][0]), (nq, i)
+    for i in (0, 4):
+        d = oracle.adc_batch(oracle.build_adc_table(cb, Q[i]), codes)
+        oi, od, _ = oracle.topk_canonical(d, k)
+        assert np.array_equal(single[i][0][0], oi) and np.array_equal(single[i][1][0], od)
+    # a query whose table the prefilter cannot serve (NaN component) rides in a pair with a healthy one
+    Qb = Q[:2].copy()
+    Qb[1, 3] = np.nan
+    lab, dist = enc.Search(Qb, k)
+    assert np.array_equal(lab[0], single[0][0][0]) and np.array_equal(dist[0], single[0][1][0])
+    lab1, dist1 = enc.Search(Qb[1:2], k)
+    assert np.array_equal(lab[1], lab1[0]) and np.array_equal(dist[1], dist1[0], equal_nan=True)
+    enc.Close()
