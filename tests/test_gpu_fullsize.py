@@ -33,23 +33,30 @@ def test_full_size_batch(oracle, corpus, metric):
     idx.add_device(N, X.data_ptr())
     dist = torch.empty((B, K), device="cuda")
     lab = torch.empty((B, K), dtype=torch.int64, device="cuda")
+    # the library default (LB_CAND_AUTO: split-bf16 candidates on the 256 x 256 tile) ...
     idx.search_device(B, Q.data_ptr(), K, dist.data_ptr(), lab.data_ptr())
     fallbacks = idx.last_fallbacks
     dist_h, lab_h = dist.cpu().numpy(), lab.cpu().numpy()
+    # ... and the strict mode (f32 MFMA candidates, the headline of bench.py): identical lists for ALL 1024 queries
+    idx.set_candidate_mode(0)
+    idx.search_device(B, Q.data_ptr(), K, dist.data_ptr(), lab.data_ptr())
+    assert np.array_equal(lab.cpu().numpy(), lab_h) and np.array_equal(dist.cpu().numpy(), dist_h)
+    fallbacks = max(fallbacks, idx.last_fallbacks)
+    idx.set_candidate_mode(3)
     # properties: ascending, labels unique and in range
     assert np.all(np.diff(dist_h, axis=1) >= 0)
     assert lab_h.min() >= 0 and lab_h.max() < N
     assert all(len(np.unique(r)) == K for r in lab_h[::64])
-    # the batched (MFMA candidate + exact re-rank) path == the exact scan path, bit for bit
-    sub = np.arange(0, B, 128)
-    for s in sub:
-        d1 = torch.empty((1, K), device="cuda")
-        l1 = torch.empty((1, K), dtype=torch.int64, device="cuda")
-        idx.search_device(1, Q[s:s + 1].contiguous().data_ptr(), K, d1.data_ptr(), l1.data_ptr())
-        assert np.array_equal(l1.cpu().numpy()[0], lab_h[s]) and np.array_equal(d1.cpu().numpy()[0], dist_h[s])
-    # oracle on a subsample (scalar CPU restatement: ~1 s per query per core)
+    # the batched (MFMA candidate + exact re-rank) path == the EXACT SCAN path, bit for bit, for ALL 1024 queries
+    # (4 queries per call: below the batched path's minimum, 0.55 ms per call)
+    d4 = torch.empty((4, K), device="cuda")
+    l4 = torch.empty((4, K), dtype=torch.int64, device="cuda")
+    for s in range(0, B, 4):
+        idx.search_device(4, Q[s:s + 4].contiguous().data_ptr(), K, d4.data_ptr(), l4.data_ptr())
+        assert np.array_equal(l4.cpu().numpy(), lab_h[s:s + 4]) and np.array_equal(d4.cpu().numpy(), dist_h[s:s + 4]), s
+    # oracle on 64 queries spread over the batch (scalar CPU restatement: ~1 s per query per core, 16 threads)
     Xh = X.cpu().numpy()
-    qs = np.arange(0, B, 64)
+    qs = np.arange(0, B, 16)
     oi, od = oracle.search_batch(metric, Q.cpu().numpy()[qs], Xh, K, nthreads=16)
     assert np.array_equal(lab_h[qs], oi)
     assert np.array_equal(dist_h[qs], od)
@@ -94,9 +101,15 @@ def test_config3_10m_dot_single_gpu_view(oracle):
         assert res[Bq][0].min() >= 0 and res[Bq][0].max() < rows
     assert np.array_equal(res[256][0][:1], res[1][0]) and np.array_equal(res[256][1][:1], res[1][1])
     Qh = Q.cpu().numpy()
-    for qi in (0, 255):
+    for qi in (0, 37, 74, 111, 148, 185, 222, 255):  # 8 queries against the oracle over all 10M rows
         lab, dist = oracle_topk_rows_parallel(oracle, 2, Qh[qi], Xh, K3, nthreads=16)
-        assert np.array_equal(res[256][0][qi], lab) and np.array_equal(res[256][1][qi], dist)
+        assert np.array_equal(res[256][0][qi], lab) and np.array_equal(res[256][1][qi], dist), qi
+    # every query of the batch against the exact scan path (4 per call)
+    d4 = torch.empty((4, K3), device="cuda")
+    l4 = torch.empty((4, K3), dtype=torch.int64, device="cuda")
+    for s in range(0, 256, 4):
+        idx.search_device(4, Q[s:s + 4].contiguous().data_ptr(), K3, d4.data_ptr(), l4.data_ptr())
+        assert np.array_equal(l4.cpu().numpy(), res[256][0][s:s + 4]) and np.array_equal(d4.cpu().numpy(), res[256][1][s:s + 4]), s
     idx.Close()
 
 
@@ -130,12 +143,15 @@ def test_config4_100m_pq_adc(oracle):
         enc.encode_device(1, one.data_ptr(), dc.data_ptr())
         assert np.array_equal(dc.cpu().numpy()[0], oracle.pq_encode(cb, v)), int(r)
     del buf
-    Q = torch.empty((4, dims), device="cuda")
+    NQ4 = 8
+    Q = torch.empty((NQ4, dims), device="cuda")
     assert lib.lb_gpu_fill_uniform_device(0, Q.data_ptr(), Q.numel(), 42, 0, None) == 0
-    od = torch.empty((4, K4), device="cuda")
-    ol = torch.empty((4, K4), dtype=torch.int64, device="cuda")
-    enc.search_device(4, Q.data_ptr(), K4, od.data_ptr(), ol.data_ptr())
-    lab, dist = ol.cpu().numpy(), od.cpu().numpy()
+    od = torch.empty((NQ4, K4), device="cuda")
+    ol = torch.empty((NQ4, K4), dtype=torch.int64, device="cuda")
+    enc.search_device(NQ4, Q.data_ptr(), K4, od.data_ptr(), ol.data_ptr())  # (two queries per pass over the codes)
+    lab, dist = ol.cpu().numpy().copy(), od.cpu().numpy().copy()
+    enc.search_device(1, Q[5:6].contiguous().data_ptr(), K4, od.data_ptr(), ol.data_ptr())  # a single-query pass agrees
+    assert np.array_equal(ol.cpu().numpy()[0], lab[5]) and np.array_equal(od.cpu().numpy()[0], dist[5])
     assert np.all(np.diff(dist, axis=1) >= 0) and lab.min() >= 0 and lab.max() < n
     assert all(len(np.unique(r)) == K4 for r in lab)
     enc.set_prefilter(False)  # the exact full pass (no byte-table prefilter) returns the same lists
@@ -146,10 +162,10 @@ def test_config4_100m_pq_adc(oracle):
     Qh = Q.cpu().numpy()
     d2, s2 = enc.Rerank(Qh[0], lab[0])
     assert np.array_equal(d2, dist[0])
-    # oracle over ALL 100M codes for two queries (threaded ADC restatement on the downloaded codes)
+    # oracle over ALL 100M codes for every one of the 8 queries (threaded ADC restatement on the downloaded codes)
     codes = enc.get_codes()
     assert codes.shape == (n, M)
-    for qi in (0, 3):
+    for qi in range(NQ4):
         table = oracle.build_adc_table(cb, Qh[qi])
         d = oracle_adc_parallel(oracle, table, codes, nthreads=16)
         oi, odist, cnt = oracle.topk_canonical(d, K4)
