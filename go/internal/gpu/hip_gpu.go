@@ -22,6 +22,7 @@ package gpu
 import "C"
 
 import (
+	"context"
 	"errors"
 	"fmt"
 	"runtime"
@@ -157,6 +158,84 @@ func (idx *HIPIndex) SearchBatch(queries []float32, nq, k int) ([]int64, []float
 	return labels, distances, nil
 }
 
+// SearchBatchContext is SearchBatch under a context.Context: the reference's brute-force loop polls ctx.Err() every
+// 1000 rows (internal/store/adaptive_index.go:182); here the context's cancellation and deadline are handed to the
+// library through an lb_cancel, which it polls before every kernel launch of the search (one launch covers at most
+// one pass over <= 2.5M rows).  Returns ctx.Err() when the search was cut short.
+func (idx *HIPIndex) SearchBatchContext(ctx context.Context, queries []float32, nq, k int) ([]int64, []float32, error) {
+	if err := ctx.Err(); err != nil {
+		return nil, nil, err
+	}
+	idx.mu.RLock()
+	defer idx.mu.RUnlock()
+	if idx.closed {
+		return nil, nil, fmt.Errorf("index is closed")
+	}
+	if nq <= 0 || k <= 0 {
+		return nil, nil, nil
+	}
+	if len(queries) != nq*idx.dim {
+		return nil, nil, fmt.Errorf("query vector dimension %d does not match index dimension %d", len(queries)/max(nq, 1), idx.dim)
+	}
+	cc := C.lb_cancel_new()
+	if cc == nil {
+		return nil, nil, fmt.Errorf("out of memory")
+	}
+	defer C.lb_cancel_free(cc)
+	if dl, ok := ctx.Deadline(); ok {
+		C.lb_cancel_set_deadline_ms(cc, C.int64_t(max(time.Until(dl).Milliseconds(), 0)))
+	}
+	done := make(chan struct{})
+	defer close(done)
+	go func() { // fires the library-side flag when the context ends before the call does
+		select {
+		case <-ctx.Done():
+			C.lb_cancel_fire(cc)
+		case <-done:
+		}
+	}()
+	distances := make([]float32, nq*k)
+	labels := make([]int64, nq*k)
+	rc := C.lb_gpu_index_search_ctx(idx.h, C.int64_t(nq), (*C.float)(unsafe.Pointer(&queries[0])), C.int(k),
+		(*C.float)(unsafe.Pointer(&distances[0])), (*C.int64_t)(unsafe.Pointer(&labels[0])), cc)
+	switch rc {
+	case C.LB_OK:
+		return labels, distances, nil
+	case C.LB_ERR_CANCELLED:
+		return nil, nil, context.Canceled
+	case C.LB_ERR_DEADLINE:
+		return nil, nil, context.DeadlineExceeded
+	}
+	metrics.VectorSearchGPUOperationsTotal.WithLabelValues("search", "error").Inc()
+	return nil, nil, hipError(idx.h, "search", rc)
+}
+
+// SetCandidateMode chooses how batched searches generate candidates (results are identical in every mode):
+// C.LB_CAND_AUTO (default), C.LB_CAND_F32_MFMA (strict), C.LB_CAND_SPLIT_BF16 (corpus image, second copy in HBM),
+// C.LB_CAND_SPLIT_BF16_INREG.
+func (idx *HIPIndex) SetCandidateMode(mode int) error {
+	idx.mu.Lock()
+	defer idx.mu.Unlock()
+	if idx.closed {
+		return fmt.Errorf("index is closed")
+	}
+	if rc := C.lb_gpu_index_set_candidate_mode(idx.h, C.int(mode)); rc != C.LB_OK {
+		return hipError(idx.h, "set_candidate_mode", rc)
+	}
+	return nil
+}
+
+// FusedGiveups reports how many small-batch searches had their in-launch threshold hand-off give up (~1 ms) and were
+// redone on the exact path since the index was created: a latency event for a metrics gauge.
+func (idx *HIPIndex) FusedGiveups() int64 {
+	idx.mu.RLock()
+	defer idx.mu.RUnlock()
+	if idx.closed {
+		return 0
+	}
+	return int64(C.lb_gpu_index_fused_giveups(idx.h))
+}
+
 // SetFilter installs a byte-per-row predicate mask (0 = excluded), e.g. the output of
 // query.FilterEvaluator (internal/query/filter_evaluator.go:79-115).  nil clears it.
 func (idx *HIPIndex) SetFilter(mask []byte) error {
@@ -270,6 +349,9 @@ func (n *NodeIndex) SearchBatch(queries []float32, nq, k int) ([]int64, []float3
 	}
 	if nq <= 0 || k <= 0 {
 		return nil, nil, nil
+	}
+	if dim := n.shards[0].dim; len(queries) != nq*dim { // (checked before &queries[0] goes to C)
+		return nil, nil, fmt.Errorf("query vector dimension %d does not match index dimension %d", len(queries)/nq, dim)
 	}
 	hs := make([]*C.lb_gpu_index, len(n.shards))
 	for i, s := range n.shards {

@@ -166,6 +166,10 @@ int lb_gpu_index_filter_float32(lb_gpu_index *h, const float *column, int64_t n,
 /* Per-search telemetry of the most recent search on this handle (for benches):
  * number of queries that needed the exact-scan fallback. */
 int64_t lb_gpu_index_last_fallbacks(const lb_gpu_index *h);
+/* Cumulative count of small-batch searches (5..32 queries) whose in-launch threshold hand-off gave up after its
+ * ~1 ms bound (the launch's workgroups were not co-resident, e.g. many such launches from many streams at once) and
+ * were redone on the exact path: a latency event worth a metric, never a correctness one. */
+int64_t lb_gpu_index_fused_giveups(const lb_gpu_index *h);
 
 /* Candidate re-rank: the distance step of processChunkInternal
  * (internal/store/parallel_search.go:274-364).  The reference gathers the candidates' vectors into a

@@ -84,6 +84,23 @@ class Index {
         return wrap("search", lb_gpu_index_search(h_, nq, queries, k, distances, ids));
     }
 
+    // SearchBatch under a cancellation context (the ctx of SearchVectors, internal/store/adaptive_index.go:182):
+    // LB_ERR_CANCELLED / LB_ERR_DEADLINE when `ctx` fired or its deadline passed before the search finished
+    Error SearchBatch(const float *queries, int64_t nq, int k, int64_t *ids, float *distances, const lb_cancel *ctx)
+    {
+        std::shared_lock<std::shared_mutex> g(mu_);
+        if (closed_) return {LB_ERR_CLOSED, "index is closed"};
+        return wrap("search", lb_gpu_index_search_ctx(h_, nq, queries, k, distances, ids, ctx));
+    }
+
+    // lb_candidate_mode: LB_CAND_AUTO (default), LB_CAND_F32_MFMA (strict), LB_CAND_SPLIT_BF16[_INREG]; same results
+    Error SetCandidateMode(int mode)
+    {
+        std::unique_lock<std::shared_mutex> g(mu_);
+        if (closed_) return {LB_ERR_CLOSED, "index is closed"};
+        return wrap("set_candidate_mode", lb_gpu_index_set_candidate_mode(h_, mode));
+    }
+
     // The distance step of processChunkInternal (internal/store/parallel_search.go:274-364) on rows that are
     // resident on the GPU: dist[i] as simd.EuclideanDistanceBatchFlat computes it (4-accumulator order),
     // score[i] = 1/(1+dist[i]).  rows are row positions.

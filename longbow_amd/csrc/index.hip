@@ -254,6 +254,7 @@ struct lb_gpu_index {
     std::string last_error;
 
     std::atomic<int64_t> last_fallbacks{0};
+    std::atomic<int64_t> fused_giveups{0}; // fused sample launches whose waits gave up (batch redone on the exact path)
     std::atomic<int> profiling{0};
     std::mutex prof_mu;
     float prof_ms[5] = {0, 0, 0, 0, 0};
@@ -856,6 +857,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         bad.resize((size_t)nq);
         for (int i = 0; i < nq; i++) bad[(size_t)i] = i;
         nbad = nq;
+        h->fused_giveups.fetch_add(1);
         LB_HIP(hipMemsetAsync(w->d_fsync, 0, sizeof(uint32_t), s));
         w->fs_base = 0;
     }
@@ -1473,6 +1475,7 @@ int lb_simd_and_bytes(int device, uint8_t *dst, const uint8_t *src, int64_t n)
 }
 
 int64_t lb_gpu_index_last_fallbacks(const lb_gpu_index *h) { return h ? h->last_fallbacks.load() : 0; }
+int64_t lb_gpu_index_fused_giveups(const lb_gpu_index *h) { return h ? h->fused_giveups.load() : 0; }
 
 int lb_gpu_index_search_device_ctx(lb_gpu_index *h, int64_t nq, const float *d_queries, int k, float *d_dist,
                                    int64_t *d_labels, void *stream, const lb_cancel *ctx)

@@ -77,7 +77,9 @@ void read_fused_probe(unsigned long long out[8], bool reset)
 }
 #endif
 // ---- helpers of the fused sample (FUSED) ---------------------------------------------------------------------
-constexpr uint32_t kSpinLimit = 40000; // x ~0.25 us: a wait that long means the launch's workgroups are not co-resident
+constexpr uint32_t kSpinLimit = 1500; // x ~0.6 us (s_sleep 8 + one L2 round trip) ~ 1 ms: a wait that long means the launch's workgroups are
+                                      // not co-resident; the batch is then redone on the exact path and the give-up is counted
+                                      // (lb_gpu_index_fused_giveups)
 
 // ||q||^2 in the reference's accumulation order (as kernels_scan.hip: exact_sq_norm_lds), q in LDS, one lane
 __device__ __forceinline__ float narrow_exact_sq_norm(const float *sq, int D, int order)
@@ -252,7 +254,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
                 // early look at this workgroup's thresholds (a K-loop ahead of their use): published long ago for all but
                 // the first workgroups of a launch, and the two dependent device-scope loads then cost nothing at the end
                 const int qj = q0 + tid < a.nq ? q0 + tid : a.nq - 1;
-                if (kt == 0) spec_ready = __hip_atomic_load(&a.fs.ready[qj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // (the flag is read with ACQUIRE: pairs with the release store of the threshold workgroup)
+                if (kt == 0) spec_ready = __hip_atomic_load(&a.fs.ready[qj], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
                 if (kt == 3 && spec_ready == a.fs.epoch)
                     spec_tau = __hip_atomic_load(&a.cs.tau[qj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -345,13 +348,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
                 tau = spec_tau;
             } else if (qj < a.nq) {
                 bool ok = false;
-                for (uint32_t it = 0; it < kSpinLimit; it++) {
+                for (uint32_t it = 0; it < kSpinLimit; it++) { // relaxed polls (acquire polls cost 2-3x per hop) ...
                     if (__hip_atomic_load(&a.fs.ready[qj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.fs.epoch) {
                         ok = true;
                         break;
                     }
                     __builtin_amdgcn_s_sleep(8);
                 }
+                // ... and ONE acquire once the flag has matched, in front of the payload load
+                if (ok) ok = __hip_atomic_load(&a.fs.ready[qj], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == a.fs.epoch;
                 if (ok) tau = __hip_atomic_load(&a.cs.tau[qj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 else *a.fs.fail_host = a.fs.epoch; // no threshold in time: the host redoes the batch on the exact path
             }
@@ -597,8 +602,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
         __hip_atomic_store(&a.cs.cnt[j], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&a.cs.tau[j], kth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (!all_in) *a.fs.fail_host = a.fs.epoch;
+        // publish: cnt / tau above, then ready[j] with RELEASE semantics at agent scope; the waiters read ready[j] with
+        // ACQUIRE.  (The asm wait stays: ROCm 7.2 can drop the release fence's own vmcnt wait when the scoreboard looks
+        // empty to it -- MI355X_MICROARCH.md "Compiler hazard".)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(&a.fs.ready[j], a.fs.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&a.fs.ready[j], a.fs.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef LB_DIAG
         atomicMax(&g_fused_probe[1], (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #endif

@@ -217,6 +217,12 @@ class Index:
         return int(self._lib.lb_gpu_index_ntotal(self._h))
 
     @property
+    def fused_giveups(self):
+        """searches whose in-launch threshold hand-off gave up (~1 ms) and were redone exactly (cumulative)"""
+        self._live()
+        return int(self._lib.lb_gpu_index_fused_giveups(self._h))
+
+    @property
     def last_fallbacks(self):
         self._live()
         return int(self._lib.lb_gpu_index_last_fallbacks(self._h))

@@ -153,6 +153,23 @@ static void TestGPUIndex_BatchedMetricsMatchOracle()
             REQUIRE(lab[i] == oi[i], "metric %d entry %zu: id %lld vs %lld", metric, i, (long long)lab[i], (long long)oi[i]);
             REQUIRE(dist[i] == od[i], "metric %d entry %zu: %.9g vs %.9g", metric, i, dist[i], od[i]);
         }
+        // a cancellation context: live -> same results; fired -> LB_ERR_CANCELLED (context.Canceled)
+        lb_cancel *ctx = lb_cancel_new();
+        std::vector<int64_t> lab2(lab.size());
+        std::vector<float> dist2(dist.size());
+        err = idx->SearchBatch(Q.data(), nq, k, lab2.data(), dist2.data(), ctx);
+        REQUIRE(!err && lab2 == lab && dist2 == dist, "search under a live context");
+        lb_cancel_fire(ctx);
+        err = idx->SearchBatch(Q.data(), nq, k, lab2.data(), dist2.data(), ctx);
+        REQUIRE(err.code == LB_ERR_CANCELLED, "fired context: code %d", err.code);
+        lb_cancel_free(ctx);
+        // every candidate mode returns the same lists
+        for (int mode : {LB_CAND_F32_MFMA, LB_CAND_SPLIT_BF16_INREG, LB_CAND_AUTO}) {
+            err = idx->SetCandidateMode(mode);
+            REQUIRE(!err, "%s", err.message.c_str());
+            err = idx->SearchBatch(Q.data(), nq, k, lab2.data(), dist2.data());
+            REQUIRE(!err && lab2 == lab && dist2 == dist, "candidate mode %d", mode);
+        }
     }
     std::printf("ok   TestGPUIndex_BatchedMetricsMatchOracle\n");
 }

@@ -513,10 +513,11 @@ def test_fused_sample_launch_and_its_give_up_path(oracle):
                 lab, dist = idx.SearchBatch(Q[:nq], k)
                 assert_same(lab, dist, want[nq][0], want[nq][1], f"fused metric={metric} nq={nq} rep={rep}")
                 assert idx.last_fallbacks <= nq // 4
+        before = idx.fused_giveups
         lib.lb_debug_fused_fail_next(1)
         lab, dist = idx.SearchBatch(Q[:9], k)
         assert_same(lab, dist, want[9][0], want[9][1], f"fused give-up metric={metric}")
-        assert idx.last_fallbacks == 9
+        assert idx.last_fallbacks == 9 and idx.fused_giveups == before + 1
         lab, dist = idx.SearchBatch(Q[:32], k)
         assert_same(lab, dist, want[32][0], want[32][1], f"fused after give-up metric={metric}")
         assert idx.last_fallbacks <= 8
