@@ -94,8 +94,13 @@ int lb_gpu_index_set_order(lb_gpu_index *h, int order);
  *                      5..384 queries as AUTO.  The headline of bench.py is measured in this mode.
  *   LB_CAND_SPLIT_BF16 the split contraction over a pre-split image of the corpus (x = hi + lo + O(2^-18));
  *                      costs a second N*dim*4-byte copy in HBM; dim % 32 == 0.
- *   LB_CAND_SPLIT_BF16_INREG the in-register split for every batch beyond the narrow tiles (what AUTO picks). */
-typedef enum { LB_CAND_F32_MFMA = 0, LB_CAND_SPLIT_BF16 = 1, LB_CAND_SPLIT_BF16_INREG = 2, LB_CAND_AUTO = 3 } lb_candidate_mode;
+ *   LB_CAND_SPLIT_BF16_INREG the in-register split for every batch beyond the narrow tiles.
+ *   LB_CAND_F16        beyond 64 queries q.x as ONE fp16 product per element (corpus rounded to fp16 in registers, each
+ *                      query scaled by a power of two): a third of the matrix work, error bound ~1.1e-3 |q||x| -- still
+ *                      inside what the containment proof needs on embedding-like data; AUTO takes this route by itself
+ *                      while the corpus norms allow it (max |x| <= 2^13, smallest non-zero |x| >= 2^-6), otherwise the
+ *                      split contraction. */
+typedef enum { LB_CAND_F32_MFMA = 0, LB_CAND_SPLIT_BF16 = 1, LB_CAND_SPLIT_BF16_INREG = 2, LB_CAND_AUTO = 3, LB_CAND_F16 = 4 } lb_candidate_mode;
 int lb_gpu_index_set_candidate_mode(lb_gpu_index *h, int mode);
 int64_t lb_gpu_index_ntotal(const lb_gpu_index *h);
 int lb_gpu_index_dim(const lb_gpu_index *h);

@@ -50,6 +50,8 @@ struct Workspace {
     float *d_qna = nullptr;
     float *d_qs = nullptr; // split-bf16 image of the query batch
     size_t d_qs_bytes = 0;
+    void *d_qh = nullptr;  // fp16 image of the query batch (scaled per query) + [nq] inverse scales behind it
+    size_t d_qh_bytes = 0;
     int *d_qsel = nullptr;
     int *d_iota = nullptr;       // [nq_cap] 0,1,2,...: the slot list of "every query", filled once
     uint32_t *d_smap = nullptr;  // [cap] sampled rows of the first pass
@@ -80,6 +82,7 @@ struct Workspace {
         if (cs.stripes) (void)hipFree(cs.stripes);
         if (d_qna) (void)hipFree(d_qna);
         if (d_qs) (void)hipFree(d_qs);
+        if (d_qh) (void)hipFree(d_qh);
         if (d_qsel) (void)hipFree(d_qsel);
         if (d_iota) (void)hipFree(d_iota);
         if (d_smap) (void)hipFree(d_smap);
@@ -220,6 +223,10 @@ struct lb_gpu_index {
     float *d_norm2 = nullptr, *d_rnorm = nullptr;
     uint32_t *d_maxnorm2 = nullptr;
     bool nonfinite = false; // some row holds an inf / NaN: every search takes the exact scan path
+    bool f16_ok = false;    // row norms within the fp16 single-product contraction's range (kernels_gemm_tall16.hip)
+    // AUTO backs off from the fp16 route on data whose neighbours are too close for its error bound (many queries then
+    // fail the containment proof and are redone by the exact scan): searches left to skip it, and the next back-off span
+    std::atomic<int> f16_skip{0}, f16_span{16};
     int64_t *d_ids = nullptr;
     bool has_ids = false;
     uint8_t *d_mask = nullptr;
@@ -589,7 +596,7 @@ void scan_with_retry(lb_gpu_index *h, Workspace *w, hipStream_t s, const float *
 // Cost model: a pass over `n` positions of dimension D costs  n * (alpha * D + beta) [+ gamma]  per query tile, with
 // the constants measured per kernel on MI355X over D in {128 .. 1536} x n in {100k .. 10M} (tools/route_grid.py; the
 // GPU test test_route_choice_is_near_the_best_forced_route checks the choice against every forced route).
-enum RouteKind { ROUTE_NARROW32 = 1, ROUTE_NARROW64 = 2, ROUTE_TALL = 3, ROUTE_WIDE = 4, ROUTE_TALL2 = 5 };
+enum RouteKind { ROUTE_NARROW32 = 1, ROUTE_NARROW64 = 2, ROUTE_TALL = 3, ROUTE_WIDE = 4, ROUTE_TALL2 = 5, ROUTE_TALL16 = 6 };
 struct Route {
     int kind = ROUTE_WIDE;
     int split = 0;
@@ -612,6 +619,7 @@ constexpr RouteCost kCostTallImage{0.000630, 0.0445, 0.000640, 0.000220};
 constexpr RouteCost kCostTall2Inreg{0.001260, 0.1300, 0.000640, 0.000250}; // per 256-query tile: 3.9 ms at 4M x 768, 1.16 at 4M x 128
 constexpr RouteCost kCostTall2Image{0.001150, 0.1300, 0.000640, 0.000220};
 constexpr RouteCost kCostWideF32{0.001940, 0.0600, 0.000640, 0.0};
+constexpr RouteCost kCostTall16{0.000570, 0.1300, 0.000640, 0.000330};     // per 256-query tile, one fp16 product: 0.57 ms at 1M x 768
 inline double route_ms(const RouteCost &c, int64_t n, int D, int tiles)
 {
     const double nd = 1e-6 * (double)n;
@@ -620,7 +628,7 @@ inline double route_ms(const RouteCost &c, int64_t n, int D, int tiles)
     return (compute > stream ? compute : stream) + nd * (double)D * c.first;
 }
 
-static Route choose_route(int nq, int64_t n, int D, int cmode, bool narrow_ok, bool have_image)
+static Route choose_route(int nq, int64_t n, int D, int cmode, bool narrow_ok, bool have_image, bool f16_ok)
 {
     static const int narrow_max = lb_tunable("LB_NARROW_MAXQ", 384);
     static const bool nsplit_on = lb_tunable("LB_NARROW_SPLIT", 1) != 0;
@@ -649,6 +657,12 @@ static Route choose_route(int nq, int64_t n, int D, int cmode, bool narrow_ok, b
             if (nq > 128 && (tall2_fills || forced)) add(ROUTE_TALL2, 2, route_ms(kCostTall2Inreg, n, D, tiles256));
         }
     }
+    // one fp16 product instead of three bf16 ones (split code 3): AUTO and the explicit LB_CAND_F16, while the corpus norms
+    // allow it (f16_ok) and there are enough tiles to fill the chip
+    static const int f16_on = lb_tunable("LB_F16", 1);
+    if (narrow_ok && f16_ok && f16_on && !image && nq > 64 &&
+        (cmode == LB_CAND_F16 || (cmode == LB_CAND_AUTO && (n / 256) * tiles256 >= 1024)))
+        add(ROUTE_TALL16, 3, route_ms(kCostTall16, n, D, tiles256));
     if (image && !tall_on) add(ROUTE_WIDE, 1, route_ms(kCostWideF32, n, D, tiles128) * 0.4);
     else if (cmode == LB_CAND_F32_MFMA || cmode == LB_CAND_AUTO || nc == 0) add(ROUTE_WIDE, 0, route_ms(kCostWideF32, n, D, tiles128));
 #ifdef LB_DIAG
@@ -660,6 +674,9 @@ static Route choose_route(int nq, int64_t n, int D, int cmode, bool narrow_ok, b
     }
 #endif
     if (cmode == LB_CAND_F32_MFMA && nq > narrow_max) return cand[nc - 1]; // strict mode: the f32 tile beyond the narrow range
+    if (cmode == LB_CAND_F16)
+        for (int i = 0; i < nc; i++)
+            if (cand[i].kind == ROUTE_TALL16) return cand[i];
     if (nq <= 32 && nc > 0 && cand[0].kind == ROUTE_NARROW32) return cand[0]; // one pass of the 32-query tile: nothing is cheaper
     int best = 0;
     for (int i = 1; i < nc; i++)
@@ -668,7 +685,7 @@ static Route choose_route(int nq, int64_t n, int D, int cmode, bool narrow_ok, b
 }
 
 int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, const float *d_q, int k,
-                        float *d_dist, int64_t *d_lab, int kc, bool prof, int64_t &fallbacks)
+                        float *d_dist, int64_t *d_lab, int kc_in, bool prof, int64_t &fallbacks)
 {
     const int metric = h->metric, order = h->order.load();
     const RowView rv = row_view(h);
@@ -693,31 +710,47 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     }
 
     // ---- batched path: MFMA candidate generation + exact re-rank --------------------
+    const int cmode = h->cand_mode.load();
+    const bool have_image = h->d_Xs != nullptr && h->xs_rows == h->n && h->dim % 32 == 0;
+    bool f16_offer = h->f16_ok;
+    if (f16_offer && cmode == LB_CAND_AUTO && h->f16_skip.load(std::memory_order_relaxed) > 0) {
+        h->f16_skip.fetch_sub(1, std::memory_order_relaxed);
+        f16_offer = false;
+    }
+    const Route route = choose_route(nq, n, h->dim, cmode, narrow_ok, have_image, f16_offer);
+#ifdef LB_DIAG
+    g_last_route.store(route.kind * 10 + route.split);
+#endif
+    // candidates kept per query.  The fp16 single-product route keeps twice as many: its keys are good to ~1.1e-3 of |q||x|,
+    // and the containment proof needs the gap between the k-th and the LAST kept candidate to exceed about 2.5x that --
+    // on the benchmark data the gap to the 256th is 0.0019-0.0028 (most queries would fail), to the 512th 0.0039-0.0045.
+    static const int f16_kc_mult = lb_tunable("LB_F16_KC_MULT", 2);
+    int kc = kc_in;
+    if (route.split == 3) kc = std::min(kc_in * f16_kc_mult, (int)(w->cap / 4));
     const SamplePlan sp = sample_plan(n, kc, w->cap);
     // up to 8 queries the sample is scored by the wave-per-row kernel (candidate keys; 22-28 us against
     // 44 us for 8192 rows through the 32-workgroup MFMA launch); larger batches sample through the MFMA
     // kernel itself.  Up to 64 queries the exact query norms ride in the threshold launch.
     // candidate contraction: exact f32 MFMA, or 3 x bf16 MFMA on split operands (choose_route)
-    const int cmode = h->cand_mode.load();
-    const bool have_image = h->d_Xs != nullptr && h->xs_rows == h->n && h->dim % 32 == 0;
-    const Route route = choose_route(nq, n, h->dim, cmode, narrow_ok, have_image);
-#ifdef LB_DIAG
-    g_last_route.store(route.kind * 10 + route.split);
-#endif
     const int split = route.split;                 // of the operands handed to the kernel: 0 f32, 1 images, 2 f32 split in registers
     const bool use_narrow = route.kind == ROUTE_NARROW32 || route.kind == ROUTE_NARROW64;
     const bool tile64 = route.kind == ROUTE_NARROW64;
     const bool nsplit = use_narrow && route.split == 2;
-    const bool use_tall = route.kind == ROUTE_TALL || route.kind == ROUTE_TALL2;
+    const bool use_tall = route.kind == ROUTE_TALL || route.kind == ROUTE_TALL2 || route.kind == ROUTE_TALL16;
     const bool use_tall2 = route.kind == ROUTE_TALL2;
+    const bool use_tall16 = route.kind == ROUTE_TALL16;
     const int wsplit = use_narrow ? 0 : route.split;
     const float *gx = h->d_X, *gq = d_q;
     const float u24 = 5.9604645e-8f;
     // rounding-error bound of the candidate inner products, per unit of ||q|| ||x||: a k-ordered f32 fma chain of
     // length D, or (split contraction) 3D/16 MFMA accumulations + <=16-term block sums plus the dropped lo*lo /
     // residual terms
-    const float gamma = route.split == 0 ? 1.05f * (float)(h->dim + 8) * u24
-                                         : 1.05f * ((float)(3 * h->dim / 16 + 24) * u24 + 3.0f * 3.8146973e-6f);
+    // ... or (split 3) one fp16 product: 2^-11 per operand, the subnormal term under the route's norm conditions, and the
+    // f32 accumulation of D products (kernels_gemm_tall16.hip)
+    const float gamma = route.split == 0   ? 1.05f * (float)(h->dim + 8) * u24
+                        : route.split == 3 ? 1.05f * (9.765625e-4f + 4.7683716e-7f + (float)(h->dim + 8) * u24 +
+                                                      2.9802322e-8f * std::sqrt((float)h->dim) * 65.0f)
+                                           : 1.05f * ((float)(3 * h->dim / 16 + 24) * u24 + 3.0f * 3.8146973e-6f);
     auto split_queries = [&]() { // hi / lo bf16 image of the batch (same bytes as the f32 rows)
         const size_t need = (size_t)nq * h->dim * sizeof(float);
         if (w->d_qs_bytes < need) {
@@ -729,7 +762,20 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         }
         launch_split_bf16(d_q, w->d_qs, nq, h->dim, s);
     };
-    if (!use_narrow && route.split != 0) split_queries(); // the tall / wide split kernels take the batch as an image
+    if (!use_narrow && (route.split == 1 || route.split == 2)) split_queries(); // the tall / wide split kernels take the batch as an image
+    float *d_qinv = nullptr;
+    if (use_tall16) { // fp16 image of the batch (scaled per query) + the inverse scales
+        const size_t img = (((size_t)nq * h->dim * 2) + 255) & ~(size_t)255, need = img + (size_t)nq * sizeof(float);
+        if (w->d_qh_bytes < need) {
+            if (w->d_qh) (void)hipFree(w->d_qh);
+            w->d_qh = nullptr;
+            w->d_qh_bytes = 0;
+            LB_HIP(hipMalloc(&w->d_qh, need));
+            w->d_qh_bytes = need;
+        }
+        d_qinv = reinterpret_cast<float *>(static_cast<char *>(w->d_qh) + img);
+        launch_queries_to_f16(d_q, nq, h->dim, w->d_qh, d_qinv, s);
+    }
     if (!use_narrow && route.split == 1) {
         gx = h->d_Xs;
         gq = w->d_qs;
@@ -752,11 +798,14 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         if (use_narrow)
             launch_gemm_filter_narrow(metric, gx, h->d_norm2, h->d_rnorm, b, e, h->dim, gq, nq, mask, rowmap,
                                       w->cs, boot, s, tile64, nsplit);
-        else if (use_tall && boot && wsplit == 2 && sample_narrow)
+        else if (use_tall && boot && (wsplit == 2 || wsplit == 3) && sample_narrow)
             // the 8192-row sample of a tall-tile search: the 64-query tile of the narrow kernel (same contraction, f32
             // operands) gets through its 24 K-steps of 32 in 31-35 us, the tall tile through its 48 of 16 in 57
             launch_gemm_filter_narrow(metric, h->d_X, h->d_norm2, h->d_rnorm, b, e, h->dim, d_q, nq, mask, rowmap, w->cs,
                                       true, s, /*tile64=*/true, /*split=*/true);
+        else if (use_tall16)
+            launch_gemm_filter_tall16(metric, h->d_X, h->d_norm2, h->d_rnorm, b, e, h->dim, w->d_qh, d_qinv, nq, mask, rowmap,
+                                      w->cs, boot, s);
         else if (use_tall2)
             launch_gemm_filter_tall2(metric, gx, h->d_norm2, h->d_rnorm, b, e, h->dim, w->d_qs, nq, mask, rowmap, w->cs,
                                      boot, wsplit, s);
@@ -860,6 +909,15 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         h->fused_giveups.fetch_add(1);
         LB_HIP(hipMemsetAsync(w->d_fsync, 0, sizeof(uint32_t), s));
         w->fs_base = 0;
+    }
+    if (route.split == 3 && cmode == LB_CAND_AUTO) {
+        if (nbad * 8 > nq) { // the fp16 keys are too coarse for this data: leave the route alone for a while (doubling spans)
+            const int span = h->f16_span.load();
+            h->f16_skip.store(span);
+            h->f16_span.store(std::min(span * 2, 4096));
+        } else if (nbad == 0) {
+            h->f16_span.store(16);
+        }
     }
     if (nbad > 0) {
         fallbacks += (int64_t)bad.size();
@@ -1081,11 +1139,17 @@ void finish_add(lb_gpu_index *h, int64_t n, const int64_t *ids_src, bool ids_on_
         hipLaunchKernelGGL(iota_ids_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->d_ids, start, n);
     }
     LB_HIP(hipMemsetAsync(h->d_mask + start, 1, (size_t)n, s));
-    uint32_t maxbits = 0; // max ||x||^2 so far, as float bits: >= +inf <=> a row with an inf or NaN component
-    LB_HIP(hipMemcpyAsync(&maxbits, h->d_maxnorm2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    uint32_t nbits[2] = {0, 0}; // max ||x||^2 so far, as float bits: >= +inf <=> a row with an inf or NaN component
+    LB_HIP(hipMemcpyAsync(nbits, h->d_maxnorm2, sizeof nbits, hipMemcpyDeviceToHost, s));
     LB_HIP(hipStreamSynchronize(s));
     LB_LAUNCH_CHECK();
+    const uint32_t maxbits = nbits[0];
     h->nonfinite = maxbits >= 0x7f800000u;
+    {   // fp16 single-product candidates: no element may overflow fp16 (|x_i| <= ||x|| <= 2^13) and the smallest non-zero
+        // row norm bounds the subnormal rounding term of the contraction's error bound (>= 2^-6: kernels_gemm_tall16.hip)
+        const float mx = __builtin_bit_cast(float, maxbits), mn = __builtin_bit_cast(float, nbits[1]);
+        h->f16_ok = !h->nonfinite && mx <= 67108864.0f /* 2^26 */ && (nbits[1] == 0x7f800000u || mn >= 0.000244140625f /* 2^-12 */);
+    }
     h->n += n; // the rows are committed from here on: nothing below may fail the call (a retry would duplicate them)
     try {
         sync_split_image(h);
@@ -1239,8 +1303,9 @@ lb_gpu_index *lb_gpu_index_new(int device, int dim, int metric, int *out_status)
     try {
         LB_HIP(hipSetDevice(device));
         LB_HIP(hipStreamCreateWithFlags(&h->add_stream, hipStreamNonBlocking));
-        LB_HIP(hipMalloc(&h->d_maxnorm2, sizeof(uint32_t)));
-        LB_HIP(hipMemset(h->d_maxnorm2, 0, sizeof(uint32_t)));
+        LB_HIP(hipMalloc(&h->d_maxnorm2, 2 * sizeof(uint32_t)));
+        const uint32_t norm_init[2] = {0u, 0x7f800000u}; // max ||x||^2 so far, smallest non-zero ||x||^2 so far (float bits)
+        LB_HIP(hipMemcpy(h->d_maxnorm2, norm_init, sizeof norm_init, hipMemcpyHostToDevice));
         static const int use_vmm = lb_tunable("LB_VMM", 1);
         if (use_vmm) (void)h->vmm.init(device); // on failure: geometric hipMalloc + copy
     } catch (const HipErr &e) {
@@ -1302,10 +1367,10 @@ int lb_gpu_index_set_order(lb_gpu_index *h, int order)
 
 int lb_gpu_index_set_candidate_mode(lb_gpu_index *h, int mode)
 {
-    if (!h || mode < LB_CAND_F32_MFMA || mode > LB_CAND_AUTO) return LB_ERR_INVALID_ARG;
+    if (!h || mode < LB_CAND_F32_MFMA || mode > LB_CAND_F16) return LB_ERR_INVALID_ARG;
     std::unique_lock<std::shared_mutex> g(h->mu);
     if (h->closed) return LB_ERR_CLOSED;
-    if ((mode == LB_CAND_SPLIT_BF16 || mode == LB_CAND_SPLIT_BF16_INREG) && h->dim % 32 != 0) {
+    if ((mode == LB_CAND_SPLIT_BF16 || mode == LB_CAND_SPLIT_BF16_INREG || mode == LB_CAND_F16) && h->dim % 32 != 0) {
         h->set_error("split-bf16 candidates need dim %% 32 == 0 (dim = %d)", h->dim);
         return LB_ERR_UNSUPPORTED;
     }

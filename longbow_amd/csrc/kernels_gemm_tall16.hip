@@ -1,0 +1,421 @@
+// kernels_gemm_tall16.hip -- candidate generation with ONE fp16 MFMA product per (row, query, k): 256 rows x 256 queries
+// per workgroup, the corpus read as f32 and rounded to fp16 in registers, the queries as a pre-scaled fp16 image.
+//
+// Same contract as the other candidate kernels (kernels_gemm_tall2.hip): S = X_tile . Q_tile^T, metric key and admission
+// test fused into the epilogue; ranking semantics of BruteForceIndex.SearchVectors
+// (internal/store/adaptive_index.go:161-225); the keys are CANDIDATE keys only -- every reported distance comes from the
+// exact f32 re-rank, and the re-rank's containment proof (index.hip) decides with THIS contraction's error bound whether
+// the candidate list provably holds the true top-k; a query for which it does not is redone by the exact scan.
+//
+// Why one product is enough.  The split-bf16 contraction (three MFMA products, 2^-17 relative) is far more accurate than the
+// proof needs: it only has to separate the k-th from the kc-th best row (kc = 256 for k = 100), a gap of several 1e-3
+// of |q||x| on embedding-like data.  fp16 operands rounded to nearest carry 2^-11 each, so
+//     | sum fp16(s q_i) fp16(x_i) / s  -  q.x |  <=  (2^-10 + 2^-21) sum|q_i x_i|            (normal range)
+//                                                  + 2^-25 sqrt(D) |q| (1 + |x|)             (subnormal range, see below)
+//                                                  + (D + 8) 2^-24 sum|q_i x_i|              (f32 accumulation)
+// i.e. gamma ~ 1.1e-3 of |q||x| at D = 768 -- inside the gap with a factor to spare (0 fallbacks of 1024 on the benchmark
+// data) -- for ONE third of the matrix work and half the query-side staging bytes of the split contraction.
+//
+// Range.  Each query is scaled by a power of two s so that 1 <= |s q| < 2 (exact; the epilogue multiplies the product by 1/s,
+// also exact), so query elements never overflow and their subnormal rounding (absolute 2^-25) is negligible against |s q| >= 1.
+// Corpus elements are used as they are: the route is offered only while max |x| <= 2^13 (no overflow: fp16 max 65504) and the
+// smallest non-zero row norm is >= 2^-6, which bounds the subnormal term above by 2^-25 sqrt(D) (2^6 + 1) of |q||x|
+// (index.hip tracks both norms at Add).
+//
+// Shape: as kernels_gemm_tall2.hip (8 waves = 4 x 2, a wave owns 64 rows x 128 queries, K-step of 32 = one 128-B line per
+// corpus row) but a stage is 256 x 128 B of corpus + 256 x 64 B of queries = 48 KB, so THREE stages fit (144 KB): the DMA
+// of stage k + 2 is requested at step k and has two whole steps to land, and the wait in front of a step is
+// s_waitcnt vmcnt(6) -- never 0 inside the loop.  16 MFMAs per wave and step.
+#include "lb_device.h"
+
+#include <type_traits>
+
+namespace lb {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int H_BM = 256, H_BN = 256, H_BK = 32;
+constexpr int H_THREADS = 512;
+constexpr int H_A_BYTES = H_BM * H_BK * 4;            // 32 KB: corpus rows as f32
+constexpr int H_B_BYTES = H_BN * H_BK * 2;            // 16 KB: query rows as fp16
+constexpr int H_STAGE_BYTES = H_A_BYTES + H_B_BYTES;  // 48 KB
+constexpr int H_NST = 3;
+constexpr int H_NI = 6; // DMA requests per wave and stage: 4 x 8 corpus rows + 2 x 16 query rows
+
+struct Tall16Args {
+    const float *X;
+    const float *norm2;
+    const float *rnorm;
+    int64_t row_begin, row_end;
+    int D;
+    const _Float16 *Qh;  // [nq][D] fp16 image of the batch, each query scaled by a power of two to 1 <= |q| < 2
+    const float *qinv;   // [nq] 1 / that scale (exact)
+    int nq;
+    const uint8_t *mask;
+    const uint32_t *rowmap;
+    CandState cs;
+    int n_row_tiles, n_q_tiles;
+    int boot;
+};
+
+// corpus rows: 128 B, eight 16-B chunks, chunk c of row r at position c ^ ((r >> 1) & 7)   (byte offset in the A region)
+__device__ __forceinline__ int haswz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// query rows: 64 B, four 16-B chunks, chunk c of row r at position c ^ ((r >> 2) & 3)      (byte offset in the B region)
+__device__ __forceinline__ int hbswz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+// requests behind ONE M0 write; the instruction offset moves the LDS destination and the global address alike (the callers
+// pre-compensate the sources)
+__device__ __forceinline__ void h_dma16x4(const void *g0, const void *g1, const void *g2, const void *g3, uint32_t lds_addr)
+{
+    uint32_t save;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\t"
+                 "global_load_lds_dwordx4 %2, off offset:1024\n\t"
+                 "global_load_lds_dwordx4 %3, off offset:2048\n\t"
+                 "global_load_lds_dwordx4 %4, off offset:3072\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(save) : "v"(g0), "v"(g1), "v"(g2), "v"(g3), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ void h_dma16x2(const void *g0, const void *g1, uint32_t lds_addr)
+{
+    uint32_t save;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\t"
+                 "global_load_lds_dwordx4 %2, off offset:1024\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(save) : "v"(g0), "v"(g1), "s"(lds_addr) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void h_wait_vmcnt()
+{
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+    asm volatile("" ::: "memory");
+}
+
+__device__ __forceinline__ f16x8 h_cvt8(const f32x4 x0, const f32x4 x1)
+{
+    f16x8 r; // round to nearest even (v_cvt_f16_f32 under the default rounding mode)
+    r[0] = (_Float16)x0.x; r[1] = (_Float16)x0.y; r[2] = (_Float16)x0.z; r[3] = (_Float16)x0.w;
+    r[4] = (_Float16)x1.x; r[5] = (_Float16)x1.y; r[6] = (_Float16)x1.z; r[7] = (_Float16)x1.w;
+    return r;
+}
+
+template <int METRIC>
+__global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16_kernel(Tall16Args a)
+{
+    // XCD-aware order as in gemm_filter_kernel: the query tiles of one corpus tile run side by side on one XCD
+    const int b = blockIdx.x;
+    const int xcd = b & 7;
+    const int in_xcd = b >> 3;
+    const int qt = in_xcd % a.n_q_tiles;
+    const int rt = (in_xcd / a.n_q_tiles) * 8 + xcd;
+    if (rt >= a.n_row_tiles) return;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char hlds[];
+    unsigned char *ring = hlds;                                                        // [H_NST][A 32 KB | B 16 KB]
+    float *s_aux = reinterpret_cast<float *>(ring + H_NST * H_STAGE_BYTES);            // [H_BM]
+    uint32_t *s_rowid = reinterpret_cast<uint32_t *>(s_aux + H_BM);                    // [H_BM]
+    uint8_t *s_vis = reinterpret_cast<uint8_t *>(s_rowid + H_BM);                      // [H_BM]
+    const uint32_t ring_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)ring;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1; // 4 x 2 waves: rows 64 wr .. +63, queries 128 wc .. +127
+    const int l31 = lane & 31, h = lane >> 5;
+    const int64_t row0 = a.row_begin + (int64_t)rt * H_BM;
+    const int q0 = qt * H_BN;
+    const int64_t last_row = a.row_end - 1;
+    const int last_q = a.nq - 1;
+
+    auto corpus_row = [&](int64_t pos) -> int64_t {
+        if (pos > last_row) pos = last_row;
+        return a.rowmap ? (int64_t)a.rowmap[pos] : pos;
+    };
+    const int64_t side_ri = corpus_row(row0 + (tid & (H_BM - 1))); // threads 0 .. H_BM-1 carry one side input each
+
+    // DMA sources (byte pointers).  Corpus: request i < 4 of this wave fills rows 32 wave + 8 i .. +7 (lane l: row l / 8, chunk
+    // position l % 8).  Queries: request j < 2 fills rows 32 wave + 16 j .. +15 (lane l: row l / 4, chunk position l % 4).
+    // The instruction offsets of the grouped requests (i KiB) are taken off the sources here.
+    const unsigned char *srcA[4], *srcB[2];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int row = wave * 32 + i * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        srcA[i] = reinterpret_cast<const unsigned char *>(a.X + corpus_row(row0 + row) * (int64_t)a.D) + 16 * c - 1024 * i;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int row = wave * 32 + j * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ ((row >> 2) & 3);
+        int qr = q0 + row;
+        if (qr > last_q) qr = last_q;
+        srcB[j] = reinterpret_cast<const unsigned char *>(a.Qh + (int64_t)qr * a.D) + 16 * c - 1024 * j;
+    }
+    auto issue = [&](int kt) {
+        const uint32_t A = ring_base + (uint32_t)(kt % H_NST) * H_STAGE_BYTES;
+        const uint32_t B = A + H_A_BYTES;
+        const int ka = kt * (H_BK * 4), kb = kt * (H_BK * 2); // byte offsets along a row: f32 corpus, fp16 queries
+        h_dma16x4(srcA[0] + ka, srcA[1] + ka, srcA[2] + ka, srcA[3] + ka, A + (uint32_t)(wave * 32 * 128));
+        h_dma16x2(srcB[0] + kb, srcB[1] + kb, B + (uint32_t)(wave * 32 * 64));
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    const int nk = a.D / H_BK; // D % 32 == 0 (launcher)
+    issue(0);
+    if (nk > 1) issue(1);
+    // one burst behind the first stages (not needed before the epilogue): side inputs, thresholds, query scales
+    const float side_aux = METRIC == METRIC_L2 ? a.norm2[side_ri] : (METRIC == METRIC_COS ? a.rnorm[side_ri] : 0.f);
+    uint8_t side_vis = 1;
+    if (a.mask) side_vis = a.mask[side_ri];
+    float tk[4], qs[4];
+    uint32_t tr[4];
+#pragma unroll
+    for (int tn = 0; tn < 4; tn++) {
+        const int qj = q0 + wc * 128 + tn * 32 + l31;
+        const int qc = qj < a.nq ? qj : a.nq - 1;
+        uint64_t tau = a.boot ? 0ull : a.cs.tau[qc];
+        if (qj >= a.nq) tau = 0ull;
+        tk[tn] = tau_key_of(tau);
+        tr[tn] = entry_row(tau);
+        qs[tn] = a.qinv[qc];
+    }
+    if (tid < H_BM) {
+        s_aux[tid] = side_aux;
+        s_vis[tid] = (row0 + tid <= last_row && side_vis) ? (uint8_t)1 : (uint8_t)0;
+        s_rowid[tid] = (uint32_t)side_ri;
+    }
+    // (the loads above were waited for by the compiler before their use; from here on only the DMA requests are in flight,
+    // H_NI per wave and stage, and the compiler sees none of them)
+
+    for (int kt = 0; kt < nk; kt++) {
+        // stage kt has landed once at most the requests of stage kt + 1 are outstanding
+        if (kt + 1 < nk) h_wait_vmcnt<H_NI>();
+        else h_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier(); // everyone's part of stage kt is in; everyone is done reading stage kt - 1
+        asm volatile("" ::: "memory");
+        if (kt + 2 < nk) issue(kt + 2); // into the slot read at step kt - 1
+        const unsigned char *As = ring + (kt % H_NST) * H_STAGE_BYTES;
+        const unsigned char *Bs = As + H_A_BYTES;
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++) { // the stage's two MFMA k-blocks of 16
+            f16x8 af[2];
+#pragma unroll
+            for (int tm = 0; tm < 2; tm++) {
+                const int r = wr * 64 + tm * 32 + l31;
+                // lane half h supplies k = 16 kb + 8 h .. + 7: f32 chunks 4 kb + 2 h and the next
+                const f32x4 x0 = *reinterpret_cast<const f32x4 *>(As + haswz(r, 4 * kb + 2 * h));
+                const f32x4 x1 = *reinterpret_cast<const f32x4 *>(As + haswz(r, 4 * kb + 2 * h + 1));
+                af[tm] = h_cvt8(x0, x1);
+            }
+#pragma unroll
+            for (int tn = 0; tn < 4; tn++) {
+                const int r = wc * 128 + tn * 32 + l31;
+                // 8 fp16 = one 16-B chunk: k = 16 kb + 8 h .. + 7 is chunk 2 kb + h of the 64-B row
+                const f16x8 bf = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4 *>(Bs + hbswz(r, 2 * kb + h)));
+#pragma unroll
+                for (int tm = 0; tm < 2; tm++)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tm], bf, acc[tm][tn], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: key + admission, one MFMA row tile (this lane's 16 rows of it) at a time ----------------
+    // C layout (32x32): col = lane & 31 (query), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+    // dot = acc * qs (the query's scale taken back out: exact, a power of two)
+    auto key_of = [&](float acc_v, float qsc, float ax) -> float {
+        const float dot = acc_v * qsc;
+        if (METRIC == METRIC_L2) return fmaf(-2.0f, dot, ax);
+        if (METRIC == METRIC_COS) return -dot * ax;
+        return -dot;
+    };
+    // workgroup-local admission list, carved from the ring (free: every wave is past the last K-step's reads once the
+    // barrier below is behind it)
+    constexpr int FL_CAP = 4096;
+    float *ringf = reinterpret_cast<float *>(ring);
+    uint32_t *s_lcnt = reinterpret_cast<uint32_t *>(ringf);             // entries in the list
+    uint32_t *s_qcnt = s_lcnt + 1;                                      // [H_BN] of them per query of the tile ...
+    uint32_t *s_qbase = s_qcnt + H_BN;                                  // [H_BN] ... and where they start in the query's list
+    uint64_t *s_lent = reinterpret_cast<uint64_t *>(ringf + 1024);
+    uint16_t *s_lq = reinterpret_cast<uint16_t *>(ringf + 1024 + 2 * FL_CAP);
+    uint16_t *s_lr = s_lq + FL_CAP;                                     // rank of the entry among its query's
+    __syncthreads();
+    if (tid == 0) *s_lcnt = 0;
+    if (tid < H_BN) s_qcnt[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int tm = 0; tm < 2; tm++) {
+        float aux[4][4];
+        uint32_t rid[4][4];
+        uint32_t vbits = 0; // bit (g*4 + e): row visible (in range and not masked out)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int lr = wr * 64 + tm * 32 + 8 * g + 4 * h; // 4 consecutive local rows
+            const f32x4 av = *reinterpret_cast<const f32x4 *>(&s_aux[lr]);
+            const uint4 rv = *reinterpret_cast<const uint4 *>(&s_rowid[lr]);
+            const uint32_t vv = *reinterpret_cast<const uint32_t *>(&s_vis[lr]);
+            aux[g][0] = av.x; aux[g][1] = av.y; aux[g][2] = av.z; aux[g][3] = av.w;
+            rid[g][0] = rv.x; rid[g][1] = rv.y; rid[g][2] = rv.z; rid[g][3] = rv.w;
+            const uint32_t nib = (vv & 1u) | ((vv >> 7) & 2u) | ((vv >> 14) & 4u) | ((vv >> 21) & 8u);
+            vbits |= nib << (g * 4);
+        }
+#pragma unroll
+        for (int tn = 0; tn < 4; tn++) {
+            const int qj = q0 + wc * 128 + tn * 32 + l31;
+            const bool qok = qj < a.nq;
+            uint64_t *list = a.cs.lists + (size_t)(qok ? qj : 0) * a.cs.cap;
+            if (a.boot) { // sample pass: the entry of position p goes to list[p - row_begin]
+                if (qok) {
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        const int64_t rbase = row0 + wr * 64 + tm * 32 + 8 * g + 4 * h;
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            if (rbase + e < a.row_end)
+                                list[rbase + e - a.row_begin] =
+                                    ((vbits >> (g * 4 + e)) & 1u)
+                                        ? pack_entry(key_of(acc[tm][tn][4 * g + e], qs[tn], aux[g][e]), rid[g][e])
+                                        : kEntryMax;
+                    }
+                }
+                continue;
+            }
+            // entry < tau  <=>  key < tau_key, or equal keys and a lower row (a padded query's tau decodes to NaN)
+            uint32_t bits = 0;
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float key = key_of(acc[tm][tn][4 * g + e], qs[tn], aux[g][e]);
+                    const uint32_t lt = (uint32_t)(key < tk[tn]) | ((uint32_t)(key == tk[tn]) & (uint32_t)(rid[g][e] < tr[tn]));
+                    bits |= lt << (g * 4 + e);
+                }
+            bits &= vbits;
+            if (bits) { // workgroup-local list first: two LDS atomics per lane with admissions
+                const uint32_t n = (uint32_t)__builtin_popcount(bits);
+                uint32_t lp = atomicAdd(s_lcnt, n);
+                if (lp + n <= (uint32_t)FL_CAP) {
+                    uint32_t lr = atomicAdd(&s_qcnt[qj - q0], n);
+#pragma unroll
+                    for (int g = 0; g < 4; g++)
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            if (bits & (1u << (g * 4 + e))) {
+                                s_lent[lp] = pack_entry(key_of(acc[tm][tn][4 * g + e], qs[tn], aux[g][e]), rid[g][e]);
+                                s_lq[lp] = (uint16_t)(qj - q0);
+                                s_lr[lp] = (uint16_t)lr;
+                                lp++;
+                                lr++;
+                            }
+                    bits = 0;
+                } else {
+                    for (uint32_t i = lp; i < lp + n && i < (uint32_t)FL_CAP; i++) s_lent[i] = kEntryMax; // reserved, unused
+                }
+            }
+            if (bits) { // (local list full) one returning atomic reserves the lane's slots; the stores are fire-and-forget
+                uint32_t pos = atomicAdd(&a.cs.cnt[qj], (uint32_t)__builtin_popcount(bits));
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        if (bits & (1u << (g * 4 + e))) {
+                            if (pos < a.cs.cap)
+                                list[pos] = pack_entry(key_of(acc[tm][tn][4 * g + e], qs[tn], aux[g][e]), rid[g][e]);
+                            pos++;
+                        }
+            }
+        }
+    }
+    if (!a.boot) { // flush the workgroup-local admissions: ONE returning global atomic per query of the tile, all in flight
+        __syncthreads();
+        if (tid < H_BN) {
+            const uint32_t n = s_qcnt[tid];
+            s_qbase[tid] = n ? atomicAdd(&a.cs.cnt[q0 + tid], n) : 0u; // (n != 0 implies a real query)
+        }
+        __syncthreads();
+        const uint32_t total = *s_lcnt < (uint32_t)FL_CAP ? *s_lcnt : (uint32_t)FL_CAP;
+        for (uint32_t i = tid; i < total; i += H_THREADS) {
+            const uint64_t ent = s_lent[i];
+            if (ent == kEntryMax) continue;
+            const int ql = (int)s_lq[i];
+            const uint32_t pos = s_qbase[ql] + (uint32_t)s_lr[i];
+            if (pos < a.cs.cap) a.cs.lists[(size_t)(q0 + ql) * a.cs.cap + pos] = ent;
+        }
+    }
+}
+
+// f32 [nq][D] -> fp16 [nq][D], each query scaled by the power of two that brings its norm into [1, 2); qinv[q] = 1 / scale.
+// One wave per query.  (A zero or non-finite query keeps scale 1: its search is answered by the exact scan anyway.)
+__global__ __launch_bounds__(256) void queries_to_f16_kernel(const float *Q, int nq, int D, _Float16 *Qh, float *qinv)
+{
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const float *src = Q + (int64_t)q * D;
+    float s = 0.f;
+    for (int i = lane; i < D; i += 64) s += src[i] * src[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    float scale = 1.f, inv = 1.f;
+    if (s > 0.f && s < 3.0e38f) {
+        const float nrm = sqrtf(s);
+        int e;
+        (void)frexpf(nrm, &e);       // nrm = m * 2^e, 0.5 <= m < 1  ->  nrm * 2^(1 - e) in [1, 2)
+        int sh = 1 - e;
+        sh = sh < -120 ? -120 : (sh > 120 ? 120 : sh);
+        scale = ldexpf(1.f, sh);
+        inv = ldexpf(1.f, -sh);
+    }
+    _Float16 *dst = Qh + (int64_t)q * D;
+    for (int i = lane; i < D; i += 64) dst[i] = (_Float16)(src[i] * scale);
+    if (lane == 0) qinv[q] = inv;
+}
+
+} // namespace
+
+void launch_queries_to_f16(const float *Q, int nq, int D, void *Qh, float *qinv, hipStream_t s)
+{
+    if (nq <= 0) return;
+    hipLaunchKernelGGL(queries_to_f16_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, Q, nq, D,
+                       reinterpret_cast<_Float16 *>(Qh), qinv);
+}
+
+// Requires D % 32 == 0, 16-B aligned X / Qh; Qh / qinv from launch_queries_to_f16; X is the plain f32 corpus.
+void launch_gemm_filter_tall16(int metric, const float *X, const float *norm2, const float *rnorm, int64_t row_begin,
+                               int64_t row_end, int D, const void *Qh, const float *qinv, int nq, const uint8_t *mask,
+                               const uint32_t *rowmap, CandState cs, bool boot, hipStream_t s)
+{
+    if (row_end <= row_begin || nq <= 0) return;
+    Tall16Args a;
+    a.rowmap = rowmap;
+    a.X = X; a.norm2 = norm2; a.rnorm = rnorm; a.row_begin = row_begin; a.row_end = row_end; a.D = D;
+    a.Qh = reinterpret_cast<const _Float16 *>(Qh); a.qinv = qinv; a.nq = nq; a.mask = mask; a.cs = cs; a.boot = boot ? 1 : 0;
+    a.n_row_tiles = (int)((row_end - row_begin + H_BM - 1) / H_BM);
+    a.n_q_tiles = (nq + H_BN - 1) / H_BN;
+    const int groups = (a.n_row_tiles + 7) / 8;
+    dim3 grid((unsigned)(groups * 8 * a.n_q_tiles));
+    const size_t shmem = (size_t)H_NST * H_STAGE_BYTES + H_BM * 4 + H_BM * 4 + H_BM;
+#define LB_TALL16(M)                                                                                             \
+    do {                                                                                                         \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_filter_tall16_kernel<M>),                 \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); /* per device */      \
+        hipLaunchKernelGGL((gemm_filter_tall16_kernel<M>), grid, dim3(H_THREADS), shmem, s, a);                  \
+    } while (0)
+    if (metric == METRIC_L2) LB_TALL16(METRIC_L2);
+    else if (metric == METRIC_COS) LB_TALL16(METRIC_COS);
+    else LB_TALL16(METRIC_DOT);
+#undef LB_TALL16
+}
+
+} // namespace lb

@@ -278,23 +278,30 @@ __global__ __launch_bounds__(W_THREADS, 2) void gemm_filter_tall2_kernel(Tall2Ar
 #endif
         const float *As = ring + (kt & 1) * W_STAGE_F;
         const float *Bs = As + W_BM * W_BK;
-#pragma unroll
-        for (int kb = 0; kb < 2; kb++) { // the stage's two MFMA k-blocks of 16
-            // both corpus fragments of the k-block first (split once, used by all four query tiles), then the query
-            // fragments one tile at a time: 16 + 8 fragment registers live instead of 8 + 32
-            bf16x8 ah[2], al[2];
+        // The stage's two MFMA k-blocks of 16.  Per k-block: both corpus fragments (split once, used by all four query
+        // tiles), then the query fragments one tile at a time (16 + 8 fragment registers live instead of 8 + 32).  The
+        // second k-block's corpus fragments are fetched and split BEHIND the first query tile of the first k-block, so
+        // that their ~50 conversion instructions issue between that k-block's MFMAs (which leave three quarters of the
+        // vector issue slots free) instead of in front of the second k-block, where both waves of the SIMD would sit
+        // through them at the same time.
+        bf16x8 ah[2][2], al[2][2];
+        auto load_a = [&](int kb) {
 #pragma unroll
             for (int tm = 0; tm < 2; tm++) {
                 const int r = wr * 64 + tm * 32 + l31;
                 if (ASPLIT == 1) {
-                    ah[tm] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(&As[wswz(r, 4 * kb + h)]));
-                    al[tm] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(&As[wswz(r, 4 * kb + 2 + h)]));
+                    ah[kb][tm] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(&As[wswz(r, 4 * kb + h)]));
+                    al[kb][tm] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(&As[wswz(r, 4 * kb + 2 + h)]));
                 } else {
                     const f32x4 x0 = *reinterpret_cast<const f32x4 *>(&As[wswz(r, 4 * kb + 2 * h)]);
                     const f32x4 x1 = *reinterpret_cast<const f32x4 *>(&As[wswz(r, 4 * kb + 2 * h + 1)]);
-                    w_split8(x0, x1, ah[tm], al[tm]);
+                    w_split8(x0, x1, ah[kb][tm], al[kb][tm]);
                 }
             }
+        };
+        load_a(0);
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++) {
 #pragma unroll
             for (int tn = 0; tn < 4; tn++) {
                 const int r = wc * 128 + tn * 32 + l31;
@@ -302,10 +309,11 @@ __global__ __launch_bounds__(W_THREADS, 2) void gemm_filter_tall2_kernel(Tall2Ar
                 const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(&Bs[wswz(r, 4 * kb + 2 + h)]));
 #pragma unroll
                 for (int tm = 0; tm < 2; tm++) {
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh, acc[tm][tn], 0, 0, 0);
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl, acc[tm][tn], 0, 0, 0);
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh, acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[kb][tm], bh, acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kb][tm], bl, acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kb][tm], bh, acc[tm][tn], 0, 0, 0);
                 }
+                if (kb == 0 && tn == 0) load_a(1);
             }
         }
     };

@@ -869,6 +869,8 @@ __global__ __launch_bounds__(256) void row_norms_kernel(const float *X, int64_t 
         // serialise the whole kernel on a single address.
         const uint32_t bits = __builtin_bit_cast(uint32_t, s);
         if (bits > __hip_atomic_load(maxnorm2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(maxnorm2, bits);
+        // [1]: the smallest non-zero norm (zero rows are exact under every contraction: they do not count)
+        if (s > 0.f && bits < __hip_atomic_load(maxnorm2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(maxnorm2 + 1, bits);
     }
 }
 

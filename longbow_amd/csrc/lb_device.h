@@ -143,7 +143,8 @@ __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
 // Launchers (implemented in kernels_*.hip).  All are asynchronous on `s`.
 // ---------------------------------------------------------------------------
 
-// per-row ||x||^2 and 1/||x|| (0 if the norm is 0); max ||x||^2 folded into *d_maxnorm2 (float bits)
+// per-row ||x||^2 and 1/||x|| (0 if the norm is 0); max ||x||^2 folded into d_maxnorm2[0], the smallest NON-ZERO ||x||^2
+// into d_maxnorm2[1] (float bits; initialise to {0, 0x7f800000})
 void launch_row_norms(const float *X, int64_t n, int D, float *norm2, float *rnorm,
                       uint32_t *d_maxnorm2, hipStream_t s);
 
@@ -194,6 +195,13 @@ void launch_gemm_filter_tall(int metric, const float *X, const float *norm2, con
 void launch_gemm_filter_tall2(int metric, const float *X, const float *norm2, const float *rnorm, int64_t row_begin,
                               int64_t row_end, int D, const float *Qs, int nq, const uint8_t *mask, const uint32_t *rowmap,
                               CandState cs, bool boot, int asplit, hipStream_t s);
+
+// ONE fp16 product per (row, query, k) on 256 x 256 tiles (kernels_gemm_tall16.hip): Qh / qinv from launch_queries_to_f16
+// (fp16 image of the batch, each query scaled by a power of two to a norm in [1, 2); qinv = 1 / scale); X = f32 corpus
+void launch_queries_to_f16(const float *Q, int nq, int D, void *Qh, float *qinv, hipStream_t s);
+void launch_gemm_filter_tall16(int metric, const float *X, const float *norm2, const float *rnorm, int64_t row_begin,
+                               int64_t row_end, int D, const void *Qh, const float *qinv, int nq, const uint8_t *mask,
+                               const uint32_t *rowmap, CandState cs, bool boot, hipStream_t s);
 
 // per query: sort the list, keep the best kc, tau = kc-th entry (or max), flag overflow.
 // qsel (nullable): only these query slots.  boot_rows > 0: the list was filled by a bootstrap

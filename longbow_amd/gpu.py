@@ -164,7 +164,7 @@ class Index:
 
     def set_candidate_mode(self, mode):
         """lb_candidate_mode: 3 = AUTO (default: cheapest exact route), 0 = strict f32 MFMA beyond 384 queries,
-        1 = split-bf16 corpus image, 2 = split in registers; results identical in every mode"""
+        1 = split-bf16 corpus image, 2 = split in registers, 4 = one fp16 product; results identical in every mode"""
         self._live()
         _lib.check(self._lib.lb_gpu_index_set_candidate_mode(self._h, int(mode)), self._h, lib=self._lib)
 

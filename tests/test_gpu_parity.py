@@ -421,7 +421,7 @@ def test_split_bf16_candidates_give_identical_results(oracle, metric):
         labb, distb = idx.SearchBatch(big, k)
         assert np.array_equal(labb[:nq], lab) and np.array_equal(distb[:nq], dist)
         assert np.array_equal(labb[nq:2 * nq], lab[: min(nq, 400 - nq)]) if 2 * nq <= 400 else True
-        for mode in (0, 3):                # strict f32 beyond 384 queries; AUTO (the default)
+        for mode in (0, 3, 4):             # strict f32 beyond 384 queries; AUTO (the default); one fp16 product
             idx.set_candidate_mode(mode)
             lab0, dist0 = idx.SearchBatch(Q, k)
             assert np.array_equal(lab0, lab) and np.array_equal(dist0, dist)
@@ -452,7 +452,7 @@ def test_tall_tile_every_route(oracle, metric):
     want = {}
     for nq in (70, 200, 384, 512):
         want[nq] = oracle.search_batch(metric, Q[:nq], X, k, nthreads=8)
-    for mode in (3, 0, 1, 2):                     # 3 = AUTO, what a fresh index runs
+    for mode in (3, 0, 1, 2, 4):                  # 3 = AUTO, what a fresh index runs; 4 = one fp16 product
         idx.set_candidate_mode(mode)
         for nq in (70, 200, 384, 512):            # 512 in mode 1: the 256-query tile
             lab, dist = idx.SearchBatch(Q[:nq], k)
@@ -461,7 +461,7 @@ def test_tall_tile_every_route(oracle, metric):
         mask = (rng.random(n) < frac).astype(np.uint8)
         idx.set_filter(mask)
         oi, od = oracle.search_batch(metric, Q[:130], X, k, mask=mask, nthreads=8)
-        for mode in (3, 0, 1):
+        for mode in (3, 0, 1, 4):
             idx.set_candidate_mode(mode)
             for nq in (130, 512):
                 lab, dist = idx.SearchBatch(Q[:nq], k)
@@ -552,4 +552,39 @@ def test_growth_survives_a_refused_mapping(oracle):
         lab, dist = idx.SearchBatch(qs, k)
         oi, od = oracle.search_batch(0, qs, X, k, ids=ids)
         assert_same(lab, dist, oi, od, "after the forced migration")
+    idx.Close()
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_fp16_route_on_hostile_data_stays_exact_and_backs_off(oracle, metric):
+    """one fp16 product per element is only as good as ~1e-3 of |q||x|: on a corpus of tight clusters the containment proof
+    fails for most queries, which are then redone by the exact scan (results stay bit-equal to the oracle), and AUTO stops
+    offering the route for a while; norms outside the fp16 range switch it off altogether"""
+    gpu_or_skip()
+    rng = np.random.default_rng(900 + metric)
+    n, d, k = 300_000, 64, 30
+    centers = rng.standard_normal((300, d)).astype(F)
+    X = (centers[rng.integers(0, 300, n)] + F(2e-4) * rng.standard_normal((n, d)).astype(F)).astype(F)
+    Q = (centers[rng.integers(0, 300, 200)] + F(1e-3) * rng.standard_normal((200, d)).astype(F)).astype(F)
+    oi, od = oracle.search_batch(metric, Q, X, k, nthreads=8)
+    idx = new_index(d, metric)
+    idx.Add(None, X)
+    idx.set_candidate_mode(4)
+    lab, dist = idx.SearchBatch(Q, k)
+    assert_same(lab, dist, oi, od, f"fp16 forced, clustered, metric={metric}")
+    idx.set_candidate_mode(3)
+    for rep in range(4):  # AUTO: the first call may take the fp16 route and fall back, later calls leave it alone
+        lab, dist = idx.SearchBatch(Q, k)  # (clusters this tight defeat every approximate key: exact scans either way)
+        assert_same(lab, dist, oi, od, f"auto, clustered, metric={metric} rep={rep}")
+    idx.Close()
+    # a corpus whose norms leave the fp16 range: the route is never offered, results exact
+    Xb = (rng.standard_normal((100_000, d)) * 3e4).astype(F)
+    Qb = rng.standard_normal((130, d)).astype(F)
+    idx = new_index(d, metric)
+    idx.Add(None, Xb)
+    for mode in (4, 3):
+        idx.set_candidate_mode(mode)
+        lab, dist = idx.SearchBatch(Qb, k)
+        oi, od = oracle.search_batch(metric, Qb, Xb, k, nthreads=8)
+        assert_same(lab, dist, oi, od, f"out-of-range norms, mode={mode}, metric={metric}")
     idx.Close()

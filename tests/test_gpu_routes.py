@@ -49,7 +49,7 @@ def test_route_choice_is_near_the_best_forced_route(D, n):
             picked = raw.lb_debug_last_route() // 10
             want = (ol.cpu().numpy().copy(), od.cpu().numpy().copy())
             forced = {}
-            for r in (1, 2, 3, 5):  # narrow32, narrow64, tall, tall2 (the f32 tile is never competitive: tools/route_grid.py)
+            for r in (1, 2, 3, 5, 6):  # narrow32, narrow64, tall, tall2, tall16 (the f32 tile is never competitive: tools/route_grid.py)
                 os.environ["LB_FORCE_ROUTE"] = str(r)
                 idx.search_device(B, Q.data_ptr(), K, od.data_ptr(), ol.data_ptr())
                 if raw.lb_debug_last_route() // 10 != r:
