@@ -69,16 +69,26 @@ __device__ __forceinline__ int hbswz(int row, int chunk) { return row * 64 + ((c
 
 // requests behind ONE M0 write; the instruction offset moves the LDS destination and the global address alike (the callers
 // pre-compensate the sources)
+template <bool NT>
 __device__ __forceinline__ void h_dma16x4(const void *g0, const void *g1, const void *g2, const void *g3, uint32_t lds_addr)
 {
     uint32_t save;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, off\n\t"
-                 "global_load_lds_dwordx4 %2, off offset:1024\n\t"
-                 "global_load_lds_dwordx4 %3, off offset:2048\n\t"
-                 "global_load_lds_dwordx4 %4, off offset:3072\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(save) : "v"(g0), "v"(g1), "v"(g2), "v"(g3), "s"(lds_addr) : "memory");
+    if (NT) // non-temporal: a corpus line that only this workgroup will read (one or two query tiles per corpus tile)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off nt\n\t"
+                     "global_load_lds_dwordx4 %2, off offset:1024 nt\n\t"
+                     "global_load_lds_dwordx4 %3, off offset:2048 nt\n\t"
+                     "global_load_lds_dwordx4 %4, off offset:3072 nt\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(save) : "v"(g0), "v"(g1), "v"(g2), "v"(g3), "s"(lds_addr) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\t"
+                     "global_load_lds_dwordx4 %2, off offset:1024\n\t"
+                     "global_load_lds_dwordx4 %3, off offset:2048\n\t"
+                     "global_load_lds_dwordx4 %4, off offset:3072\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(save) : "v"(g0), "v"(g1), "v"(g2), "v"(g3), "s"(lds_addr) : "memory");
 }
 __device__ __forceinline__ void h_dma16x2(const void *g0, const void *g1, uint32_t lds_addr)
 {
@@ -104,7 +114,8 @@ __device__ __forceinline__ f16x8 h_cvt8(const f32x4 x0, const f32x4 x1)
     return r;
 }
 
-template <int METRIC>
+// NT: the corpus requests carry the non-temporal policy (few query tiles per corpus tile: the line is not read again)
+template <int METRIC, bool NT>
 __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16_kernel(Tall16Args a)
 {
     // XCD-aware order as in gemm_filter_kernel: the query tiles of one corpus tile run side by side on one XCD
@@ -160,7 +171,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16_kernel(Tall16
         const uint32_t A = ring_base + (uint32_t)(kt % H_NST) * H_STAGE_BYTES;
         const uint32_t B = A + H_A_BYTES;
         const int ka = kt * (H_BK * 4), kb = kt * (H_BK * 2); // byte offsets along a row: f32 corpus, fp16 queries
-        h_dma16x4(srcA[0] + ka, srcA[1] + ka, srcA[2] + ka, srcA[3] + ka, A + (uint32_t)(wave * 32 * 128));
+        h_dma16x4<NT>(srcA[0] + ka, srcA[1] + ka, srcA[2] + ka, srcA[3] + ka, A + (uint32_t)(wave * 32 * 128));
         h_dma16x2(srcB[0] + kb, srcB[1] + kb, B + (uint32_t)(wave * 32 * 64));
     };
 
@@ -406,15 +417,23 @@ void launch_gemm_filter_tall16(int metric, const float *X, const float *norm2, c
     const int groups = (a.n_row_tiles + 7) / 8;
     dim3 grid((unsigned)(groups * 8 * a.n_q_tiles));
     const size_t shmem = (size_t)H_NST * H_STAGE_BYTES + H_BM * 4 + H_BM * 4 + H_BM;
-#define LB_TALL16(M)                                                                                             \
+    static const int nt_max_tiles = lb_tunable("LB_F16_NT_MAXTILES", 1);
+    const bool nt = a.n_q_tiles <= nt_max_tiles;
+#define LB_TALL16(M, N)                                                                                          \
     do {                                                                                                         \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_filter_tall16_kernel<M>),                 \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_filter_tall16_kernel<M, N>),              \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); /* per device */      \
-        hipLaunchKernelGGL((gemm_filter_tall16_kernel<M>), grid, dim3(H_THREADS), shmem, s, a);                  \
+        hipLaunchKernelGGL((gemm_filter_tall16_kernel<M, N>), grid, dim3(H_THREADS), shmem, s, a);               \
     } while (0)
-    if (metric == METRIC_L2) LB_TALL16(METRIC_L2);
-    else if (metric == METRIC_COS) LB_TALL16(METRIC_COS);
-    else LB_TALL16(METRIC_DOT);
+#define LB_TALL16_M(M)               \
+    do {                             \
+        if (nt) LB_TALL16(M, true);  \
+        else LB_TALL16(M, false);    \
+    } while (0)
+    if (metric == METRIC_L2) LB_TALL16_M(METRIC_L2);
+    else if (metric == METRIC_COS) LB_TALL16_M(METRIC_COS);
+    else LB_TALL16_M(METRIC_DOT);
+#undef LB_TALL16_M
 #undef LB_TALL16
 }
 
