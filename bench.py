@@ -88,6 +88,16 @@ def rank_ids(part, rank, global_rows):
 # ---------------------------------------------------------------------------------------------------
 # secondary legs (N = 1 only)
 # ---------------------------------------------------------------------------------------------------
+def route_roof_ms(kind, form, B, rows):
+    """time the route's contraction needs at the dense MFMA peak of its operand type, and what it is called"""
+    flop = 2.0 * B * rows * DIM
+    if kind == 4 and form == 0:
+        return flop / (PEAK_F32_MFMA_TFLOPS * 1e12) * 1e3, "mfma_f32"
+    if form == 3:
+        return flop / (PEAK_BF16_MFMA_TFLOPS * 1e12) * 1e3, "mfma_f16_1_product"
+    return 3.0 * flop / (PEAK_BF16_MFMA_TFLOPS * 1e12) * 1e3, "mfma_bf16_3_products"
+
+
 def leg_batch_sweep(torch, dev, idx, Q, rows):
     """HBM-bound regime: whole-search time vs batch size (the reference's live multi-query path issues small
     batches sequentially, internal/store/vector_search_action.go:73)"""
@@ -98,13 +108,14 @@ def leg_batch_sweep(torch, dev, idx, Q, rows):
         ol = torch.empty((B, K), dtype=torch.int64, device=dev)
         q = Q[:B].contiguous()
         ms = timed_ms(lambda: idx.search_device(B, q.data_ptr(), K, od.data_ptr(), ol.data_ptr(), stream), torch, dev, n=9, skip=3)
-        # binding roof of the batch: the corpus stream (HBM) or the split contraction's 3 x 2 B N D bf16 flop (MFMA)
+        # binding roof of the batch: the corpus stream (HBM) or the contraction of the route the library took (MFMA)
+        kind, form, rname = idx.last_route
         hbm_ms = 4.0 * rows * DIM / (PEAK_HBM_GBS * 1e9) * 1e3
-        mfma_ms = 6.0 * B * rows * DIM / (PEAK_BF16_MFMA_TFLOPS * 1e12) * 1e3
+        mfma_ms, mname = route_roof_ms(kind, form, B, rows) if kind != 0 else (0.0, "")
         out.append({"batch": B, "ms": round(ms, 4), "ms_per_query": round(ms / B, 5), "queries_per_s": round(B / ms * 1e3, 1),
-                    "corpus_read_equiv_TBs": round(4.0 * rows * DIM / (ms * 1e-3) / 1e12, 3),
+                    "route": rname, "corpus_read_equiv_TBs": round(4.0 * rows * DIM / (ms * 1e-3) / 1e12, 3),
                     "frac_of_8TBs": round(hbm_ms / ms, 4),
-                    "binding_roof": "hbm" if hbm_ms >= mfma_ms else "mfma_bf16_split",
+                    "binding_roof": "hbm" if hbm_ms >= mfma_ms else mname,
                     "frac_of_binding_roof": round(max(hbm_ms, mfma_ms) / ms, 4)})
     return out
 
@@ -542,7 +553,7 @@ def main():
 
     single = world == 1 and not use_dist and not strong and X is not None
 
-    def mode_leg(mode, kernel_name, note):
+    def mode_leg(mode, note):
         """the same batch in another candidate mode: identical results required, own roofline"""
         idx.set_candidate_mode(mode)
         for _ in range(2):
@@ -563,13 +574,23 @@ def main():
         labf, ddf = step()
         labf, ddf = labf.cpu().numpy(), ddf.cpu().numpy()
         same = bool(np.array_equal(labf, lab_h) and np.array_equal(ddf, dist_h))
-        ach = 3.0 * flops_per_step * args.steps / (f_ms * 1e-3) / 1e12 if f_ms > 0 else 0.0
+        kind, form, rname = idx.last_route
+        passes = 1.0 if form == 3 else 3.0
+        ach = passes * flops_per_step * args.steps / (f_ms * 1e-3) / 1e12 if f_ms > 0 else 0.0
+        kms = f_ms / args.steps
+        # bytes the kernel stages from L2 into LDS per step: (corpus rows + query rows) x row bytes, per workgroup tile
+        tiles_q = -(-B // 256) if kind in (5, 6) else -(-B // 128)
+        row_tiles = -(-rows // 256)
+        stage_bytes = row_tiles * tiles_q * DIM * ((256 * 4) + (256 if kind in (5, 6) else 128) * (2 if form == 3 else 4))
         return {"value": round(B * args.steps / f_el, 1), "unit": "queries/s", "ms_per_step": round(1e3 * f_el / args.steps, 4),
-                "results_identical_to_f32_mode": same, "fallback_queries": int(f_fb),
-                "roofline": {"bound": "mfma", "kernel": kernel_name, "achieved": round(ach, 1),
-                             "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s (bf16, 3 MFMA passes counted)",
-                             "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "kernel_ms_per_step": round(f_ms / args.steps, 4),
-                             "launches_per_step": f_launch / args.steps},
+                "route": rname, "results_identical_to_f32_mode": same, "fallback_queries": int(f_fb),
+                "roofline": {"bound": "mfma", "kernel": rname, "achieved": round(ach, 1),
+                             "peak": PEAK_BF16_MFMA_TFLOPS,
+                             "unit": f"TFLOP/s ({'fp16, 1 MFMA product' if form == 3 else 'bf16, 3 MFMA products'} per element counted)",
+                             "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "kernel_ms_per_step": round(kms, 4),
+                             "launches_per_step": f_launch / args.steps,
+                             "l2_to_lds_staged_TBs": round(stage_bytes / (kms * 1e-3) / 1e12, 2) if kms > 0 else None,
+                             "hbm_floor_ms": round(4.0 * rows * DIM / (PEAK_HBM_GBS * 1e9) * 1e3, 4)},
                 "note": note}, labf, ddf
 
     auto_lab = auto_dist = None
@@ -577,18 +598,21 @@ def main():
         # ---- the library's DEFAULT path (LB_CAND_AUTO): same exact results, no second copy of the corpus -------
         try:
             result["auto_path"], auto_lab, auto_dist = mode_leg(
-                CAND_AUTO, "gemm_filter_tall_kernel<split in registers>",
-                "LB_CAND_AUTO, the library default: candidates from hi*hi+hi*lo+lo*hi on the bf16 MFMA with both f32 operands "
-                "split in registers (no second corpus image); reported distances/ids come from the exact f32 re-rank and the "
-                "containment proof, as in every mode")
+                CAND_AUTO,
+                "LB_CAND_AUTO, the library default: the cheapest exact route -- here ONE fp16 MFMA product per element (corpus "
+                "rounded to fp16 in registers, 512 candidates kept per query, error bound 1.1e-3 |q||x| in the containment proof); "
+                "reported distances/ids come from the exact f32 re-rank, as in every mode; no second copy of the corpus")
             result["auto_path"]["extra_hbm_bytes"] = 0
+            result["split_bf16_in_registers"], _, _ = mode_leg(
+                CAND_INREG, "lb_gpu_index_set_candidate_mode(LB_CAND_SPLIT_BF16_INREG): hi*hi + hi*lo + lo*hi on the bf16 MFMA, both "
+                            "f32 operands split in registers (what AUTO falls back to when the corpus norms rule fp16 out)")
+            result["split_bf16_in_registers"]["extra_hbm_bytes"] = 0
         except Exception as e:  # keep the primary line even if an optional leg fails
             result["auto_path"] = {"error": str(e)}
         # ---- opt-in: pre-split bf16 image of the corpus (a second N*D*4-byte copy) --------------------------------
         try:
             result["split_bf16_candidates"], _, _ = mode_leg(
-                CAND_IMAGE, "gemm_filter_tall_kernel<corpus image>",
-                "opt-in lb_gpu_index_set_candidate_mode(LB_CAND_SPLIT_BF16): the same contraction over a pre-split image")
+                CAND_IMAGE, "opt-in lb_gpu_index_set_candidate_mode(LB_CAND_SPLIT_BF16): the split contraction over a pre-split image")
             result["split_bf16_candidates"]["extra_hbm_bytes"] = int(4 * rows * DIM)
         except Exception as e:
             result["split_bf16_candidates"] = {"error": str(e)}

@@ -175,6 +175,11 @@ int64_t lb_gpu_index_last_fallbacks(const lb_gpu_index *h);
  * ~1 ms bound (the launch's workgroups were not co-resident, e.g. many such launches from many streams at once) and
  * were redone on the exact path: a latency event worth a metric, never a correctness one. */
 int64_t lb_gpu_index_fused_giveups(const lb_gpu_index *h);
+/* Which kernel generated the candidates of the most recent batched search on this handle: kind * 10 + operand form.
+ * kind: 0 exact scan path (<= 4 queries, non-finite data), 1 / 2 narrow tile (32 / 64 queries per pass), 3 256 x 128
+ * split-bf16 tile, 4 128 x 128 f32-MFMA tile, 5 256 x 256 split-bf16 tile, 6 256 x 256 fp16 single-product tile;
+ * form: 0 f32 operands, 1 pre-split corpus image, 2 split in registers, 3 fp16.  Telemetry only. */
+int lb_gpu_index_last_route(const lb_gpu_index *h);
 
 /* Candidate re-rank: the distance step of processChunkInternal
  * (internal/store/parallel_search.go:274-364).  The reference gathers the candidates' vectors into a

@@ -73,6 +73,7 @@ SIGNATURES = [
     ("lb_gpu_index_filter_float32", _i, [_vp, _vp, _i64, C.c_float, _i, _vp, _i64, _i]),
     ("lb_gpu_index_last_fallbacks", _i64, [_vp]),
     ("lb_gpu_index_fused_giveups", _i64, [_vp]),
+    ("lb_gpu_index_last_route", _i, [_vp]),
     ("lb_gpu_index_rerank", _i, [_vp, _vp, _vp, _i64, _i, _vp, _vp]),
     ("lb_gpu_index_rerank_device", _i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _vp]),
     ("lb_simd_match_int64", _i, [_i, _vp, _i64, _i64, _i, _vp]),

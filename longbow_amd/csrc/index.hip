@@ -261,6 +261,7 @@ struct lb_gpu_index {
     std::string last_error;
 
     std::atomic<int64_t> last_fallbacks{0};
+    std::atomic<int> last_route{0}; // RouteKind * 10 + operand form of the most recent batched search (0: exact scan path)
     std::atomic<int64_t> fused_giveups{0}; // fused sample launches whose waits gave up (batch redone on the exact path)
     std::atomic<int> profiling{0};
     std::mutex prof_mu;
@@ -703,6 +704,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     // rows with inf / NaN components: the MFMA pipeline's keys and error bounds assume finite data;
     // the scan path orders non-finite distances canonically (NaN last)
     if (h->nonfinite || nq < (narrow_ok ? narrow_min : kGemmMinQ)) {
+        h->last_route.store(0, std::memory_order_relaxed);
         std::vector<int> all(nq);
         for (int i = 0; i < nq; i++) all[i] = i;
         scan_with_retry(h, w, s, d_q, nq, all, k, d_dist, d_lab, prof);
@@ -718,6 +720,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         f16_offer = false;
     }
     const Route route = choose_route(nq, n, h->dim, cmode, narrow_ok, have_image, f16_offer);
+    h->last_route.store(route.kind * 10 + route.split, std::memory_order_relaxed);
 #ifdef LB_DIAG
     g_last_route.store(route.kind * 10 + route.split);
 #endif
@@ -1541,6 +1544,7 @@ int lb_simd_and_bytes(int device, uint8_t *dst, const uint8_t *src, int64_t n)
 
 int64_t lb_gpu_index_last_fallbacks(const lb_gpu_index *h) { return h ? h->last_fallbacks.load() : 0; }
 int64_t lb_gpu_index_fused_giveups(const lb_gpu_index *h) { return h ? h->fused_giveups.load() : 0; }
+int lb_gpu_index_last_route(const lb_gpu_index *h) { return h ? h->last_route.load() : 0; }
 
 int lb_gpu_index_search_device_ctx(lb_gpu_index *h, int64_t nq, const float *d_queries, int k, float *d_dist,
                                    int64_t *d_labels, void *stream, const lb_cancel *ctx)

@@ -216,6 +216,16 @@ class Index:
         self._live()
         return int(self._lib.lb_gpu_index_ntotal(self._h))
 
+    ROUTE_NAMES = {0: "exact scan", 1: "narrow 256x32", 2: "narrow 128x64", 3: "tall 256x128 split-bf16", 4: "wide 128x128 f32 MFMA",
+                   5: "tall 256x256 split-bf16", 6: "tall 256x256 fp16 single product"}
+
+    @property
+    def last_route(self):
+        """(kind, operand form, name) of the kernel that generated the last batched search's candidates"""
+        self._live()
+        v = int(self._lib.lb_gpu_index_last_route(self._h))
+        return v // 10, v % 10, self.ROUTE_NAMES.get(v // 10, "?")
+
     @property
     def fused_giveups(self):
         """searches whose in-launch threshold hand-off gave up (~1 ms) and were redone exactly (cumulative)"""
