@@ -189,6 +189,7 @@ def leg_pq_adc(torch, dev, lib, _lib, cores, check=True):
                      "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(n * M / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                      "kernel_ms": round(k_ms, 4), "whole_search_device_ms": round(d_ms, 4),
                      "whole_search_frac_of_8TBs": round(n * M / (ms1 * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                     "whole_search_device_frac_of_8TBs": round(n * M / (d_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                      "algorithmic_bytes_per_query": n * M + 4 * M * 256 + 12 * K},
         "exact_f32_table_pass_ms": round(ms_exact, 4), "prefilter_equals_exact_pass": same,
         "encode": {"vectors": n, "seconds_incl_generation": round(enc_s, 2), "vectors_per_s": round(n / enc_s, 0)},

@@ -662,7 +662,7 @@ static Route choose_route(int nq, int64_t n, int D, int cmode, bool narrow_ok, b
     // allow it (f16_ok) and there are enough tiles to fill the chip
     static const int f16_on = lb_tunable("LB_F16", 1);
     if (narrow_ok && f16_ok && f16_on && !image && nq > 64 &&
-        (cmode == LB_CAND_F16 || (cmode == LB_CAND_AUTO && (n / 256) * tiles256 >= 4096)))
+        (cmode == LB_CAND_F16 || (cmode == LB_CAND_AUTO && n >= 262144))) // (below: launch overheads decide, and the narrow tiles win)
         add(ROUTE_TALL16, 3, route_ms(kCostTall16, n, D, tiles256));
     if (image && !tall_on) add(ROUTE_WIDE, 1, route_ms(kCostWideF32, n, D, tiles128) * 0.4);
     else if (cmode == LB_CAND_F32_MFMA || cmode == LB_CAND_AUTO || nc == 0) add(ROUTE_WIDE, 0, route_ms(kCostWideF32, n, D, tiles128));
