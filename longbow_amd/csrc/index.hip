@@ -414,7 +414,8 @@ static RowView row_view(const lb_gpu_index *h)
 // so a list that ends with >= keep entries holds exactly the span's best `keep`.
 //   too tight:  fewer than `keep` rows pass iff >= m sampled rows are among the span's best keep-1;
 //               that count is ~Poisson(lambda = keep*count/span), and m = lambda + 5 sqrt(lambda) + 4
-//               puts the tail below 1e-6 (m = 10 for k = 100, 14 for the 256 MFMA candidates at 1M rows);
+//               puts the tail below 1e-6 (m = 10 for k = 100, 14 for the 256 MFMA candidates at 1M rows, 27-41 for the
+//               1024 candidates the fp16 route keeps beyond 1024 dimensions);
 //   too loose:  about m*span/count rows pass (1.2k-1.8k at 1M rows), relative spread 1/sqrt(m); the span
 //               is capped so that mean + 5 sigma stays below the list capacity.
 // Either miss is detected (flag bit 2 / bit 0) and the query is redone by the classic bootstrap
@@ -448,7 +449,7 @@ static SamplePlan sample_plan(int64_t n, int keep, uint32_t cap, uint32_t count_
         const int need = (int)std::ceil(lambda + 5.0 * std::sqrt(lambda) + 4.0);
         if (need <= m) break;
         m = need;
-        if (m > 32) return p;
+        if (m > 64) return p; // (sample_tau_kernel: m rounds of a workgroup-wide minimum, m <= 64)
     }
     if (span < 8 * (int64_t)count || !sample_tau_supported(count, m)) return p;
     p.on = true;
@@ -620,7 +621,7 @@ constexpr RouteCost kCostTallImage{0.000630, 0.0445, 0.000640, 0.000220};
 constexpr RouteCost kCostTall2Inreg{0.001260, 0.1300, 0.000640, 0.000250}; // per 256-query tile: 3.9 ms at 4M x 768, 1.16 at 4M x 128
 constexpr RouteCost kCostTall2Image{0.001150, 0.1300, 0.000640, 0.000220};
 constexpr RouteCost kCostWideF32{0.001940, 0.0600, 0.000640, 0.0};
-constexpr RouteCost kCostTall16{0.000570, 0.1300, 0.000640, 0.000330};     // per 256-query tile, one fp16 product: 0.57 ms at 1M x 768
+constexpr RouteCost kCostTall16{0.000570, 0.1300, 0.000900, 0.000220};     // (a single query tile streams the corpus at ~4.5 TB/s)     // per 256-query tile, one fp16 product: 0.57 ms at 1M x 768
 inline double route_ms(const RouteCost &c, int64_t n, int D, int tiles)
 {
     const double nd = 1e-6 * (double)n;
@@ -686,7 +687,7 @@ static Route choose_route(int nq, int64_t n, int D, int cmode, bool narrow_ok, b
 }
 
 int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, const float *d_q, int k,
-                        float *d_dist, int64_t *d_lab, int kc_in, bool prof, int64_t &fallbacks)
+                        float *d_dist, int64_t *d_lab, int kc_in, bool prof, int64_t &fallbacks, bool allow_f16 = true)
 {
     const int metric = h->metric, order = h->order.load();
     const RowView rv = row_view(h);
@@ -714,7 +715,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     // ---- batched path: MFMA candidate generation + exact re-rank --------------------
     const int cmode = h->cand_mode.load();
     const bool have_image = h->d_Xs != nullptr && h->xs_rows == h->n && h->dim % 32 == 0;
-    bool f16_offer = h->f16_ok;
+    bool f16_offer = h->f16_ok && allow_f16;
     if (f16_offer && cmode == LB_CAND_AUTO && h->f16_skip.load(std::memory_order_relaxed) > 0) {
         h->f16_skip.fetch_sub(1, std::memory_order_relaxed);
         f16_offer = false;
@@ -727,9 +728,11 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     // candidates kept per query.  The fp16 single-product route keeps twice as many: its keys are good to ~1.1e-3 of |q||x|,
     // and the containment proof needs the gap between the k-th and the LAST kept candidate to exceed about 2.5x that --
     // on the benchmark data the gap to the 256th is 0.0019-0.0028 (most queries would fail), to the 512th 0.0039-0.0045.
-    static const int f16_kc_mult = lb_tunable("LB_F16_KC_MULT", 2);
+    // (Uniform random data is the hard case: its distances concentrate like 1/sqrt(D), so the gap shrinks with the dimension
+    // while the bound does not -- beyond 1024 dimensions four times as many candidates are kept.)
+    static const int f16_kc_mult = lb_tunable("LB_F16_KC_MULT", 0);
     int kc = kc_in;
-    if (route.split == 3) kc = std::min(kc_in * f16_kc_mult, (int)(w->cap / 4));
+    if (route.split == 3) kc = std::min(kc_in * (f16_kc_mult > 0 ? f16_kc_mult : (h->dim > 1024 ? 4 : 2)), (int)(w->cap / 4));
     const SamplePlan sp = sample_plan(n, kc, w->cap);
     // up to 8 queries the sample is scored by the wave-per-row kernel (candidate keys; 22-28 us against
     // 44 us for 8192 rows through the 32-workgroup MFMA launch); larger batches sample through the MFMA
@@ -921,6 +924,9 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         } else if (nbad == 0) {
             h->f16_span.store(16);
         }
+        // more than a handful of unproven queries: one pass of the split-bf16 route over the whole batch (its keys are
+        // ~100x finer) costs less than exact scans of the unproven queries; what it cannot prove goes to the scan from there
+        if (nbad > 8) return search_batch_device(h, w, s, nq, d_q, k, d_dist, d_lab, kc_in, prof, fallbacks, /*allow_f16=*/false);
     }
     if (nbad > 0) {
         fallbacks += (int64_t)bad.size();
