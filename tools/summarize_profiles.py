@@ -20,7 +20,7 @@ def find(sub, suffix):
 
 
 def short(name):
-    return name.split("(")[0].replace("void ", "").strip()
+    return name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").strip()
 
 
 # ---- kernel stats
