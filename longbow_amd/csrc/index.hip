@@ -696,9 +696,8 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     ctx_check(w->ctx);
     ProfScope whole(w, s, prof, 4);
 
-    // Path selection (measured at 1M x 768 on MI355X, tools/bench_sweep.py): <= 4 queries exact scan
-    // (0.50-0.55 ms); 5..384 queries narrow MFMA tiles on the split-bf16 contraction (0.59 ms at 8, 0.62 at 32,
-    // 0.66 at 64, 1.1 at 128, 1.95 at 256); beyond that the 128-query f32 tile.
+    // Path selection: <= 4 queries exact scan (0.50-0.55 ms at 1M x 768); from 5 queries a candidate route picked by
+    // choose_route's cost model (narrow / tall / tall2 / fp16 / f32 tile), exact re-rank behind every one of them.
     const bool narrow_ok = h->dim % 32 == 0 && ((reinterpret_cast<uintptr_t>(d_q) & 15) == 0);
     static const int narrow_min = lb_tunable("LB_NARROW_MINQ", 5);
     static const int narrow_max = lb_tunable("LB_NARROW_MAXQ", 384);
@@ -874,6 +873,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
             fs.qna = norm_riders ? w->d_qna : nullptr;
             fs.order = order;
             fs.fail_host = w->h_fail;
+            fs.relaxed = lb_tunable("LB_FUSED_RELAXED", 0);
             launch_gemm_filter_narrow_fused(metric, gx, h->d_norm2, h->d_rnorm, 0, sp.span, h->dim, gq, nq, mask, rv.rowmap,
                                             w->cs, s, tile64, fs);
             w->fs_base += fused_sample_blocks(sp.count, nq, tile64);

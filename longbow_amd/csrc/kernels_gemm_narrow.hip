@@ -255,6 +255,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
                 // the first workgroups of a launch, and the two dependent device-scope loads then cost nothing at the end
                 const int qj = q0 + tid < a.nq ? q0 + tid : a.nq - 1;
                 // (the flag is read with ACQUIRE: pairs with the release store of the threshold workgroup)
+#ifdef LB_DIAG
+                if (kt == 0 && a.fs.relaxed) spec_ready = __hip_atomic_load(&a.fs.ready[qj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else
+#endif
                 if (kt == 0) spec_ready = __hip_atomic_load(&a.fs.ready[qj], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
                 if (kt == 3 && spec_ready == a.fs.epoch)
                     spec_tau = __hip_atomic_load(&a.cs.tau[qj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -605,9 +609,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_filter_narrow_kernel(NarrowA
         // publish: cnt / tau above, then ready[j] with RELEASE semantics at agent scope; the waiters read ready[j] with
         // ACQUIRE.  (The asm wait stays: ROCm 7.2 can drop the release fence's own vmcnt wait when the scoreboard looks
         // empty to it -- MI355X_MICROARCH.md "Compiler hazard".)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(&a.fs.ready[j], a.fs.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef LB_DIAG
+        if (a.fs.relaxed) { // A/B only: what the release costs
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&a.fs.ready[j], a.fs.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else
+#endif
+        {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&a.fs.ready[j], a.fs.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
 #ifdef LB_DIAG
         atomicMax(&g_fused_probe[1], (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #endif

@@ -178,6 +178,7 @@ struct FusedSample {
     float *qna = nullptr; // or null (not cosine)
     int order = 0;
     uint32_t *fail_host = nullptr; // pinned: set to `epoch` when a wait gave up (the host then redoes the batch exactly)
+    int relaxed = 0;               // diagnostic build only: hand-off without release / acquire (A/B of their cost)
 };
 void launch_gemm_filter_narrow_fused(int metric, const float *X, const float *norm2, const float *rnorm, int64_t row_begin,
                                      int64_t row_end, int D, const float *Q, int nq, const uint8_t *mask,
