@@ -46,6 +46,10 @@ constexpr int H_STAGE_BYTES = H_A_BYTES + H_B_BYTES;  // 48 KB
 constexpr int H_NST = 3;
 constexpr int H_NI = 6; // DMA requests per wave and stage: 4 x 8 corpus rows + 2 x 16 query rows
 
+#ifdef LB_DIAG
+__device__ unsigned long long g_tall16_probe[8]; // ABL == 5: cycle stamps summed over waves (tools/tall16_probe.py)
+#endif
+
 struct Tall16Args {
     const float *X;
     const float *norm2;
@@ -99,6 +103,22 @@ __device__ __forceinline__ void h_dma16x2(const void *g0, const void *g1, uint32
                  "s_mov_b32 m0, %0"
                  : "=&s"(save) : "v"(g0), "v"(g1), "s"(lds_addr) : "memory");
 }
+// ONE request (SPREAD: a stage's six requests are issued one at a time between the MFMAs of the step before)
+template <bool NT>
+__device__ __forceinline__ void h_dma16(const void *g, uint32_t lds_addr)
+{
+    uint32_t save;
+    if (NT)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off nt\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(save) : "v"(g), "s"(lds_addr));
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(save) : "v"(g), "s"(lds_addr));
+}
 template <int N>
 __device__ __forceinline__ void h_wait_vmcnt()
 {
@@ -115,7 +135,11 @@ __device__ __forceinline__ f16x8 h_cvt8(const f32x4 x0, const f32x4 x1)
 }
 
 // NT: the corpus requests carry the non-temporal policy (few query tiles per corpus tile: the line is not read again)
-template <int METRIC, bool NT>
+// SPREAD: the requests of stage k + 2 go out one by one between the MFMAs of step k instead of in one burst behind the barrier
+// (in a burst all eight waves queue on the CU's one address unit while the matrix pipe idles)
+// ABL (diagnostic build; the product instantiates 0 only): timing-only ablations 1 = no requests inside the loop, 2 = requests,
+// waits and barriers only (no LDS reads, no MFMAs), 3 = corpus requests only; 5 = cycle stamps
+template <int METRIC, bool NT, bool SPREAD, int ABL = 0>
 __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16_kernel(Tall16Args a)
 {
     // XCD-aware order as in gemm_filter_kernel: the query tiles of one corpus tile run side by side on one XCD
@@ -126,6 +150,8 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16_kernel(Tall16
     const int rt = (in_xcd / a.n_q_tiles) * 8 + xcd;
     if (rt >= a.n_row_tiles) return;
 
+    unsigned long long pr_start = 0;
+    if (ABL == 5) pr_start = __builtin_amdgcn_s_memtime();
     extern __shared__ __attribute__((aligned(16))) unsigned char hlds[];
     unsigned char *ring = hlds;                                                        // [H_NST][A 32 KB | B 16 KB]
     float *s_aux = reinterpret_cast<float *>(ring + H_NST * H_STAGE_BYTES);            // [H_BM]
@@ -191,7 +217,6 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16_kernel(Tall16
     uint8_t side_vis = 1;
     if (a.mask) side_vis = a.mask[side_ri];
     float tk[4], qs[4];
-    uint32_t tr[4];
 #pragma unroll
     for (int tn = 0; tn < 4; tn++) {
         const int qj = q0 + wc * 128 + tn * 32 + l31;
@@ -199,7 +224,6 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16_kernel(Tall16
         uint64_t tau = a.boot ? 0ull : a.cs.tau[qc];
         if (qj >= a.nq) tau = 0ull;
         tk[tn] = tau_key_of(tau);
-        tr[tn] = entry_row(tau);
         qs[tn] = a.qinv[qc];
     }
     if (tid < H_BM) {
@@ -210,37 +234,74 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16_kernel(Tall16
     // (the loads above were waited for by the compiler before their use; from here on only the DMA requests are in flight,
     // H_NI per wave and stage, and the compiler sees none of them)
 
-    for (int kt = 0; kt < nk; kt++) {
+    unsigned long long pr_wait = 0, pr_bar = 0, pr_t0 = 0, pr_r0 = 0;
+    if (ABL == 5) { pr_t0 = __builtin_amdgcn_s_memtime(); pr_r0 = __builtin_amdgcn_s_memrealtime(); }
+    // one K-step; ISSUE: the requests of stage kt + 2 are made during it
+    auto step = [&](int kt, auto issue_c) {
+        constexpr bool ISSUE = decltype(issue_c)::value && ABL != 1;
+        unsigned long long s0 = 0, s1 = 0;
+        if (ABL == 5) s0 = __builtin_amdgcn_s_memtime();
         // stage kt has landed once at most the requests of stage kt + 1 are outstanding
-        if (kt + 1 < nk) h_wait_vmcnt<H_NI>();
+        if (kt + 1 < nk) h_wait_vmcnt<(ABL == 3 ? 4 : H_NI)>();
         else h_wait_vmcnt<0>();
+        if (ABL == 5) s1 = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_barrier(); // everyone's part of stage kt is in; everyone is done reading stage kt - 1
         asm volatile("" ::: "memory");
-        if (kt + 2 < nk) issue(kt + 2); // into the slot read at step kt - 1
+        if (ABL == 5) { pr_wait += s1 - s0; pr_bar += __builtin_amdgcn_s_memtime() - s1; }
+        if (ISSUE && !SPREAD) issue(kt + 2); // into the slot read at step kt - 1
+        const uint32_t A2 = ring_base + (uint32_t)((kt + 2) % H_NST) * H_STAGE_BYTES + (uint32_t)(wave * 32 * 128);
+        const uint32_t B2 = ring_base + (uint32_t)((kt + 2) % H_NST) * H_STAGE_BYTES + H_A_BYTES + (uint32_t)(wave * 32 * 64);
+        const int ka2 = (kt + 2) * (H_BK * 4), kb2 = (kt + 2) * (H_BK * 2);
         const unsigned char *As = ring + (kt % H_NST) * H_STAGE_BYTES;
         const unsigned char *Bs = As + H_A_BYTES;
 #pragma unroll
         for (int kb = 0; kb < 2; kb++) { // the stage's two MFMA k-blocks of 16
             f16x8 af[2];
+            if (ABL != 2) {
 #pragma unroll
-            for (int tm = 0; tm < 2; tm++) {
-                const int r = wr * 64 + tm * 32 + l31;
-                // lane half h supplies k = 16 kb + 8 h .. + 7: f32 chunks 4 kb + 2 h and the next
-                const f32x4 x0 = *reinterpret_cast<const f32x4 *>(As + haswz(r, 4 * kb + 2 * h));
-                const f32x4 x1 = *reinterpret_cast<const f32x4 *>(As + haswz(r, 4 * kb + 2 * h + 1));
-                af[tm] = h_cvt8(x0, x1);
+                for (int tm = 0; tm < 2; tm++) {
+                    const int r = wr * 64 + tm * 32 + l31;
+                    // lane half h supplies k = 16 kb + 8 h .. + 7: f32 chunks 4 kb + 2 h and the next
+                    const f32x4 x0 = *reinterpret_cast<const f32x4 *>(As + haswz(r, 4 * kb + 2 * h));
+                    const f32x4 x1 = *reinterpret_cast<const f32x4 *>(As + haswz(r, 4 * kb + 2 * h + 1));
+                    af[tm] = h_cvt8(x0, x1);
+                }
             }
 #pragma unroll
             for (int tn = 0; tn < 4; tn++) {
-                const int r = wc * 128 + tn * 32 + l31;
-                // 8 fp16 = one 16-B chunk: k = 16 kb + 8 h .. + 7 is chunk 2 kb + h of the 64-B row
-                const f16x8 bf = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4 *>(Bs + hbswz(r, 2 * kb + h)));
+                if (ABL != 2) {
+                    const int r = wc * 128 + tn * 32 + l31;
+                    // 8 fp16 = one 16-B chunk: k = 16 kb + 8 h .. + 7 is chunk 2 kb + h of the 64-B row
+                    const f16x8 bf = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4 *>(Bs + hbswz(r, 2 * kb + h)));
 #pragma unroll
-                for (int tm = 0; tm < 2; tm++)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tm], bf, acc[tm][tn], 0, 0, 0);
+                    for (int tm = 0; tm < 2; tm++)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tm], bf, acc[tm][tn], 0, 0, 0);
+                }
+                if (ISSUE && SPREAD) { // slots 0 1 2 . 4 5 6 . of the step's eight MFMA pairs: corpus 0..3, queries 0..1
+                    const int slot = kb * 4 + tn;
+                    if (slot < 3) h_dma16<NT>(srcA[slot] + 1024 * slot + ka2, A2 + 1024u * slot);
+                    else if (slot == 4) h_dma16<NT>(srcA[3] + 1024 * 3 + ka2, A2 + 1024u * 3);
+                    else if (slot == 5 && ABL != 3) h_dma16<false>(srcB[0] + kb2, B2);
+                    else if (slot == 6 && ABL != 3) h_dma16<false>(srcB[1] + 1024 + kb2, B2 + 1024u);
+                }
             }
         }
+    };
+    int kt = 0;
+    for (; kt + 2 < nk; kt++) step(kt, std::true_type{});
+    for (; kt < nk; kt++) step(kt, std::false_type{});
+#ifdef LB_DIAG
+    if (ABL == 5 && lane == 0) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        atomicAdd(&g_tall16_probe[0], t1 - pr_t0); // loop cycles
+        atomicAdd(&g_tall16_probe[1], r1 - pr_r0); // the same in 100 MHz ticks
+        atomicAdd(&g_tall16_probe[2], 1ull);       // waves
+        atomicAdd(&g_tall16_probe[3], pr_wait);    // in s_waitcnt vmcnt
+        atomicAdd(&g_tall16_probe[4], pr_bar);     // in s_barrier
+        atomicAdd(&g_tall16_probe[5], pr_t0 - pr_start); // prologue (kernel start -> loop start)
     }
+    const unsigned long long pr_loop_end = ABL == 5 ? __builtin_amdgcn_s_memtime() : 0ull;
+#endif
 
     // ---- epilogue: key + admission, one MFMA row tile (this lane's 16 rows of it) at a time ----------------
     // C layout (32x32): col = lane & 31 (query), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
@@ -302,16 +363,20 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16_kernel(Tall16
                 }
                 continue;
             }
-            // entry < tau  <=>  key < tau_key, or equal keys and a lower row (a padded query's tau decodes to NaN)
-            uint32_t bits = 0;
+            // Admission test, two VALU operations per element beside the key: the SIGN of (tau_key - key), shifted into a mask.
+            // It admits key <= tau_key -- the exact rule (key < tau_key, or equal keys and a lower row) plus the ties with a
+            // higher row: a superset, which the select behind this launch orders exactly as it orders every other entry
+            // (tau only bounds the list; an entry at tau displaces nothing).  Both operands of the subtraction are the
+            // rounded f32 values the exact rule compares, so its sign is theirs.
+            uint32_t rej = 0; // bit i: element i is beyond the threshold (or a padded query: tk NaN with the sign set)
 #pragma unroll
-            for (int g = 0; g < 4; g++)
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const float key = key_of(acc[tm][tn][4 * g + e], qs[tn], aux[g][e]);
-                    const uint32_t lt = (uint32_t)(key < tk[tn]) | ((uint32_t)(key == tk[tn]) & (uint32_t)(rid[g][e] < tr[tn]));
-                    bits |= lt << (g * 4 + e);
-                }
+            for (int i = 15; i >= 0; i--) { // element 15 first: each step shifts the mask left, element i ends in bit i
+                const float key = key_of(acc[tm][tn][i], qs[tn], aux[i >> 2][i & 3]);
+                const float d = tk[tn] - key;
+                rej = __builtin_amdgcn_alignbit(rej, __builtin_bit_cast(uint32_t, d), 31); // (rej << 1) | sign(d)
+            }
+            uint32_t bits = ~rej & 0xffffu;
+            if (!qok) bits = 0;
             bits &= vbits;
             if (bits) { // workgroup-local list first: two LDS atomics per lane with admissions
                 const uint32_t n = (uint32_t)__builtin_popcount(bits);
@@ -364,6 +429,9 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16_kernel(Tall16
             if (pos < a.cs.cap) a.cs.lists[(size_t)(q0 + ql) * a.cs.cap + pos] = ent;
         }
     }
+#ifdef LB_DIAG
+    if (ABL == 5 && lane == 0) atomicAdd(&g_tall16_probe[6], __builtin_amdgcn_s_memtime() - pr_loop_end); // epilogue
+#endif
 }
 
 // f32 [nq][D] -> fp16 [nq][D], each query scaled by the power of two that brings its norm into [1, 2); qinv[q] = 1 / scale.
@@ -395,6 +463,17 @@ __global__ __launch_bounds__(256) void queries_to_f16_kernel(const float *Q, int
 
 } // namespace
 
+#ifdef LB_DIAG
+void read_tall16_probe(unsigned long long out[8], bool reset)
+{
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tall16_probe), 8 * sizeof(unsigned long long));
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tall16_probe), z, sizeof z);
+    }
+}
+#endif
+
 void launch_queries_to_f16(const float *Q, int nq, int D, void *Qh, float *qinv, hipStream_t s)
 {
     if (nq <= 0) return;
@@ -419,17 +498,48 @@ void launch_gemm_filter_tall16(int metric, const float *X, const float *norm2, c
     const size_t shmem = (size_t)H_NST * H_STAGE_BYTES + H_BM * 4 + H_BM * 4 + H_BM;
     static const int nt_max_tiles = lb_tunable("LB_F16_NT_MAXTILES", 1);
     const bool nt = a.n_q_tiles <= nt_max_tiles;
-#define LB_TALL16(M, N)                                                                                          \
+    static const int spread = lb_tunable("LB_F16_SPREAD", 1);
+    static const int abl = lb_tunable("LB_F16_ABL", 0);
+#define LB_TALL16(M, N, S, A)                                                                                    \
     do {                                                                                                         \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_filter_tall16_kernel<M, N>),              \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_filter_tall16_kernel<M, N, S, A>),        \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); /* per device */      \
-        hipLaunchKernelGGL((gemm_filter_tall16_kernel<M, N>), grid, dim3(H_THREADS), shmem, s, a);               \
+        hipLaunchKernelGGL((gemm_filter_tall16_kernel<M, N, S, A>), grid, dim3(H_THREADS), shmem, s, a);         \
     } while (0)
-#define LB_TALL16_M(M)               \
-    do {                             \
-        if (nt) LB_TALL16(M, true);  \
-        else LB_TALL16(M, false);    \
+#ifdef LB_DIAG
+    if (abl && metric == METRIC_COS) { // timing-only ablations / stamps (the bench metric only)
+        if (nt) {
+            if (abl == 1) LB_TALL16(METRIC_COS, true, true, 1);
+            else if (abl == 2) LB_TALL16(METRIC_COS, true, true, 2);
+            else if (abl == 3) LB_TALL16(METRIC_COS, true, true, 3);
+            else LB_TALL16(METRIC_COS, true, true, 5);
+        } else {
+            if (abl == 1) LB_TALL16(METRIC_COS, false, true, 1);
+            else if (abl == 2) LB_TALL16(METRIC_COS, false, true, 2);
+            else if (abl == 3) LB_TALL16(METRIC_COS, false, true, 3);
+            else LB_TALL16(METRIC_COS, false, true, 5);
+        }
+        return;
+    }
+#define LB_TALL16_M(M)                                   \
+    do {                                                 \
+        if (spread) {                                    \
+            if (nt) LB_TALL16(M, true, true, 0);         \
+            else LB_TALL16(M, false, true, 0);           \
+        } else {                                         \
+            if (nt) LB_TALL16(M, true, false, 0);        \
+            else LB_TALL16(M, false, false, 0);          \
+        }                                                \
     } while (0)
+#else
+#define LB_TALL16_M(M)                        \
+    do {                                      \
+        (void)spread;                         \
+        (void)abl;                            \
+        if (nt) LB_TALL16(M, true, true, 0);  \
+        else LB_TALL16(M, false, true, 0);    \
+    } while (0)
+#endif
     if (metric == METRIC_L2) LB_TALL16_M(METRIC_L2);
     else if (metric == METRIC_COS) LB_TALL16_M(METRIC_COS);
     else LB_TALL16_M(METRIC_DOT);
