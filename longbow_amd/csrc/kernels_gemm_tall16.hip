@@ -66,6 +66,7 @@ struct Tall16Args {
     CandState cs;
     int n_row_tiles, n_q_tiles;
     int boot;
+    int abl; // diagnostic build: timing-only ablations of the persistent form (6 = no epilogue, 7 = no flush)
 };
 
 // corpus rows: 128 B, eight 16-B chunks, chunk c of row r at position c ^ ((r >> 1) & 7)   (byte offset in the A region)
@@ -439,6 +440,267 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16_kernel(Tall16
 #endif
 }
 
+// ---- persistent form: one workgroup per CU walks its corpus tiles as ONE flat pipeline ------------------------------------
+// (unfiltered searches: no row map, no mask).  What it removes from every tile of the kernel above: the prologue (a round trip
+// for the side inputs before the first K-step), the pipeline refill (the first stages of the NEXT tile are requested during
+// the last K-steps and land under the epilogue) and the reload of the per-query thresholds and scales (a workgroup keeps its
+// query tile).  Workgroup b sits in slot b >> 3 of XCD b & 7; the slots of an XCD form groups of n_q_tiles workgroups that walk
+// the same corpus tiles side by side (they share the corpus lines through that XCD's L2), group g taking the tiles
+// 8 (g + groups i) + xcd, i = 0, 1, ...  A stage beyond the last tile re-reads the last stage (its ring slot is free by
+// then), so every K-step issues the same six requests and every wait is s_waitcnt vmcnt(6).
+template <int METRIC, bool NT>
+__global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall16Args a, int spx)
+{
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int nqt = a.n_q_tiles;
+    const int gpx = spx / nqt; // >= 1 (launcher)
+    const int group = slot / nqt, qt = slot - group * nqt;
+    if (group >= gpx) return;
+    const int jtop = a.n_row_tiles - 1 - xcd;
+    if (jtop < 0 || group > (jtop >> 3)) return;
+    const int n_my = ((jtop >> 3) - group) / gpx + 1; // corpus tiles of this workgroup
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char hlds[];
+    unsigned char *ring = hlds;                                                     // [H_NST][A 32 KB | B 16 KB]
+    float *s_auxp = reinterpret_cast<float *>(ring + H_NST * H_STAGE_BYTES);        // [2][512]: side input of the tile, double-buffered
+    const uint32_t ring_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)ring;
+    const uint32_t aux_base = ring_base + (uint32_t)(H_NST * H_STAGE_BYTES);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int q0 = qt * H_BN;
+    const int last_q = a.nq - 1;
+    const int64_t last_pos = a.row_end - a.row_begin - 1; // positions of this launch: corpus row = row_begin + position
+    const unsigned char *Xb = reinterpret_cast<const unsigned char *>(a.X + a.row_begin * (int64_t)a.D);
+    const int64_t row_bytes = (int64_t)a.D * 4;
+    const float *auxg = METRIC == METRIC_L2 ? a.norm2 + a.row_begin : (METRIC == METRIC_COS ? a.rnorm + a.row_begin : nullptr);
+    auto rt_of = [&](int i) { return (group + gpx * i) * 8 + xcd; };
+
+    // request sources.  Corpus: request i < 4 of this wave fills local rows 32 wave + 8 i .. + 7 (lane l: row l / 8, chunk
+    // position l % 8); recomputed when the request cursor enters a tile.  Queries: fixed for the workgroup.
+    const unsigned char *srcA[4], *srcB[2];
+    auto set_srcA = [&](int rt) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int row = wave * 32 + i * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            int64_t pos = (int64_t)rt * H_BM + row;
+            if (pos > last_pos) pos = last_pos;
+            srcA[i] = Xb + pos * row_bytes + 16 * c;
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int row = wave * 32 + j * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ ((row >> 2) & 3);
+        int qr = q0 + row;
+        if (qr > last_q) qr = last_q;
+        srcB[j] = reinterpret_cast<const unsigned char *>(a.Qh + (int64_t)qr * H_BK) + 16 * c;
+    }
+    const int64_t kb_stride = (int64_t)a.nq * (H_BK * 2);
+    const int nk = a.D / H_BK;
+
+    // request cursor: the stage to be requested next = K-step ik of this workgroup's tile it, into ring slot islot
+    int it = 0, ik = 0, islot = 0;
+    bool cursor_new_tile = false;
+    auto piece = [&](int p) {
+        const uint32_t A = ring_base + (uint32_t)islot * H_STAGE_BYTES + (uint32_t)(wave * 32 * 128);
+        const uint32_t B = ring_base + (uint32_t)islot * H_STAGE_BYTES + H_A_BYTES + (uint32_t)(wave * 32 * 64);
+        if (p < 4) h_dma16<NT>(srcA[p] + ik * (H_BK * 4), A + 1024u * p);
+        else h_dma16<false>(srcB[p - 4] + ik * kb_stride, B + 1024u * (p - 4));
+    };
+    auto advance = [&]() { // (beyond the last stage the cursor stays on it)
+        islot = islot == H_NST - 1 ? 0 : islot + 1;
+        if (ik + 1 < nk) ik++;
+        else if (it + 1 < n_my) { it++; ik = 0; cursor_new_tile = true; }
+    };
+    auto aux_request = [&](int i) { // side input of tile i -> buffer i & 1 (every wave asks for 64 rows: entries 256 .. 511 repeat 0 .. 255)
+        if (METRIC == METRIC_DOT) return;
+        int64_t pos = (int64_t)rt_of(i) * H_BM + ((wave & 3) * 64 + lane);
+        if (pos > last_pos) pos = last_pos;
+        uint32_t save;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(save) : "v"(auxg + pos), "s"(aux_base + (uint32_t)(i & 1) * 2048u + (uint32_t)wave * 256u));
+    };
+
+    set_srcA(rt_of(0));
+    aux_request(0);
+#pragma unroll
+    for (int p = 0; p < 6; p++) piece(p);
+    advance();
+    if (cursor_new_tile) { set_srcA(rt_of(it)); cursor_new_tile = false; }
+#pragma unroll
+    for (int p = 0; p < 6; p++) piece(p);
+    advance();
+
+    // thresholds and scales of this workgroup's queries (kept for all its tiles).  tkc: the threshold in the form the epilogue
+    // compares -- tau_key itself for L2, tau_key / qs for cosine and dot (qs = 2^-sh exactly, so 1 / qs is the float whose
+    // exponent field is 254 minus that of qs, and the product is exact unless it leaves the normal range: an overflow admits
+    // everything or nothing exactly as the unscaled comparison would, an underflow only moves ties -- see the epilogue)
+    float tkc[4], qs[4], m2qs[4];
+#pragma unroll
+    for (int tn = 0; tn < 4; tn++) {
+        const int qj = q0 + wc * 128 + tn * 32 + l31;
+        const int qc = qj < a.nq ? qj : a.nq - 1;
+        uint64_t tau = a.boot ? 0ull : a.cs.tau[qc];
+        if (qj >= a.nq) tau = 0ull;
+        const float tk = tau_key_of(tau);
+        qs[tn] = a.qinv[qc];
+        m2qs[tn] = -2.0f * qs[tn];
+        const float scale = __builtin_bit_cast(float, (254u << 23) - __builtin_bit_cast(uint32_t, qs[tn]));
+        tkc[tn] = METRIC == METRIC_L2 ? tk : tk * scale;
+    }
+    int cslot = 0; // ring slot of the stage being computed
+    for (int i = 0; i < n_my; i++) {
+        const int rt = rt_of(i);
+        f32x16 acc[2][4];
+#pragma unroll
+        for (int x = 0; x < 2; x++)
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[x][y][r] = 0.f;
+
+        for (int kt = 0; kt < nk; kt++) {
+            h_wait_vmcnt<H_NI>(); // this stage has landed: at most the six requests of the next one (or younger ones) are out
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (cursor_new_tile) { set_srcA(rt_of(it)); cursor_new_tile = false; }
+            if (kt == 1 && i + 1 < n_my) aux_request(i + 1);
+            const unsigned char *As = ring + cslot * H_STAGE_BYTES;
+            const unsigned char *Bs = As + H_A_BYTES;
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++) {
+                f16x8 af[2];
+#pragma unroll
+                for (int tm = 0; tm < 2; tm++) {
+                    const int r = wr * 64 + tm * 32 + l31;
+                    const f32x4 x0 = *reinterpret_cast<const f32x4 *>(As + haswz(r, 4 * kb + 2 * h));
+                    const f32x4 x1 = *reinterpret_cast<const f32x4 *>(As + haswz(r, 4 * kb + 2 * h + 1));
+                    af[tm] = h_cvt8(x0, x1);
+                }
+#pragma unroll
+                for (int tn = 0; tn < 4; tn++) {
+                    const int r = wc * 128 + tn * 32 + l31;
+                    const f16x8 bf = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4 *>(Bs + hbswz(r, 2 * kb + h)));
+#pragma unroll
+                    for (int tm = 0; tm < 2; tm++)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tm], bf, acc[tm][tn], 0, 0, 0);
+                    const int sl = kb * 4 + tn; // the next-but-one stage's requests between the MFMA pairs
+                    if (sl < 3) piece(sl);
+                    else if (sl == 4) piece(3);
+                    else if (sl == 5) piece(4);
+                    else if (sl == 6) piece(5);
+                }
+            }
+            advance();
+            if (kt + 1 < nk) cslot = cslot == H_NST - 1 ? 0 : cslot + 1;
+        }
+
+#ifdef LB_DIAG
+        if (a.abl == 6) { // timing only: no epilogue
+            cslot = cslot == H_NST - 1 ? 0 : cslot + 1;
+            continue;
+        }
+#endif
+        // ---- epilogue of the tile; scratch = the ring slot just consumed (the two others are being filled) ------------
+        // Two VALU operations per element: the candidate key in the form that needs ONE operation (cosine / dot: acc * (-ax),
+        // compared with tau_key / qs -- qs is a power of two, so this is the comparison of the keys themselves; L2:
+        // fma(acc, -2 qs, ax)) and v_cmp_le against the threshold.  It admits key <= tau_key: the exact rule (key < tau_key, or
+        // equal keys and a lower row) plus the ties with a higher row -- a superset, which the select behind this launch orders
+        // as it orders every other entry (tau only bounds the list).  Rows beyond the launch's range carry a NaN side input and
+        // fail every comparison.  An admitted element costs three LDS stores; packing and the global atomic happen in the flush.
+        // Every wave keeps its admissions in its own 512-entry segment of the slot, its count in a scalar register (slots from
+        // the lane's rank among the admitted lanes: no atomic, no wait), and flushes the segment itself: no barrier after the
+        // one that frees the slot.
+        constexpr uint32_t WCAP = 512;
+        unsigned char *seg = ring + cslot * H_STAGE_BYTES + wave * (WCAP * 10);
+        float *s_key = reinterpret_cast<float *>(seg);               // [WCAP]
+        uint32_t *s_rid = reinterpret_cast<uint32_t *>(s_key + WCAP); // [WCAP]
+        uint16_t *s_q = reinterpret_cast<uint16_t *>(s_rid + WCAP);   // [WCAP] query of the entry (in the tile)
+        uint32_t wcnt = 0;                                            // (wave-uniform)
+        const float *s_aux = s_auxp + (i & 1) * 512;
+        __syncthreads(); // every wave is past its reads of the slot
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++) {
+            float aux[4][4]; // cosine: -1/|x|, dot: -1, L2: |x|^2; NaN for a row beyond the range
+            const int64_t pos0 = (int64_t)rt * H_BM + wr * 64 + tm * 32 + 4 * h; // position of element (g, e): pos0 + 8 g + e
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int lr = wr * 64 + tm * 32 + 8 * g + 4 * h;
+                f32x4 av = {1.f, 1.f, 1.f, 1.f};
+                if (METRIC != METRIC_DOT) av = *reinterpret_cast<const f32x4 *>(&s_aux[lr]);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float v = METRIC == METRIC_L2 ? av[e] : -av[e];
+                    aux[g][e] = pos0 + 8 * g + e <= last_pos ? v : __builtin_nanf("");
+                }
+            }
+            const uint32_t rid0 = (uint32_t)(a.row_begin + pos0);
+#pragma unroll
+            for (int tn = 0; tn < 4; tn++) {
+                const int qj = q0 + wc * 128 + tn * 32 + l31;
+                const bool qok = qj < a.nq;
+                uint64_t *list = a.cs.lists + (size_t)(qok ? qj : 0) * a.cs.cap;
+                if (a.boot) { // sample pass: the entry of position p goes to list[p] (rows beyond the range: none)
+                    if (qok) {
+#pragma unroll
+                        for (int x = 0; x < 16; x++) {
+                            const float kp = METRIC == METRIC_L2 ? fmaf(acc[tm][tn][x], m2qs[tn], aux[x >> 2][x & 3])
+                                                                 : acc[tm][tn][x] * aux[x >> 2][x & 3];
+                            if (pos0 + 8 * (x >> 2) + (x & 3) <= last_pos)
+                                list[pos0 + 8 * (x >> 2) + (x & 3)] =
+                                    pack_entry(METRIC == METRIC_L2 ? kp : kp * qs[tn], rid0 + 8 * (x >> 2) + (x & 3));
+                        }
+                    }
+                    continue;
+                }
+#pragma unroll
+                for (int x = 0; x < 16; x++) {
+                    const float kp = METRIC == METRIC_L2 ? fmaf(acc[tm][tn][x], m2qs[tn], aux[x >> 2][x & 3])
+                                                         : acc[tm][tn][x] * aux[x >> 2][x & 3];
+                    const bool adm = kp <= tkc[tn]; // (a padded query's threshold is NaN)
+                    const uint64_t am = __builtin_amdgcn_ballot_w64(adm);
+                    if (am != 0) { // (wave-uniform; one element in six has an admitted lane)
+                        if (adm) {
+                            const uint32_t sl = wcnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
+                            const float key = METRIC == METRIC_L2 ? kp : kp * qs[tn];
+                            const uint32_t rid = rid0 + 8 * (x >> 2) + (x & 3);
+                            if (sl < WCAP) {
+                                s_key[sl] = key;
+                                s_rid[sl] = rid;
+                                s_q[sl] = (uint16_t)(qj - q0);
+                            } else { // (segment full) straight to the query's list
+                                const uint32_t pos = atomicAdd(&a.cs.cnt[qj], 1u);
+                                if (pos < a.cs.cap) list[pos] = pack_entry(key, rid);
+                            }
+                        }
+                        wcnt += (uint32_t)__builtin_popcountll(am);
+                    }
+                }
+            }
+        }
+        bool flush = !a.boot;
+#ifdef LB_DIAG
+        if (a.abl == 7) flush = false;
+#endif
+        if (flush) { // the wave's own entries, one per lane: pack, ONE returning global atomic, store -- all in flight together
+            const uint32_t total = wcnt < WCAP ? wcnt : WCAP;
+            for (uint32_t z = lane; z < total; z += 64) {
+                const int qg = q0 + (int)s_q[z];
+                const uint32_t pos = atomicAdd(&a.cs.cnt[qg], 1u);
+                if (pos < a.cs.cap) a.cs.lists[(size_t)qg * a.cs.cap + pos] = pack_entry(s_key[z], s_rid[z]);
+            }
+        }
+        cslot = cslot == H_NST - 1 ? 0 : cslot + 1; // (the next step's barrier separates these reads from the slot's refill)
+    }
+    h_wait_vmcnt<0>(); // the re-read stages behind the last tile: nothing may land in LDS after the workgroup has gone
+}
+
 // f32 [nq][D] -> fp16 [D / 32][nq][32], each query scaled by the power of two that brings its norm into [1, 2); qinv[q] = 1 / scale.
 // One wave per query.  (A zero or non-finite query keeps scale 1: its search is answered by the exact scan anyway.)
 __global__ __launch_bounds__(256) void queries_to_f16_kernel(const float *Q, int nq, int D, _Float16 *Qh, float *qinv)
@@ -497,9 +759,41 @@ void launch_gemm_filter_tall16(int metric, const float *X, const float *norm2, c
     a.Qh = reinterpret_cast<const _Float16 *>(Qh); a.qinv = qinv; a.nq = nq; a.mask = mask; a.cs = cs; a.boot = boot ? 1 : 0;
     a.n_row_tiles = (int)((row_end - row_begin + H_BM - 1) / H_BM);
     a.n_q_tiles = (nq + H_BN - 1) / H_BN;
+    a.abl = lb_tunable("LB_F16_ABL", 0);
     const int groups = (a.n_row_tiles + 7) / 8;
     dim3 grid((unsigned)(groups * 8 * a.n_q_tiles));
     const size_t shmem = (size_t)H_NST * H_STAGE_BYTES + H_BM * 4 + H_BM * 4 + H_BM;
+    // persistent form for unfiltered searches: one workgroup per CU (the ring leaves room for one), slots per XCD = CUs / 8
+    static const int persist = lb_tunable("LB_F16_PERSIST", 1);
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n;
+    }();
+    const int spx = cus / 8;
+    if (persist && !rowmap && !mask && spx >= 1 && a.n_q_tiles <= spx) {
+        const size_t pshmem = (size_t)H_NST * H_STAGE_BYTES + 2 * 512 * sizeof(float) + 16;
+        const bool pnt = a.n_q_tiles <= 1;
+        dim3 pgrid((unsigned)(spx * 8));
+#define LB_TALL16P(M, N)                                                                                          \
+    do {                                                                                                          \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_filter_tall16p_kernel<M, N>),              \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)pshmem);                       \
+        hipLaunchKernelGGL((gemm_filter_tall16p_kernel<M, N>), pgrid, dim3(H_THREADS), pshmem, s, a, spx);        \
+    } while (0)
+#define LB_TALL16P_M(M)              \
+    do {                             \
+        if (pnt) LB_TALL16P(M, true); \
+        else LB_TALL16P(M, false);   \
+    } while (0)
+        if (metric == METRIC_L2) LB_TALL16P_M(METRIC_L2);
+        else if (metric == METRIC_COS) LB_TALL16P_M(METRIC_COS);
+        else LB_TALL16P_M(METRIC_DOT);
+#undef LB_TALL16P_M
+#undef LB_TALL16P
+        return;
+    }
     static const int nt_max_tiles = lb_tunable("LB_F16_NT_MAXTILES", 1);
     const bool nt = a.n_q_tiles <= nt_max_tiles;
     static const int spread = lb_tunable("LB_F16_SPREAD", 1);

@@ -131,13 +131,15 @@ __global__ __launch_bounds__(THREADS, 2) void stage_kernel(const float *X, int64
 //       bit 2: the 16 LDS fragment reads of a K-step     bit 3: the 16 MFMAs (on whatever the registers hold)
 //       bit 4: requests spread between the MFMA pairs instead of one burst behind the barrier
 //       bit 5: query image K-blocked ([k-block][query][32 halfs]: a K-step's 256 x 64 B are contiguous)
+//       bit 6: L2 prefetch: one dword per 128-B line, `pf` K-steps ahead (into the successor block's tile near the end), by LDS-DMA into a junk
+//              area (no register is written later); the sharers of a corpus tile take turns
 // rot: the query tiles of one corpus tile walk K rotated by rot K-steps against each other (they do not ask for the same line at once)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr int T_STAGE = 48 * 1024;
 
 template <int PARTS, bool NT>
-__global__ __launch_bounds__(THREADS, 2) void tile_kernel(const float *X, const _Float16 *Qh, int n_row_tiles, int n_q_tiles, float *sink, int rot)
+__global__ __launch_bounds__(THREADS, 2) void tile_kernel(const float *X, const _Float16 *Qh, int n_row_tiles, int n_q_tiles, float *sink, int rot, int pf)
 {
     const int b = blockIdx.x;
     const int xcd = b & 7, in_xcd = b >> 3;
@@ -185,6 +187,18 @@ __global__ __launch_bounds__(THREADS, 2) void tile_kernel(const float *X, const 
 #pragma unroll
         for (int p = 0; p < 6; p++) piece(kt, p);
     };
+    // prefetch source: lane l < 32: row 32 wave + l at K-step kt + pf; lanes 32..63: the same rows one K-step further
+    const int64_t succ_rows = (int64_t)(32 / n_q_tiles) * 8 * ROWS; // the tile of block b + 256 (same XCD, same query tile)
+    const unsigned char *pfsrc = reinterpret_cast<const unsigned char *>(X + ((int64_t)rt * ROWS + wave * 32 + (lane & 31)) * D) + (lane >> 5) * 128;
+    const uint32_t junk = ring + 3 * T_STAGE + (uint32_t)wave * 256u;
+    auto prefetch = [&](int kt) {
+        int ke = kt + pf;
+        const unsigned char *g = pfsrc;
+        if (ke >= NK) { ke -= NK; g += succ_rows * D * 4; if ((int64_t)rt * ROWS + succ_rows >= (int64_t)n_row_tiles * ROWS) return; }
+        uint32_t save;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(save) : "v"(g + ke * 128), "s"(junk));
+    };
     issue(0);
     issue(1);
 #pragma unroll 1
@@ -195,6 +209,7 @@ __global__ __launch_bounds__(THREADS, 2) void tile_kernel(const float *X, const 
         asm volatile("" ::: "memory");
         const bool pre = kt + 2 < NK;
         if (pre && !(PARTS & 16)) issue(kt + 2);
+        if ((PARTS & 64) && !(kt & 1) && ((kt >> 1) % n_q_tiles) == qt) prefetch(kt);
         const unsigned char *As = lds + (kt % 3) * T_STAGE;
         const unsigned char *Bs = As + 32768;
 #pragma unroll
@@ -251,18 +266,18 @@ __global__ __launch_bounds__(THREADS, 2) void tile_kernel(const float *X, const 
 }
 
 template <int PARTS, bool NT>
-static double run_tile(const float *X, const _Float16 *Qh, int n_row_tiles, int n_q_tiles, float *sink, int rot = 0)
+static double run_tile(const float *X, const _Float16 *Qh, int n_row_tiles, int n_q_tiles, float *sink, int rot = 0, int pf = 0)
 {
-    const size_t shmem = 3 * T_STAGE;
+    const size_t shmem = 3 * T_STAGE + 2048;
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(tile_kernel<PARTS, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     const int grid = ((n_row_tiles + 7) / 8) * 8 * n_q_tiles;
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    for (int w = 0; w < 2; w++) hipLaunchKernelGGL((tile_kernel<PARTS, NT>), dim3(grid), dim3(THREADS), shmem, 0, X, Qh, n_row_tiles, n_q_tiles, sink, rot);
+    for (int w = 0; w < 2; w++) hipLaunchKernelGGL((tile_kernel<PARTS, NT>), dim3(grid), dim3(THREADS), shmem, 0, X, Qh, n_row_tiles, n_q_tiles, sink, rot, pf);
     CK(hipEventRecord(e0));
     const int reps = 5;
-    for (int r = 0; r < reps; r++) hipLaunchKernelGGL((tile_kernel<PARTS, NT>), dim3(grid), dim3(THREADS), shmem, 0, X, Qh, n_row_tiles, n_q_tiles, sink, rot);
+    for (int r = 0; r < reps; r++) hipLaunchKernelGGL((tile_kernel<PARTS, NT>), dim3(grid), dim3(THREADS), shmem, 0, X, Qh, n_row_tiles, n_q_tiles, sink, rot, pf);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms = 0;
@@ -338,6 +353,11 @@ int main()
         TROW(34, false, "query requests only, K-blocked image")
         TROW(35, false, "corpus + query requests, K-blocked query image")
         TROW(63, false, "everything, spread, K-blocked query image")
+        if (nq == 4)
+            for (int pf = 4; pf <= 12; pf += 2)
+                printf("  L2 prefetch %2d K-steps ahead: corpus only %8.3f ms   corpus + K-blocked queries %8.3f   everything spread, K-blocked Q %8.3f\n", pf,
+                       run_tile<65, false>(X, Qh, (int)n_tiles, nq, sink, 0, pf), run_tile<99, false>(X, Qh, (int)n_tiles, nq, sink, 0, pf),
+                       run_tile<127, false>(X, Qh, (int)n_tiles, nq, sink, 0, pf));
         if (nq == 4)
             for (int rot = 1; rot <= 6; rot += (rot < 3 ? 1 : 3)) {
                 printf("  rot %d: corpus only %8.3f ms   corpus + queries %8.3f   everything spread %8.3f   everything, K-blocked Q %8.3f\n", rot,
