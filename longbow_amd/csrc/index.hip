@@ -612,6 +612,7 @@ struct Route {
 // Fitted to tools/route_grid.py on MI355X (D in {128, 384, 768, 1536} x n in {100k, 1M, 4M}), see DESIGN.md 3.2.
 struct RouteCost {
     double alpha, beta, hbm, first;
+    double fixed = 0; // ms per search this route spends beyond the others (fp16: the query image, twice the candidates to re-rank)
 };
 // (narrow tiles: one launch, the corpus tile is read from HBM once and re-used from L2 by the other query tiles)
 constexpr RouteCost kCostNarrow32{0.000323, 0.0247, 0.000640, 0.000300};   // per 32-query tile: 1.09 ms at 4M x 768, 0.27 at 4M x 128
@@ -621,13 +622,14 @@ constexpr RouteCost kCostTallImage{0.000630, 0.0445, 0.000640, 0.000220};
 constexpr RouteCost kCostTall2Inreg{0.001260, 0.1300, 0.000640, 0.000250}; // per 256-query tile: 3.9 ms at 4M x 768, 1.16 at 4M x 128
 constexpr RouteCost kCostTall2Image{0.001150, 0.1300, 0.000640, 0.000220};
 constexpr RouteCost kCostWideF32{0.001940, 0.0600, 0.000640, 0.0};
-constexpr RouteCost kCostTall16{0.000570, 0.1300, 0.000900, 0.000220};     // (a single query tile streams the corpus at ~4.5 TB/s)     // per 256-query tile, one fp16 product: 0.57 ms at 1M x 768
+constexpr RouteCost kCostTall16{0.000540, 0.0800, 0.000660, 0.000140, 0.10}; // per 256-query tile, one fp16 product, persistent form: 0.49 ms per
+                                                                             // tile at 1M x 768, a single tile streams the corpus at 6 TB/s
 inline double route_ms(const RouteCost &c, int64_t n, int D, int tiles)
 {
     const double nd = 1e-6 * (double)n;
     const double compute = (double)tiles * nd * (c.alpha * (double)D + c.beta);
     const double stream = nd * (double)D * c.hbm;
-    return (compute > stream ? compute : stream) + nd * (double)D * c.first;
+    return (compute > stream ? compute : stream) + nd * (double)D * c.first + c.fixed;
 }
 
 static Route choose_route(int nq, int64_t n, int D, int cmode, bool narrow_ok, bool have_image, bool f16_ok)
