@@ -554,6 +554,13 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
         const float scale = __builtin_bit_cast(float, (254u << 23) - __builtin_bit_cast(uint32_t, qs[tn]));
         tkc[tn] = METRIC == METRIC_L2 ? tk : tk * scale;
     }
+    constexpr uint32_t WCAP = 100, WFLUSH = 56;
+    unsigned char *seg = reinterpret_cast<unsigned char *>(s_auxp + 2 * 512) + wave * 1024;
+    float *s_key = reinterpret_cast<float *>(seg);                // [WCAP]
+    uint32_t *s_rid = reinterpret_cast<uint32_t *>(s_key + WCAP); // [WCAP]
+    uint16_t *s_q = reinterpret_cast<uint16_t *>(s_rid + WCAP);   // [WCAP] query of the entry (in the tile)
+    uint32_t wcnt = 0;                                            // entries in the segment (wave-uniform)
+
     int cslot = 0; // ring slot of the stage being computed
     for (int i = 0; i < n_my; i++) {
         const int rt = rt_of(i);
@@ -607,24 +614,19 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
             continue;
         }
 #endif
-        // ---- epilogue of the tile; scratch = the ring slot just consumed (the two others are being filled) ------------
+        // ---- epilogue of the tile (the next tile's first two stages are landing meanwhile) --------------------------------
         // Two VALU operations per element: the candidate key in the form that needs ONE operation (cosine / dot: acc * (-ax),
         // compared with tau_key / qs -- qs is a power of two, so this is the comparison of the keys themselves; L2:
         // fma(acc, -2 qs, ax)) and v_cmp_le against the threshold.  It admits key <= tau_key: the exact rule (key < tau_key, or
         // equal keys and a lower row) plus the ties with a higher row -- a superset, which the select behind this launch orders
         // as it orders every other entry (tau only bounds the list).  Rows beyond the launch's range carry a NaN side input and
         // fail every comparison.  An admitted element costs three LDS stores; packing and the global atomic happen in the flush.
-        // Every wave keeps its admissions in its own 512-entry segment of the slot, its count in a scalar register (slots from
-        // the lane's rank among the admitted lanes: no atomic, no wait), and flushes the segment itself: no barrier after the
-        // one that frees the slot.
-        constexpr uint32_t WCAP = 512;
-        unsigned char *seg = ring + cslot * H_STAGE_BYTES + wave * (WCAP * 10);
-        float *s_key = reinterpret_cast<float *>(seg);               // [WCAP]
-        uint32_t *s_rid = reinterpret_cast<uint32_t *>(s_key + WCAP); // [WCAP]
-        uint16_t *s_q = reinterpret_cast<uint16_t *>(s_rid + WCAP);   // [WCAP] query of the entry (in the tile)
-        uint32_t wcnt = 0;                                            // (wave-uniform)
+        // Every wave keeps its admissions in its own 100-entry LDS segment (beside the ring: nothing here waits for the ring
+        // slot, so the epilogue has no barrier), its count in a scalar register (slots from the lane's rank among the
+        // admitted lanes: no atomic, no wait), and flushes the segment itself once it is more than half full or the
+        // workgroup is done -- every second or third tile: the flush's returning atomics cost a memory round trip, and under a
+        // saturated corpus stream (one query tile) that was 15 % of the kernel when paid per tile.
         const float *s_aux = s_auxp + (i & 1) * 512;
-        __syncthreads(); // every wave is past its reads of the slot
 #pragma unroll
         for (int tm = 0; tm < 2; tm++) {
             float aux[4][4]; // cosine: -1/|x|, dot: -1, L2: |x|^2; NaN for a row beyond the range
@@ -684,7 +686,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
                 }
             }
         }
-        bool flush = !a.boot;
+        bool flush = !a.boot && (wcnt > WFLUSH || i + 1 == n_my);
 #ifdef LB_DIAG
         if (a.abl == 7) flush = false;
 #endif
@@ -695,6 +697,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
                 const uint32_t pos = atomicAdd(&a.cs.cnt[qg], 1u);
                 if (pos < a.cs.cap) a.cs.lists[(size_t)qg * a.cs.cap + pos] = pack_entry(s_key[z], s_rid[z]);
             }
+            wcnt = 0;
         }
         cslot = cslot == H_NST - 1 ? 0 : cslot + 1; // (the next step's barrier separates these reads from the slot's refill)
     }
@@ -773,7 +776,7 @@ void launch_gemm_filter_tall16(int metric, const float *X, const float *norm2, c
     }();
     const int spx = cus / 8;
     if (persist && !rowmap && !mask && spx >= 1 && a.n_q_tiles <= spx) {
-        const size_t pshmem = (size_t)H_NST * H_STAGE_BYTES + 2 * 512 * sizeof(float) + 16;
+        const size_t pshmem = (size_t)H_NST * H_STAGE_BYTES + 2 * 512 * sizeof(float) + 8 * 1024; // ring, side inputs, admission segments
         const bool pnt = a.n_q_tiles <= 1;
         dim3 pgrid((unsigned)(spx * 8));
 #define LB_TALL16P(M, N)                                                                                          \
