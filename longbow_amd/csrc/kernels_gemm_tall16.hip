@@ -577,7 +577,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (cursor_new_tile) { set_srcA(rt_of(it)); cursor_new_tile = false; }
-            if (kt == 1 && i + 1 < n_my) aux_request(i + 1);
+            if (kt == (nk > 1 ? 1 : 0) && i + 1 < n_my) aux_request(i + 1); // (its buffer was last read a tile ago)
             const unsigned char *As = ring + cslot * H_STAGE_BYTES;
             const unsigned char *Bs = As + H_A_BYTES;
 #pragma unroll

@@ -588,3 +588,33 @@ def test_fp16_route_on_hostile_data_stays_exact_and_backs_off(oracle, metric):
         oi, od = oracle.search_batch(metric, Qb, Xb, k, nthreads=8)
         assert_same(lab, dist, oi, od, f"out-of-range norms, mode={mode}, metric={metric}")
     idx.Close()
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_fp16_persistent_tile_shapes(oracle, metric):
+    """the persistent fp16 kernel (kernels_gemm_tall16.hip) over the shapes its tile walk has to get right: one K-step per
+    row (D = 32: the side input of the next tile is asked for in the only step there is), fewer corpus tiles than
+    workgroups, a ragged last tile, 1 .. 6 query tiles per corpus tile (3, 5 and 6 leave workgroup slots of an XCD idle) and
+    more query tiles than an XCD has slots (the one-workgroup-per-tile form takes over) -- equal to the oracle on the
+    first queries and to the strict mode on all of them"""
+    gpu_or_skip()
+    rng = np.random.default_rng(900 + metric)
+    k = 10
+    saw_fp16 = 0
+    for n, d in ((300, 32), (5000, 64), (70001, 96), (33000, 768)):
+        X = (rng.random((n, d), dtype=F) - F(0.45)) * F(1.5)
+        nq_max = 8300 if n == 5000 else 1500
+        Q = (rng.random((nq_max, d), dtype=F) - F(0.45)) * F(1.5)
+        idx = new_index(d, metric)
+        idx.Add(None, X)
+        oi, od = oracle.search_batch(metric, Q[:24], X, k, nthreads=8)
+        for nq in (65, 257, 600, 1100, 1500) + ((8300,) if n == 5000 else ()):
+            idx.set_candidate_mode(0)
+            want = idx.SearchBatch(Q[:nq], k)
+            idx.set_candidate_mode(4)
+            lab, dist = idx.SearchBatch(Q[:nq], k)
+            saw_fp16 += idx.last_route[0] == 6  # (a batch the fp16 bound cannot prove is re-run on the split route)
+            assert_same(lab, dist, want[0], want[1], f"fp16 persistent metric={metric} n={n} d={d} nq={nq}")
+            assert_same(lab[:24], dist[:24], oi, od, f"fp16 persistent vs oracle metric={metric} n={n} d={d} nq={nq}")
+        idx.Close()
+    assert saw_fp16 >= 8, saw_fp16
