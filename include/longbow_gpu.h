@@ -102,6 +102,15 @@ int lb_gpu_index_set_order(lb_gpu_index *h, int order);
  *                      split contraction. */
 typedef enum { LB_CAND_F32_MFMA = 0, LB_CAND_SPLIT_BF16 = 1, LB_CAND_SPLIT_BF16_INREG = 2, LB_CAND_AUTO = 3, LB_CAND_F16 = 4 } lb_candidate_mode;
 int lb_gpu_index_set_candidate_mode(lb_gpu_index *h, int mode);
+/* The fp16 route's own copy of the corpus (2 bytes per element, K-blocked): half the bytes to stage per batched search of
+ * more than 64 queries (1M x 768, 1024 queries: see DESIGN.md 4.2).  mode 1 (default): kept while the route is on offer for
+ * this index (LB_CAND_AUTO from 262,144 rows, or LB_CAND_F16; dim % 32 == 0; norms in range) and the copy leaves
+ * max(2 GiB, 1/16 of the device) free -- brought up to date inside Add, dropped when the conditions end; mode 0: never (the
+ * route then rounds the f32 rows in registers).  Results do not depend on it: both forms see the same fp16 values, and every
+ * reported distance comes from the exact f32 re-rank.  There is no reference counterpart (a memory-for-speed knob of this
+ * backend, like the index's capacity reservation). */
+int lb_gpu_index_set_f16_image(lb_gpu_index *h, int mode);
+int64_t lb_gpu_index_f16_image_bytes(const lb_gpu_index *h); /* HBM held by that copy right now (0: none) */
 int64_t lb_gpu_index_ntotal(const lb_gpu_index *h);
 int lb_gpu_index_dim(const lb_gpu_index *h);
 int lb_gpu_index_device(const lb_gpu_index *h); /* GPUConfig.DeviceID (interface.go:15-19); -1 on NULL */

@@ -49,6 +49,8 @@ SIGNATURES = [
     ("lb_gpu_last_error", C.c_char_p, [_vp]),
     ("lb_gpu_index_set_order", _i, [_vp, _i]),
     ("lb_gpu_index_set_candidate_mode", _i, [_vp, _i]),
+    ("lb_gpu_index_set_f16_image", _i, [_vp, _i]),
+    ("lb_gpu_index_f16_image_bytes", _i64, [_vp]),
     ("lb_gpu_index_ntotal", _i64, [_vp]),
     ("lb_gpu_index_dim", _i, [_vp]),
     ("lb_gpu_index_device", _i, [_vp]),

@@ -248,6 +248,12 @@ struct lb_gpu_index {
     std::atomic<int> cand_mode{LB_CAND_AUTO};
     float *d_Xs = nullptr;
     int64_t xs_rows = 0; // rows of d_X already mirrored in d_Xs
+    // fp16 image of the corpus for the single-product route (K-blocked [dim / 32][xh_cap][32], kernels_gemm_tall16.hip): kept
+    // while that route is on offer and memory allows (sync_f16_image); half the bytes to stage per batched search
+    void *d_Xh = nullptr;
+    int64_t xh_rows = 0, xh_cap = 0;
+    std::atomic<int> xh_mode{1}; // lb_gpu_index_set_f16_image: 0 never, 1 when it pays and fits
+    bool xh_failed = false;      // an allocation was refused: not tried again for this handle
 
     hipStream_t add_stream = nullptr;
     void *h_stage[2] = {nullptr, nullptr};
@@ -624,6 +630,8 @@ constexpr RouteCost kCostTall2Image{0.001150, 0.1300, 0.000640, 0.000220};
 constexpr RouteCost kCostWideF32{0.001940, 0.0600, 0.000640, 0.0};
 constexpr RouteCost kCostTall16{0.000540, 0.0800, 0.000660, 0.000140, 0.10}; // per 256-query tile, one fp16 product, persistent form: 0.49 ms per
                                                                              // tile at 1M x 768, a single tile streams the corpus at 6 TB/s
+constexpr RouteCost kCostTall16Img{0.000460, 0.0500, 0.000330, 0.000040, 0.10}; // the same from the corpus's fp16 image: 0.40 ms per tile at
+                                                                                // 1M x 768, never bound by the stream (1.5 GB)
 inline double route_ms(const RouteCost &c, int64_t n, int D, int tiles)
 {
     const double nd = 1e-6 * (double)n;
@@ -632,7 +640,7 @@ inline double route_ms(const RouteCost &c, int64_t n, int D, int tiles)
     return (compute > stream ? compute : stream) + nd * (double)D * c.first + c.fixed;
 }
 
-static Route choose_route(int nq, int64_t n, int D, int cmode, bool narrow_ok, bool have_image, bool f16_ok)
+static Route choose_route(int nq, int64_t n, int D, int cmode, bool narrow_ok, bool have_image, bool f16_ok, bool have_f16_image = false)
 {
     static const int narrow_max = lb_tunable("LB_NARROW_MAXQ", 384);
     static const bool nsplit_on = lb_tunable("LB_NARROW_SPLIT", 1) != 0;
@@ -664,9 +672,9 @@ static Route choose_route(int nq, int64_t n, int D, int cmode, bool narrow_ok, b
     // one fp16 product instead of three bf16 ones (split code 3): AUTO and the explicit LB_CAND_F16, while the corpus norms
     // allow it (f16_ok) and there are enough tiles to fill the chip
     static const int f16_on = lb_tunable("LB_F16", 1);
-    if (narrow_ok && f16_ok && f16_on && !image && nq > 64 &&
+    if (narrow_ok && f16_ok && f16_on && !image && nq > 32 &&
         (cmode == LB_CAND_F16 || (cmode == LB_CAND_AUTO && n >= 262144))) // (below: launch overheads decide, and the narrow tiles win)
-        add(ROUTE_TALL16, 3, route_ms(kCostTall16, n, D, tiles256));
+        add(ROUTE_TALL16, 3, route_ms(have_f16_image ? kCostTall16Img : kCostTall16, n, D, tiles256));
     if (image && !tall_on) add(ROUTE_WIDE, 1, route_ms(kCostWideF32, n, D, tiles128) * 0.4);
     else if (cmode == LB_CAND_F32_MFMA || cmode == LB_CAND_AUTO || nc == 0) add(ROUTE_WIDE, 0, route_ms(kCostWideF32, n, D, tiles128));
 #ifdef LB_DIAG
@@ -721,7 +729,9 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         h->f16_skip.fetch_sub(1, std::memory_order_relaxed);
         f16_offer = false;
     }
-    const Route route = choose_route(nq, n, h->dim, cmode, narrow_ok, have_image, f16_offer);
+    // (the fp16 image serves unfiltered searches: under a filter the kernel gathers f32 rows)
+    const bool have_xh = h->d_Xh != nullptr && h->xh_rows == h->n && !rv.rowmap && !mask;
+    const Route route = choose_route(nq, n, h->dim, cmode, narrow_ok, have_image, f16_offer, have_xh);
     h->last_route.store(route.kind * 10 + route.split, std::memory_order_relaxed);
 #ifdef LB_DIAG
     g_last_route.store(route.kind * 10 + route.split);
@@ -812,7 +822,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
                                       true, s, /*tile64=*/true, /*split=*/true);
         else if (use_tall16)
             launch_gemm_filter_tall16(metric, h->d_X, h->d_norm2, h->d_rnorm, b, e, h->dim, w->d_qh, d_qinv, nq, mask, rowmap,
-                                      w->cs, boot, s);
+                                      w->cs, boot, s, have_xh ? h->d_Xh : nullptr, h->xh_cap);
         else if (use_tall2)
             launch_gemm_filter_tall2(metric, gx, h->d_norm2, h->d_rnorm, b, e, h->dim, w->d_qs, nq, mask, rowmap, w->cs,
                                      boot, wsplit, s);
@@ -1084,10 +1094,16 @@ int grow(lb_gpu_index *h, int64_t need)
         h->d_Xs = nullptr;
         h->xs_rows = 0;
     }
+    if (h->d_Xh) { // its planes are `capacity` rows apart: rebuilt by the next sync_f16_image
+        (void)hipFree(h->d_Xh);
+        h->d_Xh = nullptr;
+        h->xh_rows = h->xh_cap = 0;
+    }
     return LB_OK;
 }
 
 void sync_split_image(lb_gpu_index *h);
+void sync_f16_image(lb_gpu_index *h);
 
 // Recompute the visible-row list from d_mask (caller holds the exclusive lock).  The list is used
 // by searches when at most LB_ROWMAP_MAX_PCT % of the corpus is visible (default 95; measured on
@@ -1169,6 +1185,7 @@ void finish_add(lb_gpu_index *h, int64_t n, const int64_t *ids_src, bool ids_on_
         h->cand_mode.store(LB_CAND_AUTO);
         if (h->d_Xs) { (void)hipFree(h->d_Xs); h->d_Xs = nullptr; h->xs_rows = 0; }
     }
+    sync_f16_image(h); // (never throws: without the image the route stages f32 rows)
     try {
         rebuild_rowmap(h); // appended rows are visible; keep the list in step with the corpus
     } catch (const HipErr &) { // searches fall back to the per-row mask test
@@ -1193,6 +1210,51 @@ void sync_split_image(lb_gpu_index *h)
                           h->n - h->xs_rows, h->dim, h->add_stream);
         LB_HIP(hipStreamSynchronize(h->add_stream));
         h->xs_rows = h->n;
+    }
+}
+
+// Bring the corpus's fp16 image up to date (caller holds the exclusive lock), or drop it when it is not wanted any more.
+// Wanted: the fp16 route is on offer for this index (mode, dimension, norms, size) and the copy fits -- half the corpus's
+// bytes again, taken only while that leaves max(2 GiB, 1/16 of the device) free.  Never fails the caller: without the image
+// the route stages the f32 rows.
+void sync_f16_image(lb_gpu_index *h)
+{
+    const int cm = h->cand_mode.load();
+    const bool want = h->xh_mode.load() != 0 && !h->xh_failed && h->dim % 32 == 0 && h->f16_ok && h->n > 0 &&
+                      (cm == LB_CAND_F16 || (cm == LB_CAND_AUTO && h->n >= 262144));
+    try {
+        if (!want || (h->d_Xh && (h->xh_cap < h->n || h->xh_rows > h->n))) {
+            if (h->d_Xh) (void)hipFree(h->d_Xh);
+            h->d_Xh = nullptr;
+            h->xh_rows = h->xh_cap = 0;
+            if (!want) return;
+        }
+        if (h->d_Xh == nullptr) {
+            const size_t need = (size_t)h->capacity * (size_t)h->dim * 2;
+            size_t fr = 0, tot = 0;
+            LB_HIP(hipMemGetInfo(&fr, &tot));
+            const size_t keep = std::max<size_t>((size_t)2 << 30, tot / 16);
+            if (fr < need + keep) return; // (not remembered: memory may be free again at the next Add)
+            if (hipMalloc(&h->d_Xh, need) != hipSuccess) {
+                (void)hipGetLastError();
+                h->d_Xh = nullptr;
+                h->xh_failed = true;
+                return;
+            }
+            h->xh_cap = h->capacity;
+            h->xh_rows = 0;
+        }
+        if (h->xh_rows < h->n) {
+            launch_corpus_to_f16(h->d_X, h->xh_rows, h->n, h->dim, h->d_Xh, h->xh_cap, h->add_stream);
+            LB_HIP(hipStreamSynchronize(h->add_stream));
+            h->xh_rows = h->n;
+        }
+    } catch (const HipErr &) {
+        (void)hipGetLastError();
+        if (h->d_Xh) (void)hipFree(h->d_Xh);
+        h->d_Xh = nullptr;
+        h->xh_rows = h->xh_cap = 0;
+        h->xh_failed = true;
     }
 }
 
@@ -1353,6 +1415,7 @@ void lb_gpu_index_free(lb_gpu_index *h)
         if (h->d_cscratch) (void)hipFree(h->d_cscratch);
         if (h->d_maxnorm2) (void)hipFree(h->d_maxnorm2);
         if (h->d_Xs) (void)hipFree(h->d_Xs);
+        if (h->d_Xh) (void)hipFree(h->d_Xh);
         for (int i = 0; i < 2; i++) {
             if (h->h_stage[i]) (void)hipHostFree(h->h_stage[i]);
             if (h->stage_ev[i]) (void)hipEventDestroy(h->stage_ev[i]);
@@ -1390,11 +1453,33 @@ int lb_gpu_index_set_candidate_mode(lb_gpu_index *h, int mode)
         h->cand_mode.store(mode);
         if (mode == 1) sync_split_image(h);
         else if (h->d_Xs) { (void)hipFree(h->d_Xs); h->d_Xs = nullptr; h->xs_rows = 0; }
+        sync_f16_image(h);
     } catch (const HipErr &e) {
         h->cand_mode.store(LB_CAND_AUTO);
         return fail_hip(h, e);
     }
     return LB_OK;
+}
+
+int lb_gpu_index_set_f16_image(lb_gpu_index *h, int mode)
+{
+    if (!h || mode < 0 || mode > 1) return LB_ERR_INVALID_ARG;
+    try {
+        std::unique_lock<std::shared_mutex> g(h->mu);
+        if (h->closed) return LB_ERR_CLOSED;
+        if (hipSetDevice(h->device) != hipSuccess) { (void)hipGetLastError(); return LB_ERR_HIP; }
+        h->xh_mode.store(mode);
+        if (mode) h->xh_failed = false;
+        sync_f16_image(h);
+    } catch (...) {
+        return LB_ERR_INTERNAL;
+    }
+    return LB_OK;
+}
+
+int64_t lb_gpu_index_f16_image_bytes(const lb_gpu_index *h)
+{
+    return h && h->d_Xh ? (int64_t)h->xh_cap * h->dim * 2 : 0;
 }
 
 int64_t lb_gpu_index_ntotal(const lb_gpu_index *h) { return h ? h->n : 0; }

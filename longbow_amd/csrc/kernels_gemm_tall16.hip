@@ -67,6 +67,9 @@ struct Tall16Args {
     int n_row_tiles, n_q_tiles;
     int boot;
     int abl; // diagnostic build: timing-only ablations of the persistent form (6 = no epilogue, 7 = no flush)
+    int rot; // persistent form: the query tiles of a corpus tile walk K rotated by rot K-steps against each other
+    const _Float16 *Xh; // or null: fp16 image of the corpus, K-blocked [D / 32][xh_cap][32] (index.hip: sync_f16_image)
+    int64_t xh_cap;     // rows per K-block plane of Xh
 };
 
 // corpus rows: 128 B, eight 16-B chunks, chunk c of row r at position c ^ ((r >> 1) & 7)   (byte offset in the A region)
@@ -447,10 +450,20 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16_kernel(Tall16
 // query tile).  Workgroup b sits in slot b >> 3 of XCD b & 7; the slots of an XCD form groups of n_q_tiles workgroups that walk
 // the same corpus tiles side by side (they share the corpus lines through that XCD's L2), group g taking the tiles
 // 8 (g + groups i) + xcd, i = 0, 1, ...  A stage beyond the last tile re-reads the last stage (its ring slot is free by
-// then), so every K-step issues the same six requests and every wait is s_waitcnt vmcnt(6).
-template <int METRIC, bool NT>
+// then), so every K-step issues the same requests and every wait is the same s_waitcnt vmcnt(N).
+// AIMG: the corpus comes from its fp16 image (the index keeps one while memory allows): a stage is 16 KB of corpus + 16 KB of
+// queries, the ring FOUR stages deep and a stage is requested three K-steps ahead -- half the corpus bytes to stage, and
+// a third more time for a line that four CUs ask for at once to arrive.  The image is K-blocked like the
+// query image: the 64 B a K-step needs of 16 consecutive rows are one KiB of whole lines.
+template <int METRIC, bool NT, bool AIMG>
 __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall16Args a, int spx)
 {
+    constexpr int NST = AIMG ? 4 : 3;                       // ring stages
+    constexpr int A_BYTES = AIMG ? H_BM * H_BK * 2 : H_A_BYTES;
+    constexpr int STAGE = A_BYTES + H_B_BYTES;
+    constexpr int NPA = AIMG ? 2 : 4;                       // corpus requests per wave and stage
+    constexpr int NPS = NPA + 2;                            // requests per wave and stage
+    constexpr int DIST = NST - 1;                           // a stage is requested DIST K-steps before its use
     const int b = blockIdx.x;
     const int xcd = b & 7, slot = b >> 3;
     const int nqt = a.n_q_tiles;
@@ -462,10 +475,10 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
     const int n_my = ((jtop >> 3) - group) / gpx + 1; // corpus tiles of this workgroup
 
     extern __shared__ __attribute__((aligned(16))) unsigned char hlds[];
-    unsigned char *ring = hlds;                                                     // [H_NST][A 32 KB | B 16 KB]
-    float *s_auxp = reinterpret_cast<float *>(ring + H_NST * H_STAGE_BYTES);        // [2][512]: side input of the tile, double-buffered
+    unsigned char *ring = hlds;                                                     // [NST][A | B 16 KB]
+    float *s_auxp = reinterpret_cast<float *>(ring + NST * STAGE);                  // [2][512]: side input of the tile, double-buffered
     const uint32_t ring_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)ring;
-    const uint32_t aux_base = ring_base + (uint32_t)(H_NST * H_STAGE_BYTES);
+    const uint32_t aux_base = ring_base + (uint32_t)(NST * STAGE);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -481,16 +494,19 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
     auto rt_of = [&](int i) { return (group + gpx * i) * 8 + xcd; };
 
     // request sources.  Corpus: request i < 4 of this wave fills local rows 32 wave + 8 i .. + 7 (lane l: row l / 8, chunk
-    // position l % 8); recomputed when the request cursor enters a tile.  Queries: fixed for the workgroup.
+    // position l % 8) -- from the image: request i < 2 fills rows 32 wave + 16 i .. + 15 (lane l: row l / 4, chunk position
+    // l % 4, the query tile's layout); recomputed when the request cursor enters a tile.  Queries: fixed for the workgroup.
     const unsigned char *srcA[4], *srcB[2];
+    const unsigned char *Xhb = reinterpret_cast<const unsigned char *>(a.Xh) + a.row_begin * (int64_t)(H_BK * 2);
+    const int64_t plane_bytes = a.xh_cap * (int64_t)(H_BK * 2);
     auto set_srcA = [&](int rt) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int row = wave * 32 + i * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ ((row >> 1) & 7);
+        for (int i = 0; i < NPA; i++) {
+            const int row = AIMG ? wave * 32 + i * 16 + (lane >> 2) : wave * 32 + i * 8 + (lane >> 3);
+            const int c = AIMG ? (lane & 3) ^ ((row >> 2) & 3) : (lane & 7) ^ ((row >> 1) & 7);
             int64_t pos = (int64_t)rt * H_BM + row;
             if (pos > last_pos) pos = last_pos;
-            srcA[i] = Xb + pos * row_bytes + 16 * c;
+            srcA[i] = AIMG ? Xhb + pos * (H_BK * 2) + 16 * c : Xb + pos * row_bytes + 16 * c;
         }
     };
 #pragma unroll
@@ -504,17 +520,20 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
     const int64_t kb_stride = (int64_t)a.nq * (H_BK * 2);
     const int nk = a.D / H_BK;
 
+    const int krot = (qt * a.rot) % nk;
     // request cursor: the stage to be requested next = K-step ik of this workgroup's tile it, into ring slot islot
     int it = 0, ik = 0, islot = 0;
     bool cursor_new_tile = false;
-    auto piece = [&](int p) {
-        const uint32_t A = ring_base + (uint32_t)islot * H_STAGE_BYTES + (uint32_t)(wave * 32 * 128);
-        const uint32_t B = ring_base + (uint32_t)islot * H_STAGE_BYTES + H_A_BYTES + (uint32_t)(wave * 32 * 64);
-        if (p < 4) h_dma16<NT>(srcA[p] + ik * (H_BK * 4), A + 1024u * p);
-        else h_dma16<false>(srcB[p - 4] + ik * kb_stride, B + 1024u * (p - 4));
+    auto piece = [&](int p) { // request p of the cursor's stage: 0 .. NPA - 1 corpus, then two of queries
+        const uint32_t A = ring_base + (uint32_t)islot * STAGE + (uint32_t)(wave * 32 * (AIMG ? 64 : 128));
+        const uint32_t B = ring_base + (uint32_t)islot * STAGE + A_BYTES + (uint32_t)(wave * 32 * 64);
+        int ke = ik + krot; // (the sum over k does not care where it starts)
+        if (ke >= nk) ke -= nk;
+        if (p < NPA) h_dma16<NT>(srcA[p] + (AIMG ? ke * plane_bytes : (int64_t)ke * (H_BK * 4)), A + 1024u * p);
+        else h_dma16<false>(srcB[p - NPA] + ke * kb_stride, B + 1024u * (p - NPA));
     };
     auto advance = [&]() { // (beyond the last stage the cursor stays on it)
-        islot = islot == H_NST - 1 ? 0 : islot + 1;
+        islot = islot == NST - 1 ? 0 : islot + 1;
         if (ik + 1 < nk) ik++;
         else if (it + 1 < n_my) { it++; ik = 0; cursor_new_tile = true; }
     };
@@ -530,12 +549,12 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
     set_srcA(rt_of(0));
     aux_request(0);
 #pragma unroll
-    for (int p = 0; p < 6; p++) piece(p);
-    advance();
-    if (cursor_new_tile) { set_srcA(rt_of(it)); cursor_new_tile = false; }
+    for (int st = 0; st < DIST; st++) { // the first DIST stages
+        if (cursor_new_tile) { set_srcA(rt_of(it)); cursor_new_tile = false; }
 #pragma unroll
-    for (int p = 0; p < 6; p++) piece(p);
-    advance();
+        for (int p = 0; p < NPS; p++) piece(p);
+        advance();
+    }
 
     // thresholds and scales of this workgroup's queries (kept for all its tiles).  tkc: the threshold in the form the epilogue
     // compares -- tau_key itself for L2, tau_key / qs for cosine and dot (qs = 2^-sh exactly, so 1 / qs is the float whose
@@ -561,7 +580,51 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
     uint16_t *s_q = reinterpret_cast<uint16_t *>(s_rid + WCAP);   // [WCAP] query of the entry (in the tile)
     uint32_t wcnt = 0;                                            // entries in the segment (wave-uniform)
 
+    // Fragments of a K-step's two MFMA k-blocks: block 0's are read HALF A STEP EARLY -- the wait + barrier that make stage
+    // kt + 1 visible sit in the middle of step kt, and its first fragments are read while step kt's second k-block runs on
+    // the matrix pipe.  (With the barrier at the top of the step all eight waves read LDS at the same moment and the pipe
+    // idled for the latency, every step.)
+    auto load_frag = [&](int slot_, int kb, f16x8(&af)[2], f16x8(&bf)[4]) {
+        const unsigned char *As = ring + slot_ * STAGE;
+        const unsigned char *Bs = As + A_BYTES;
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++) {
+            const int r = wr * 64 + tm * 32 + l31;
+            if (AIMG) {
+                af[tm] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4 *>(As + hbswz(r, 2 * kb + h)));
+            } else {
+                const f32x4 x0 = *reinterpret_cast<const f32x4 *>(As + haswz(r, 4 * kb + 2 * h));
+                const f32x4 x1 = *reinterpret_cast<const f32x4 *>(As + haswz(r, 4 * kb + 2 * h + 1));
+                af[tm] = h_cvt8(x0, x1);
+            }
+        }
+#pragma unroll
+        for (int tn = 0; tn < 4; tn++) {
+            const int r = wc * 128 + tn * 32 + l31;
+            bf[tn] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4 *>(Bs + hbswz(r, 2 * kb + h)));
+        }
+    };
+    auto spread_piece = [&](int sl) { // the requests of the stage DIST steps ahead, between the MFMA pairs (slot sl of 8)
+        if (AIMG) {
+            if ((sl & 1) == 0) piece(sl >> 1);
+        } else {
+            if (sl < 3) piece(sl);
+            else if (sl == 4) piece(3);
+            else if (sl == 5) piece(4);
+            else if (sl == 6) piece(5);
+        }
+    };
+    constexpr int H1 = AIMG ? 2 : 3; // requests of a stage that go out in the first half of a step
+    constexpr bool PIPE = AIMG;      // (the f32 form has no registers for a third set of fragments: barrier at the top of the step)
+
     int cslot = 0; // ring slot of the stage being computed
+    f16x8 a0[2], b0[4];
+    if (PIPE) {
+        h_wait_vmcnt<NPS *(DIST - 1)>(); // stage 0 has landed: at most the requests of the DIST - 1 younger stages are out
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        load_frag(0, 0, a0, b0);
+    }
     for (int i = 0; i < n_my; i++) {
         const int rt = rt_of(i);
         f32x16 acc[2][4];
@@ -573,46 +636,47 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
                 for (int r = 0; r < 16; r++) acc[x][y][r] = 0.f;
 
         for (int kt = 0; kt < nk; kt++) {
-            h_wait_vmcnt<H_NI>(); // this stage has landed: at most the six requests of the next one (or younger ones) are out
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
+            if (!PIPE) {
+                h_wait_vmcnt<NPS *(DIST - 1)>(); // this stage has landed: at most the requests of the DIST - 1 younger ones are out
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                load_frag(cslot, 0, a0, b0);
+            }
+            f16x8 a1[2], b1[4];
+            if (PIPE) load_frag(cslot, 1, a1, b1); // (visible since the barrier in the middle of the step before)
             if (cursor_new_tile) { set_srcA(rt_of(it)); cursor_new_tile = false; }
             if (kt == (nk > 1 ? 1 : 0) && i + 1 < n_my) aux_request(i + 1); // (its buffer was last read a tile ago)
-            const unsigned char *As = ring + cslot * H_STAGE_BYTES;
-            const unsigned char *Bs = As + H_A_BYTES;
 #pragma unroll
-            for (int kb = 0; kb < 2; kb++) {
-                f16x8 af[2];
+            for (int tn = 0; tn < 4; tn++) { // k-block 0
 #pragma unroll
-                for (int tm = 0; tm < 2; tm++) {
-                    const int r = wr * 64 + tm * 32 + l31;
-                    const f32x4 x0 = *reinterpret_cast<const f32x4 *>(As + haswz(r, 4 * kb + 2 * h));
-                    const f32x4 x1 = *reinterpret_cast<const f32x4 *>(As + haswz(r, 4 * kb + 2 * h + 1));
-                    af[tm] = h_cvt8(x0, x1);
-                }
+                for (int tm = 0; tm < 2; tm++)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[tm], b0[tn], acc[tm][tn], 0, 0, 0);
+                spread_piece(tn);
+            }
+            // middle of the step: this wave's reads of stage kt are complete (so the slot may be refilled once everybody is
+            // here), stage kt + 1 has landed for this wave -- and, behind the barrier, for all
+            const int nslot = cslot == NST - 1 ? 0 : cslot + 1;
+            if (!PIPE) load_frag(cslot, 1, a1, b1);
+            if (PIPE) {
+                __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0), vmcnt / expcnt untouched
+                h_wait_vmcnt<NPS *(DIST - 2) + H1>();
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                load_frag(nslot, 0, a0, b0);
+            }
 #pragma unroll
-                for (int tn = 0; tn < 4; tn++) {
-                    const int r = wc * 128 + tn * 32 + l31;
-                    const f16x8 bf = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4 *>(Bs + hbswz(r, 2 * kb + h)));
+            for (int tn = 0; tn < 4; tn++) { // k-block 1
 #pragma unroll
-                    for (int tm = 0; tm < 2; tm++)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tm], bf, acc[tm][tn], 0, 0, 0);
-                    const int sl = kb * 4 + tn; // the next-but-one stage's requests between the MFMA pairs
-                    if (sl < 3) piece(sl);
-                    else if (sl == 4) piece(3);
-                    else if (sl == 5) piece(4);
-                    else if (sl == 6) piece(5);
-                }
+                for (int tm = 0; tm < 2; tm++)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[tm], b1[tn], acc[tm][tn], 0, 0, 0);
+                spread_piece(4 + tn);
             }
             advance();
-            if (kt + 1 < nk) cslot = cslot == H_NST - 1 ? 0 : cslot + 1;
+            cslot = nslot;
         }
 
 #ifdef LB_DIAG
-        if (a.abl == 6) { // timing only: no epilogue
-            cslot = cslot == H_NST - 1 ? 0 : cslot + 1;
-            continue;
-        }
+        if (a.abl == 6) continue; // timing only: no epilogue
 #endif
         // ---- epilogue of the tile (the next tile's first two stages are landing meanwhile) --------------------------------
         // Two VALU operations per element: the candidate key in the form that needs ONE operation (cosine / dot: acc * (-ax),
@@ -699,7 +763,6 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
             }
             wcnt = 0;
         }
-        cslot = cslot == H_NST - 1 ? 0 : cslot + 1; // (the next step's barrier separates these reads from the slot's refill)
     }
     h_wait_vmcnt<0>(); // the re-read stages behind the last tile: nothing may land in LDS after the workgroup has gone
 }
@@ -730,6 +793,19 @@ __global__ __launch_bounds__(256) void queries_to_f16_kernel(const float *Q, int
     if (lane == 0) qinv[q] = inv;
 }
 
+// f32 corpus rows [row_begin, row_end) -> the K-blocked fp16 image Xh[D / 32][cap][32] (round to nearest even, the conversion the
+// kernels above apply in registers: both forms of the route see the same fp16 values).  One workgroup = 64 rows x one K-block:
+// whole 128-B lines in, 4 KB contiguous out.
+__global__ __launch_bounds__(256) void corpus_to_f16_kernel(const float *X, int64_t row_begin, int64_t row_end, int D, _Float16 *Xh, int64_t cap)
+{
+    const int64_t row = row_begin + (int64_t)blockIdx.x * 64 + (threadIdx.x >> 2);
+    const int kb = blockIdx.y, q = threadIdx.x & 3;
+    if (row >= row_end) return;
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(X + row * (int64_t)D + kb * 32 + q * 8);
+    const f16x8 v = h_cvt8(src[0], src[1]);
+    *reinterpret_cast<f16x8 *>(Xh + ((int64_t)kb * cap + row) * 32 + q * 8) = v;
+}
+
 } // namespace
 
 #ifdef LB_DIAG
@@ -743,6 +819,13 @@ void read_tall16_probe(unsigned long long out[8], bool reset)
 }
 #endif
 
+void launch_corpus_to_f16(const float *X, int64_t row_begin, int64_t row_end, int D, void *Xh, int64_t cap, hipStream_t s)
+{
+    if (row_end <= row_begin) return;
+    dim3 grid((unsigned)((row_end - row_begin + 63) / 64), (unsigned)(D / 32));
+    hipLaunchKernelGGL(corpus_to_f16_kernel, grid, dim3(256), 0, s, X, row_begin, row_end, D, reinterpret_cast<_Float16 *>(Xh), cap);
+}
+
 void launch_queries_to_f16(const float *Q, int nq, int D, void *Qh, float *qinv, hipStream_t s)
 {
     if (nq <= 0) return;
@@ -753,7 +836,7 @@ void launch_queries_to_f16(const float *Q, int nq, int D, void *Qh, float *qinv,
 // Requires D % 32 == 0, 16-B aligned X / Qh; Qh / qinv from launch_queries_to_f16; X is the plain f32 corpus.
 void launch_gemm_filter_tall16(int metric, const float *X, const float *norm2, const float *rnorm, int64_t row_begin,
                                int64_t row_end, int D, const void *Qh, const float *qinv, int nq, const uint8_t *mask,
-                               const uint32_t *rowmap, CandState cs, bool boot, hipStream_t s)
+                               const uint32_t *rowmap, CandState cs, bool boot, hipStream_t s, const void *Xh, int64_t xh_cap)
 {
     if (row_end <= row_begin || nq <= 0) return;
     Tall16Args a;
@@ -763,6 +846,9 @@ void launch_gemm_filter_tall16(int metric, const float *X, const float *norm2, c
     a.n_row_tiles = (int)((row_end - row_begin + H_BM - 1) / H_BM);
     a.n_q_tiles = (nq + H_BN - 1) / H_BN;
     a.abl = lb_tunable("LB_F16_ABL", 0);
+    a.rot = lb_tunable("LB_F16_ROT", 0);
+    a.Xh = reinterpret_cast<const _Float16 *>(Xh);
+    a.xh_cap = xh_cap;
     const int groups = (a.n_row_tiles + 7) / 8;
     dim3 grid((unsigned)(groups * 8 * a.n_q_tiles));
     const size_t shmem = (size_t)H_NST * H_STAGE_BYTES + H_BM * 4 + H_BM * 4 + H_BM;
@@ -776,19 +862,26 @@ void launch_gemm_filter_tall16(int metric, const float *X, const float *norm2, c
     }();
     const int spx = cus / 8;
     if (persist && !rowmap && !mask && spx >= 1 && a.n_q_tiles <= spx) {
-        const size_t pshmem = (size_t)H_NST * H_STAGE_BYTES + 2 * 512 * sizeof(float) + 8 * 1024; // ring, side inputs, admission segments
+        const bool img = Xh != nullptr; // (sync_f16_image: in step with the corpus, K-blocked, xh_cap rows per plane)
+        const size_t pshmem = (img ? (size_t)4 * (H_BM * H_BK * 2 + H_B_BYTES) : (size_t)H_NST * H_STAGE_BYTES) + 2 * 512 * sizeof(float) +
+                              8 * 1024; // ring, side inputs, admission segments
         const bool pnt = a.n_q_tiles <= 1;
         dim3 pgrid((unsigned)(spx * 8));
-#define LB_TALL16P(M, N)                                                                                          \
+#define LB_TALL16P(M, N, I)                                                                                       \
     do {                                                                                                          \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_filter_tall16p_kernel<M, N>),              \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_filter_tall16p_kernel<M, N, I>),           \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)pshmem);                       \
-        hipLaunchKernelGGL((gemm_filter_tall16p_kernel<M, N>), pgrid, dim3(H_THREADS), pshmem, s, a, spx);        \
+        hipLaunchKernelGGL((gemm_filter_tall16p_kernel<M, N, I>), pgrid, dim3(H_THREADS), pshmem, s, a, spx);     \
     } while (0)
-#define LB_TALL16P_M(M)              \
-    do {                             \
-        if (pnt) LB_TALL16P(M, true); \
-        else LB_TALL16P(M, false);   \
+#define LB_TALL16P_M(M)                          \
+    do {                                         \
+        if (img) {                               \
+            if (pnt) LB_TALL16P(M, true, true);  \
+            else LB_TALL16P(M, false, true);     \
+        } else {                                 \
+            if (pnt) LB_TALL16P(M, true, false); \
+            else LB_TALL16P(M, false, false);    \
+        }                                        \
     } while (0)
         if (metric == METRIC_L2) LB_TALL16P_M(METRIC_L2);
         else if (metric == METRIC_COS) LB_TALL16P_M(METRIC_COS);

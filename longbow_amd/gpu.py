@@ -168,6 +168,16 @@ class Index:
         self._live()
         _lib.check(self._lib.lb_gpu_index_set_candidate_mode(self._h, int(mode)), self._h, lib=self._lib)
 
+    def set_f16_image(self, mode):
+        """1 (default): keep an fp16 copy of the corpus for the single-product route while it pays and fits; 0: never"""
+        self._live()
+        _lib.check(self._lib.lb_gpu_index_set_f16_image(self._h, int(mode)), self._h, lib=self._lib)
+
+    @property
+    def f16_image_bytes(self):
+        self._live()
+        return int(self._lib.lb_gpu_index_f16_image_bytes(self._h))
+
     def set_filter(self, mask):
         self._live()
         if mask is None:

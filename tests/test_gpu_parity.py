@@ -612,9 +612,39 @@ def test_fp16_persistent_tile_shapes(oracle, metric):
             idx.set_candidate_mode(0)
             want = idx.SearchBatch(Q[:nq], k)
             idx.set_candidate_mode(4)
-            lab, dist = idx.SearchBatch(Q[:nq], k)
-            saw_fp16 += idx.last_route[0] == 6  # (a batch the fp16 bound cannot prove is re-run on the split route)
-            assert_same(lab, dist, want[0], want[1], f"fp16 persistent metric={metric} n={n} d={d} nq={nq}")
-            assert_same(lab[:24], dist[:24], oi, od, f"fp16 persistent vs oracle metric={metric} n={n} d={d} nq={nq}")
+            for image in (1, 0):  # from the corpus's fp16 image (four-stage ring) / f32 rows rounded in registers
+                idx.set_f16_image(image)
+                assert (idx.f16_image_bytes > 0) == bool(image), (image, idx.f16_image_bytes)
+                lab, dist = idx.SearchBatch(Q[:nq], k)
+                saw_fp16 += idx.last_route[0] == 6  # (a batch the fp16 bound cannot prove is re-run on the split route)
+                assert_same(lab, dist, want[0], want[1], f"fp16 persistent metric={metric} n={n} d={d} nq={nq} image={image}")
+                assert_same(lab[:24], dist[:24], oi, od, f"fp16 persistent vs oracle metric={metric} n={n} d={d} nq={nq} image={image}")
+            idx.set_f16_image(1)
         idx.Close()
-    assert saw_fp16 >= 8, saw_fp16
+    assert saw_fp16 >= 16, saw_fp16
+
+
+def test_fp16_image_follows_the_corpus(oracle):
+    """the fp16 copy of the corpus is brought up to date inside Add (appends, growth past the reserved capacity) and dropped
+    when the route is no longer on offer; searches equal the oracle at every stage"""
+    gpu_or_skip()
+    rng = np.random.default_rng(77)
+    d, k, nq = 64, 10, 300
+    X = (rng.random((9000, d), dtype=F) - F(0.5))
+    Q = (rng.random((nq, d), dtype=F) - F(0.5))
+    idx = new_index(d, 1)
+    idx.set_candidate_mode(4)
+    assert idx.f16_image_bytes == 0
+    done = 0
+    for chunk in (1000, 300, 4000, 3700):      # (the third Add grows the index: the planes move apart, the copy is rebuilt)
+        idx.Add(None, X[done:done + chunk])
+        done += chunk
+        assert idx.f16_image_bytes >= done * d * 2
+        lab, dist = idx.SearchBatch(Q, k)
+        oi, od = oracle.search_batch(1, Q, X[:done], k, nthreads=8)
+        assert_same(lab, dist, oi, od, f"fp16 image after {done} rows")
+    idx.set_candidate_mode(0)                  # strict mode: no fp16 route, no copy
+    assert idx.f16_image_bytes == 0
+    idx.set_candidate_mode(3)                  # AUTO below 262,144 rows: not on offer either
+    assert idx.f16_image_bytes == 0
+    idx.Close()

@@ -14,7 +14,9 @@ X = torch.empty((rows, D), device="cuda"); Q = torch.empty((1024, D), device="cu
 lib.lb_gpu_fill_uniform_device(0, X.data_ptr(), X.numel(), 12345, 0, None)
 lib.lb_gpu_fill_uniform_device(0, Q.data_ptr(), Q.numel(), 42, 0, None)
 idx = gpu.NewIndexWithConfig(gpu.GPUConfig(0, D, 1)); idx.reserve(rows); idx.add_device(rows, X.data_ptr())
-if os.environ.get('CAND_MODE'): idx.set_candidate_mode(int(os.environ['CAND_MODE']))  # 1 = split image, 2 = split in registers
+if os.environ.get('CAND_MODE'): idx.set_candidate_mode(int(os.environ['CAND_MODE']))
+if os.environ.get('F16_IMAGE'): idx.set_f16_image(int(os.environ['F16_IMAGE']))  # 0: the fp16 route rounds f32 rows in registers
+print(f'fp16 image: {idx.f16_image_bytes / 1e9:.2f} GB', flush=True)  # 1 = split image, 2 = split in registers
 for B in [int(x) for x in os.environ.get('SWEEP', '1,2,4,8,9,16,24,32,48,64,96,97,128,256,512,1024').split(',')]:
     od = torch.empty((B, K), device="cuda"); ol = torch.empty((B, K), dtype=torch.int64, device="cuda")
     q = Q[:B].contiguous()
