@@ -110,13 +110,16 @@ def leg_batch_sweep(torch, dev, idx, Q, rows):
         ms = timed_ms(lambda: idx.search_device(B, q.data_ptr(), K, od.data_ptr(), ol.data_ptr(), stream), torch, dev, n=9, skip=3)
         # binding roof of the batch: the corpus stream (HBM) or the contraction of the route the library took (MFMA)
         kind, form, rname = idx.last_route
-        hbm_ms = 4.0 * rows * DIM / (PEAK_HBM_GBS * 1e9) * 1e3
+        hbm_ms = 4.0 * rows * DIM / (PEAK_HBM_GBS * 1e9) * 1e3  # algorithmic: the f32 corpus once
+        # what the pass physically reads: the f32 rows, or (fp16 route with the index's fp16 copy) 2 bytes per element
+        bpe = 2 if (form == 3 and idx.f16_image_bytes > 0) else 4
+        hbm_phys_ms = bpe * rows * DIM / (PEAK_HBM_GBS * 1e9) * 1e3
         mfma_ms, mname = route_roof_ms(kind, form, B, rows) if kind != 0 else (0.0, "")
         out.append({"batch": B, "ms": round(ms, 4), "ms_per_query": round(ms / B, 5), "queries_per_s": round(B / ms * 1e3, 1),
                     "route": rname, "corpus_read_equiv_TBs": round(4.0 * rows * DIM / (ms * 1e-3) / 1e12, 3),
-                    "frac_of_8TBs": round(hbm_ms / ms, 4),
-                    "binding_roof": "hbm" if hbm_ms >= mfma_ms else mname,
-                    "frac_of_binding_roof": round(max(hbm_ms, mfma_ms) / ms, 4)})
+                    "frac_of_8TBs": round(hbm_ms / ms, 4), "corpus_bytes_per_element_read": bpe,
+                    "binding_roof": "hbm" if hbm_phys_ms >= mfma_ms else mname,
+                    "frac_of_binding_roof": round(max(hbm_phys_ms, mfma_ms) / ms, 4)})
     return out
 
 
@@ -582,7 +585,8 @@ def main():
         # bytes the kernel stages from L2 into LDS per step: (corpus rows + query rows) x row bytes, per workgroup tile
         tiles_q = -(-B // 256) if kind in (5, 6) else -(-B // 128)
         row_tiles = -(-rows // 256)
-        stage_bytes = row_tiles * tiles_q * DIM * ((256 * 4) + (256 if kind in (5, 6) else 128) * (2 if form == 3 else 4))
+        img_bytes = idx.f16_image_bytes if form == 3 else 0  # the fp16 route's own copy of the corpus (2 B per element)
+        stage_bytes = row_tiles * tiles_q * DIM * ((256 * (2 if img_bytes else 4)) + (256 if kind in (5, 6) else 128) * (2 if form == 3 else 4))
         return {"value": round(B * args.steps / f_el, 1), "unit": "queries/s", "ms_per_step": round(1e3 * f_el / args.steps, 4),
                 "route": rname, "results_identical_to_f32_mode": same, "fallback_queries": int(f_fb),
                 "roofline": {"bound": "mfma", "kernel": rname, "achieved": round(ach, 1),
@@ -591,8 +595,9 @@ def main():
                              "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "kernel_ms_per_step": round(kms, 4),
                              "launches_per_step": f_launch / args.steps,
                              "l2_to_lds_staged_TBs": round(stage_bytes / (kms * 1e-3) / 1e12, 2) if kms > 0 else None,
-                             "hbm_floor_ms": round(4.0 * rows * DIM / (PEAK_HBM_GBS * 1e9) * 1e3, 4)},
-                "note": note}, labf, ddf
+                             "hbm_floor_ms": round(4.0 * rows * DIM / (PEAK_HBM_GBS * 1e9) * 1e3, 4),
+                             "corpus_bytes_read_per_pass": int((2 if img_bytes else 4) * rows * DIM)},
+                "extra_hbm_bytes": int(img_bytes), "note": note}, labf, ddf
 
     auto_lab = auto_dist = None
     if not args.no_fast and single:
@@ -600,14 +605,17 @@ def main():
         try:
             result["auto_path"], auto_lab, auto_dist = mode_leg(
                 CAND_AUTO,
-                "LB_CAND_AUTO, the library default: the cheapest exact route -- here ONE fp16 MFMA product per element (corpus "
-                "rounded to fp16 in registers, 512 candidates kept per query, error bound 1.1e-3 |q||x| in the containment proof); "
-                "reported distances/ids come from the exact f32 re-rank, as in every mode; no second copy of the corpus")
-            result["auto_path"]["extra_hbm_bytes"] = 0
+                "LB_CAND_AUTO, the library default: the cheapest exact route -- here ONE fp16 MFMA product per element over the "
+                "index's fp16 copy of the corpus (kept while memory allows: extra_hbm_bytes; 512 candidates per query, error bound "
+                "1.1e-3 |q||x| in the containment proof); reported distances/ids come from the exact f32 re-rank, as in every mode")
+            idx.set_f16_image(0)
+            result["auto_path_without_fp16_copy"], _, _ = mode_leg(
+                CAND_AUTO, "the same with lb_gpu_index_set_f16_image(h, 0): no second copy, the f32 rows are rounded to fp16 in registers "
+                           "(what AUTO does when memory is short)")
+            idx.set_f16_image(1)
             result["split_bf16_in_registers"], _, _ = mode_leg(
                 CAND_INREG, "lb_gpu_index_set_candidate_mode(LB_CAND_SPLIT_BF16_INREG): hi*hi + hi*lo + lo*hi on the bf16 MFMA, both "
                             "f32 operands split in registers (what AUTO falls back to when the corpus norms rule fp16 out)")
-            result["split_bf16_in_registers"]["extra_hbm_bytes"] = 0
         except Exception as e:  # keep the primary line even if an optional leg fails
             result["auto_path"] = {"error": str(e)}
         # ---- opt-in: pre-split bf16 image of the corpus (a second N*D*4-byte copy) --------------------------------
@@ -615,6 +623,7 @@ def main():
             result["split_bf16_candidates"], _, _ = mode_leg(
                 CAND_IMAGE, "opt-in lb_gpu_index_set_candidate_mode(LB_CAND_SPLIT_BF16): the split contraction over a pre-split image")
             result["split_bf16_candidates"]["extra_hbm_bytes"] = int(4 * rows * DIM)
+            result["split_bf16_candidates"]["roofline"]["corpus_bytes_read_per_pass"] = int(4 * rows * DIM)
         except Exception as e:
             result["split_bf16_candidates"] = {"error": str(e)}
         finally:

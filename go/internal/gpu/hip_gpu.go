@@ -225,6 +225,35 @@ func (idx *HIPIndex) SetCandidateMode(mode int) error {
 	return nil
 }
 
+// SetF16Image controls the fp16 copy of the corpus the single-product route reads (half the corpus's bytes again, kept only
+// while the device has room: lb_gpu_index_set_f16_image).  true is the default; false trades ~20 % of large-batch throughput
+// for the memory.  Results do not depend on it.
+func (idx *HIPIndex) SetF16Image(on bool) error {
+	idx.mu.Lock()
+	defer idx.mu.Unlock()
+	if idx.closed {
+		return fmt.Errorf("index is closed")
+	}
+	m := C.int(0)
+	if on {
+		m = 1
+	}
+	if rc := C.lb_gpu_index_set_f16_image(idx.h, m); rc != C.LB_OK {
+		return hipError(idx.h, "set_f16_image", rc)
+	}
+	return nil
+}
+
+// F16ImageBytes reports the HBM that copy holds right now (0: none) -- for the memory gauge.
+func (idx *HIPIndex) F16ImageBytes() int64 {
+	idx.mu.RLock()
+	defer idx.mu.RUnlock()
+	if idx.closed {
+		return 0
+	}
+	return int64(C.lb_gpu_index_f16_image_bytes(idx.h))
+}
+
 // FusedGiveups reports how many small-batch searches had their in-launch threshold hand-off give up (~1 ms) and were
 // redone on the exact path since the index was created: a latency event for a metrics gauge.
 func (idx *HIPIndex) FusedGiveups() int64 {
