@@ -604,7 +604,8 @@ void scan_with_retry(lb_gpu_index *h, Workspace *w, hipStream_t s, const float *
 // Cost model: a pass over `n` positions of dimension D costs  n * (alpha * D + beta) [+ gamma]  per query tile, with
 // the constants measured per kernel on MI355X over D in {128 .. 1536} x n in {100k .. 10M} (tools/route_grid.py; the
 // GPU test test_route_choice_is_near_the_best_forced_route checks the choice against every forced route).
-enum RouteKind { ROUTE_NARROW32 = 1, ROUTE_NARROW64 = 2, ROUTE_TALL = 3, ROUTE_WIDE = 4, ROUTE_TALL2 = 5, ROUTE_TALL16 = 6 };
+enum RouteKind { ROUTE_NARROW32 = 1, ROUTE_NARROW64 = 2, ROUTE_TALL = 3, ROUTE_WIDE = 4, ROUTE_TALL2 = 5, ROUTE_TALL16 = 6,
+                 ROUTE_NARROW16 = 7 /* the fp16 route's 64-query tile over the fp16 copy: same pipeline as TALL16, reported apart */ };
 struct Route {
     int kind = ROUTE_WIDE;
     int split = 0;
@@ -632,6 +633,7 @@ constexpr RouteCost kCostTall16{0.000540, 0.0800, 0.000660, 0.000140, 0.10}; // 
                                                                              // tile at 1M x 768, a single tile streams the corpus at 6 TB/s
 constexpr RouteCost kCostTall16Img{0.000460, 0.0500, 0.000330, 0.000040, 0.10}; // the same from the corpus's fp16 image: 0.40 ms per tile at
                                                                                 // 1M x 768, never bound by the stream (1.5 GB)
+constexpr RouteCost kCostNarrow16{0.000100, 0.0300, 0.000340, 0.000030, 0.10};  // up to 64 queries over the fp16 copy: its HBM stream (6 TB/s)
 inline double route_ms(const RouteCost &c, int64_t n, int D, int tiles)
 {
     const double nd = 1e-6 * (double)n;
@@ -672,9 +674,16 @@ static Route choose_route(int nq, int64_t n, int D, int cmode, bool narrow_ok, b
     // one fp16 product instead of three bf16 ones (split code 3): AUTO and the explicit LB_CAND_F16, while the corpus norms
     // allow it (f16_ok) and there are enough tiles to fill the chip
     static const int f16_on = lb_tunable("LB_F16", 1);
-    if (narrow_ok && f16_ok && f16_on && !image && nq > 32 &&
-        (cmode == LB_CAND_F16 || (cmode == LB_CAND_AUTO && n >= 262144))) // (below: launch overheads decide, and the narrow tiles win)
-        add(ROUTE_TALL16, 3, route_ms(have_f16_image ? kCostTall16Img : kCostTall16, n, D, tiles256));
+    if (narrow_ok && f16_ok && f16_on && !image && (nq > 32 || have_f16_image) &&
+        (cmode == LB_CAND_F16 || (cmode == LB_CAND_AUTO && n >= 262144))) { // (below: launch overheads decide, and the narrow tiles win)
+        if (have_f16_image && nq <= 64) {
+            // + what the route pays per query beside the stream: twice (beyond 1024 dimensions four times) the candidates to
+            // select and re-rank, and their admissions
+            const double q1 = D > 1024 ? 0.0099 : 0.0030, q2 = D > 1024 ? 0.0040 : 0.0012;
+            add(ROUTE_NARROW16, 3, route_ms(kCostNarrow16, n, D, 1) + q1 * std::min(nq, 32) + q2 * std::max(nq - 32, 0));
+        }
+        else add(ROUTE_TALL16, 3, route_ms(have_f16_image ? kCostTall16Img : kCostTall16, n, D, tiles256));
+    }
     if (image && !tall_on) add(ROUTE_WIDE, 1, route_ms(kCostWideF32, n, D, tiles128) * 0.4);
     else if (cmode == LB_CAND_F32_MFMA || cmode == LB_CAND_AUTO || nc == 0) add(ROUTE_WIDE, 0, route_ms(kCostWideF32, n, D, tiles128));
 #ifdef LB_DIAG
@@ -688,8 +697,15 @@ static Route choose_route(int nq, int64_t n, int D, int cmode, bool narrow_ok, b
     if (cmode == LB_CAND_F32_MFMA && nq > narrow_max) return cand[nc - 1]; // strict mode: the f32 tile beyond the narrow range
     if (cmode == LB_CAND_F16)
         for (int i = 0; i < nc; i++)
-            if (cand[i].kind == ROUTE_TALL16) return cand[i];
-    if (nq <= 32 && nc > 0 && cand[0].kind == ROUTE_NARROW32) return cand[0]; // one pass of the 32-query tile: nothing is cheaper
+            if (cand[i].kind == ROUTE_TALL16 || cand[i].kind == ROUTE_NARROW16) return cand[i];
+    if (nq <= 32 && nc > 0 && cand[0].kind == ROUTE_NARROW32) {
+        // one pass of the 32-query tile (sample and thresholds inside the launch): 0.55 ms per 1M x 768 whatever the model
+        // above says about tile counts -- nothing is cheaper but the stream of the fp16 copy
+        cand[0].cost_ms = 1e-6 * (double)n * (double)D * 0.00072;
+        for (int i = 1; i < nc; i++)
+            if (cand[i].kind == ROUTE_NARROW16 && cand[i].cost_ms < cand[0].cost_ms) return cand[i];
+        return cand[0];
+    }
     int best = 0;
     for (int i = 1; i < nc; i++)
         if (cand[i].cost_ms < cand[best].cost_ms) best = i;
@@ -753,9 +769,9 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     const bool use_narrow = route.kind == ROUTE_NARROW32 || route.kind == ROUTE_NARROW64;
     const bool tile64 = route.kind == ROUTE_NARROW64;
     const bool nsplit = use_narrow && route.split == 2;
-    const bool use_tall = route.kind == ROUTE_TALL || route.kind == ROUTE_TALL2 || route.kind == ROUTE_TALL16;
+    const bool use_tall = route.kind == ROUTE_TALL || route.kind == ROUTE_TALL2 || route.kind == ROUTE_TALL16 || route.kind == ROUTE_NARROW16;
     const bool use_tall2 = route.kind == ROUTE_TALL2;
-    const bool use_tall16 = route.kind == ROUTE_TALL16;
+    const bool use_tall16 = route.kind == ROUTE_TALL16 || route.kind == ROUTE_NARROW16; // (the launcher takes the 64-query tile by itself)
     const int wsplit = use_narrow ? 0 : route.split;
     const float *gx = h->d_X, *gq = d_q;
     const float u24 = 5.9604645e-8f;

@@ -767,6 +767,225 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
     h_wait_vmcnt<0>(); // the re-read stages behind the last tile: nothing may land in LDS after the workgroup has gone
 }
 
+// ---- up to 64 queries over the corpus's fp16 image: the pass is the image's HBM stream ---------------------------------------
+// Same persistent pipeline, tile 256 rows x 64 queries: a wave owns 32 rows x 64 queries (two MFMA tiles), stages exactly the
+// corpus rows it consumes (2 requests per stage) and an eighth of the query tile (one request, lanes 0 .. 31); a stage is
+// 16 KB + 4 KB, the ring SIX stages deep (a stage is requested five K-steps ahead: 80 KB of corpus in flight per CU), loads
+// non-temporal (every line is read once).  1M x 768: the image is 1.5 GB, the pass 0.25-0.3 ms where the f32 rows take 0.49.
+template <int METRIC>
+__global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tall16Args a, int spx)
+{
+    constexpr int NST = 6, A_BYTES = H_BM * H_BK * 2, BN = 64, B_BYTES = BN * H_BK * 2, STAGE = A_BYTES + B_BYTES;
+    constexpr int NPS = 3, DIST = NST - 1, H1 = 2;
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int jtop = a.n_row_tiles - 1 - xcd;
+    if (jtop < 0 || slot > (jtop >> 3)) return;
+    const int n_my = ((jtop >> 3) - slot) / spx + 1; // corpus tiles of this workgroup: 8 (slot + spx i) + xcd
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char hlds[];
+    unsigned char *ring = hlds;
+    float *s_auxp = reinterpret_cast<float *>(ring + NST * STAGE); // [2][512]
+    const uint32_t ring_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)ring;
+    const uint32_t aux_base = ring_base + (uint32_t)(NST * STAGE);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int last_q = a.nq - 1;
+    const int64_t last_pos = a.row_end - a.row_begin - 1;
+    const float *auxg = METRIC == METRIC_L2 ? a.norm2 + a.row_begin : (METRIC == METRIC_COS ? a.rnorm + a.row_begin : nullptr);
+    auto rt_of = [&](int i) { return (slot + spx * i) * 8 + xcd; };
+
+    const unsigned char *srcA[2], *srcB;
+    const unsigned char *Xhb = reinterpret_cast<const unsigned char *>(a.Xh) + a.row_begin * (int64_t)(H_BK * 2);
+    const int64_t plane_bytes = a.xh_cap * (int64_t)(H_BK * 2);
+    auto set_srcA = [&](int rt) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int row = wave * 32 + i * 16 + (lane >> 2);
+            const int c = (lane & 3) ^ ((row >> 2) & 3);
+            int64_t pos = (int64_t)rt * H_BM + row;
+            if (pos > last_pos) pos = last_pos;
+            srcA[i] = Xhb + pos * (H_BK * 2) + 16 * c;
+        }
+    };
+    {
+        const int row = wave * 8 + ((lane & 31) >> 2); // (lanes 32 .. 63 do not take part in the query request)
+        const int c = (lane & 3) ^ ((row >> 2) & 3);
+        const int qr = row > last_q ? last_q : row;
+        srcB = reinterpret_cast<const unsigned char *>(a.Qh + (int64_t)qr * H_BK) + 16 * c;
+    }
+    const int64_t kb_stride = (int64_t)a.nq * (H_BK * 2);
+    const int nk = a.D / H_BK;
+
+    int it = 0, ik = 0, islot = 0;
+    bool cursor_new_tile = false;
+    auto piece = [&](int p) {
+        const uint32_t A = ring_base + (uint32_t)islot * STAGE + (uint32_t)(wave * 32 * 64);
+        const uint32_t B = ring_base + (uint32_t)islot * STAGE + A_BYTES + (uint32_t)(wave * 512);
+        if (p < 2) h_dma16<true>(srcA[p] + ik * plane_bytes, A + 1024u * p);
+        else if (lane < 32) h_dma16<false>(srcB + ik * kb_stride, B);
+    };
+    auto advance = [&]() {
+        islot = islot == NST - 1 ? 0 : islot + 1;
+        if (ik + 1 < nk) ik++;
+        else if (it + 1 < n_my) { it++; ik = 0; cursor_new_tile = true; }
+    };
+    auto aux_request = [&](int i) {
+        if (METRIC == METRIC_DOT) return;
+        int64_t pos = (int64_t)rt_of(i) * H_BM + ((wave & 3) * 64 + lane);
+        if (pos > last_pos) pos = last_pos;
+        uint32_t save;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(save) : "v"(auxg + pos), "s"(aux_base + (uint32_t)(i & 1) * 2048u + (uint32_t)wave * 256u));
+    };
+
+    set_srcA(rt_of(0));
+    aux_request(0);
+#pragma unroll
+    for (int st = 0; st < DIST; st++) {
+        if (cursor_new_tile) { set_srcA(rt_of(it)); cursor_new_tile = false; }
+#pragma unroll
+        for (int p = 0; p < NPS; p++) piece(p);
+        advance();
+    }
+
+    float tkc[2], qs[2], m2qs[2];
+#pragma unroll
+    for (int tn = 0; tn < 2; tn++) {
+        const int qj = tn * 32 + l31;
+        const int qc = qj < a.nq ? qj : a.nq - 1;
+        uint64_t tau = a.boot ? 0ull : a.cs.tau[qc];
+        if (qj >= a.nq) tau = 0ull;
+        const float tk = tau_key_of(tau);
+        qs[tn] = a.qinv[qc];
+        m2qs[tn] = -2.0f * qs[tn];
+        const float scale = __builtin_bit_cast(float, (254u << 23) - __builtin_bit_cast(uint32_t, qs[tn]));
+        tkc[tn] = METRIC == METRIC_L2 ? tk : tk * scale;
+    }
+    constexpr uint32_t WCAP = 100, WFLUSH = 56;
+    unsigned char *seg = reinterpret_cast<unsigned char *>(s_auxp + 2 * 512) + wave * 1024;
+    float *s_key = reinterpret_cast<float *>(seg);
+    uint32_t *s_rid = reinterpret_cast<uint32_t *>(s_key + WCAP);
+    uint16_t *s_q = reinterpret_cast<uint16_t *>(s_rid + WCAP);
+    uint32_t wcnt = 0;
+
+    auto load_frag = [&](int slot_, int kb, f16x8 &af, f16x8(&bf)[2]) {
+        const unsigned char *As = ring + slot_ * STAGE;
+        const unsigned char *Bs = As + A_BYTES;
+        af = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4 *>(As + hbswz(wave * 32 + l31, 2 * kb + h)));
+#pragma unroll
+        for (int tn = 0; tn < 2; tn++)
+            bf[tn] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4 *>(Bs + hbswz(tn * 32 + l31, 2 * kb + h)));
+    };
+
+    int cslot = 0;
+    f16x8 a0, b0[2];
+    h_wait_vmcnt<NPS *(DIST - 1)>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    load_frag(0, 0, a0, b0);
+    for (int i = 0; i < n_my; i++) {
+        const int rt = rt_of(i);
+        f32x16 acc[2];
+#pragma unroll
+        for (int y = 0; y < 2; y++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[y][r] = 0.f;
+
+        for (int kt = 0; kt < nk; kt++) {
+            f16x8 a1, b1[2];
+            load_frag(cslot, 1, a1, b1);
+            if (cursor_new_tile) { set_srcA(rt_of(it)); cursor_new_tile = false; }
+            if (kt == (nk > 1 ? 1 : 0) && i + 1 < n_my) aux_request(i + 1);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0[0], acc[0], 0, 0, 0);
+            piece(0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0[1], acc[1], 0, 0, 0);
+            piece(1);
+            // middle of the step (see the 256-query form): reads of stage kt complete, stage kt + 1 landed, barrier
+            __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0)
+            h_wait_vmcnt<NPS *(DIST - 2) + H1>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const int nslot = cslot == NST - 1 ? 0 : cslot + 1;
+            load_frag(nslot, 0, a0, b0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1[0], acc[0], 0, 0, 0);
+            piece(2);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1[1], acc[1], 0, 0, 0);
+            advance();
+            cslot = nslot;
+        }
+
+        // ---- epilogue of the tile (as the 256-query form: 2 VALU + 1 scalar branch per element, per-wave segments) ----------
+        const float *s_aux = s_auxp + (i & 1) * 512;
+        float aux[4][4];
+        const int64_t pos0 = (int64_t)rt * H_BM + wave * 32 + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int lr = wave * 32 + 8 * g + 4 * h;
+            f32x4 av = {1.f, 1.f, 1.f, 1.f};
+            if (METRIC != METRIC_DOT) av = *reinterpret_cast<const f32x4 *>(&s_aux[lr]);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float v = METRIC == METRIC_L2 ? av[e] : -av[e];
+                aux[g][e] = pos0 + 8 * g + e <= last_pos ? v : __builtin_nanf("");
+            }
+        }
+        const uint32_t rid0 = (uint32_t)(a.row_begin + pos0);
+#pragma unroll
+        for (int tn = 0; tn < 2; tn++) {
+            const int qj = tn * 32 + l31;
+            const bool qok = qj < a.nq;
+            uint64_t *list = a.cs.lists + (size_t)(qok ? qj : 0) * a.cs.cap;
+            if (a.boot) {
+                if (qok) {
+#pragma unroll
+                    for (int x = 0; x < 16; x++) {
+                        const float kp = METRIC == METRIC_L2 ? fmaf(acc[tn][x], m2qs[tn], aux[x >> 2][x & 3]) : acc[tn][x] * aux[x >> 2][x & 3];
+                        if (pos0 + 8 * (x >> 2) + (x & 3) <= last_pos)
+                            list[pos0 + 8 * (x >> 2) + (x & 3)] = pack_entry(METRIC == METRIC_L2 ? kp : kp * qs[tn], rid0 + 8 * (x >> 2) + (x & 3));
+                    }
+                }
+                continue;
+            }
+#pragma unroll
+            for (int x = 0; x < 16; x++) {
+                const float kp = METRIC == METRIC_L2 ? fmaf(acc[tn][x], m2qs[tn], aux[x >> 2][x & 3]) : acc[tn][x] * aux[x >> 2][x & 3];
+                const bool adm = kp <= tkc[tn];
+                const uint64_t am = __builtin_amdgcn_ballot_w64(adm);
+                if (am != 0) {
+                    if (adm) {
+                        const uint32_t sl = wcnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
+                        const float key = METRIC == METRIC_L2 ? kp : kp * qs[tn];
+                        const uint32_t rid = rid0 + 8 * (x >> 2) + (x & 3);
+                        if (sl < WCAP) {
+                            s_key[sl] = key;
+                            s_rid[sl] = rid;
+                            s_q[sl] = (uint16_t)qj;
+                        } else {
+                            const uint32_t pos = atomicAdd(&a.cs.cnt[qj], 1u);
+                            if (pos < a.cs.cap) list[pos] = pack_entry(key, rid);
+                        }
+                    }
+                    wcnt += (uint32_t)__builtin_popcountll(am);
+                }
+            }
+        }
+        if (!a.boot && (wcnt > WFLUSH || i + 1 == n_my)) {
+            const uint32_t total = wcnt < WCAP ? wcnt : WCAP;
+            for (uint32_t z = lane; z < total; z += 64) {
+                const int qg = (int)s_q[z];
+                const uint32_t pos = atomicAdd(&a.cs.cnt[qg], 1u);
+                if (pos < a.cs.cap) a.cs.lists[(size_t)qg * a.cs.cap + pos] = pack_entry(s_key[z], s_rid[z]);
+            }
+            wcnt = 0;
+        }
+    }
+    h_wait_vmcnt<0>();
+}
+
 // f32 [nq][D] -> fp16 [D / 32][nq][32], each query scaled by the power of two that brings its norm into [1, 2); qinv[q] = 1 / scale.
 // One wave per query.  (A zero or non-finite query keeps scale 1: its search is answered by the exact scan anyway.)
 __global__ __launch_bounds__(256) void queries_to_f16_kernel(const float *Q, int nq, int D, _Float16 *Qh, float *qinv)
@@ -863,6 +1082,22 @@ void launch_gemm_filter_tall16(int metric, const float *X, const float *norm2, c
     const int spx = cus / 8;
     if (persist && !rowmap && !mask && spx >= 1 && a.n_q_tiles <= spx) {
         const bool img = Xh != nullptr; // (sync_f16_image: in step with the corpus, K-blocked, xh_cap rows per plane)
+        static const int n16 = lb_tunable("LB_F16_NARROW", 1);
+        if (img && nq <= 64 && n16) { // the 64-query tile: the pass is the image's HBM stream
+            const size_t nshmem = (size_t)6 * (H_BM * H_BK * 2 + 64 * H_BK * 2) + 2 * 512 * sizeof(float) + 8 * 1024;
+            dim3 ngrid((unsigned)(spx * 8));
+#define LB_NARROW16(M)                                                                                           \
+    do {                                                                                                         \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_filter_narrow16p_kernel<M>),              \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)nshmem);                      \
+        hipLaunchKernelGGL((gemm_filter_narrow16p_kernel<M>), ngrid, dim3(H_THREADS), nshmem, s, a, spx);        \
+    } while (0)
+            if (metric == METRIC_L2) LB_NARROW16(METRIC_L2);
+            else if (metric == METRIC_COS) LB_NARROW16(METRIC_COS);
+            else LB_NARROW16(METRIC_DOT);
+#undef LB_NARROW16
+            return;
+        }
         const size_t pshmem = (img ? (size_t)4 * (H_BM * H_BK * 2 + H_B_BYTES) : (size_t)H_NST * H_STAGE_BYTES) + 2 * 512 * sizeof(float) +
                               8 * 1024; // ring, side inputs, admission segments
         const bool pnt = a.n_q_tiles <= 1;

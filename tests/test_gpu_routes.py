@@ -41,7 +41,7 @@ def test_route_choice_is_near_the_best_forced_route(D, n):
     del X
     bad = []
     try:
-        for B in (48, 96, 128, 256, 384, 512, 1024):
+        for B in (8, 32, 48, 96, 128, 256, 384, 512, 1024):
             od = torch.empty((B, K), device="cuda")
             ol = torch.empty((B, K), dtype=torch.int64, device="cuda")
             os.environ["LB_FORCE_ROUTE"] = "0"
@@ -49,7 +49,7 @@ def test_route_choice_is_near_the_best_forced_route(D, n):
             picked = raw.lb_debug_last_route() // 10
             want = (ol.cpu().numpy().copy(), od.cpu().numpy().copy())
             forced = {}
-            for r in (1, 2, 3, 5, 6):  # narrow32, narrow64, tall, tall2, tall16 (the f32 tile is never competitive: tools/route_grid.py)
+            for r in (1, 2, 3, 5, 6, 7):  # narrow32, narrow64, tall, tall2, tall16, narrow16 (the f32 tile is never competitive: tools/route_grid.py)
                 os.environ["LB_FORCE_ROUTE"] = str(r)
                 idx.search_device(B, Q.data_ptr(), K, od.data_ptr(), ol.data_ptr())
                 if raw.lb_debug_last_route() // 10 != r:

@@ -10,13 +10,13 @@ sys.path.insert(0, ROOT)
 import torch
 from longbow_amd import _lib, gpu
 
-NAMES = {1: "narrow32", 2: "narrow64", 3: "tall", 4: "wide_f32", 5: "tall2", 6: "tall16"}
+NAMES = {1: "narrow32", 2: "narrow64", 3: "tall", 4: "wide_f32", 5: "tall2", 6: "tall16", 7: "narrow16"}
 
 
 def grid(quick):
     dims = (128, 768) if quick else (128, 384, 768, 1536)
     ns = (100_000, 1_000_000) if quick else (100_000, 1_000_000, 4_000_000)
-    bs = (64, 256, 1024) if quick else (48, 64, 96, 128, 192, 256, 384, 512, 768, 1024)
+    bs = (64, 256, 1024) if quick else (8, 32, 48, 64, 96, 128, 192, 256, 384, 512, 768, 1024)
     return dims, ns, bs
 
 
@@ -55,7 +55,7 @@ def main():
                 t_auto = time_search(idx, Q, B, K, od, ol)
                 picked = raw.lb_debug_last_route() // 10
                 forced = {}
-                for r in (1, 2, 3, 5, 6, 4):
+                for r in (1, 2, 3, 5, 6, 7, 4):
                     os.environ["LB_FORCE_ROUTE"] = str(r)
                     idx.search_device(B, Q.data_ptr(), K, od.data_ptr(), ol.data_ptr())
                     if raw.lb_debug_last_route() // 10 != r:
