@@ -729,7 +729,19 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     static const int narrow_max = lb_tunable("LB_NARROW_MAXQ", 384);
     // rows with inf / NaN components: the MFMA pipeline's keys and error bounds assume finite data;
     // the scan path orders non-finite distances canonically (NaN last)
-    if (h->nonfinite || nq < (narrow_ok ? narrow_min : kGemmMinQ)) {
+    const int cmode = h->cand_mode.load();
+    // (the fp16 image serves unfiltered searches: under a filter the kernel gathers f32 rows)
+    const bool have_xh = h->d_Xh != nullptr && h->xh_rows == h->n && !rv.rowmap && !mask;
+    // 1 .. 4 queries: the exact scan streams the f32 corpus (0.52 ms per 1M x 768); with the fp16 copy the candidate pass
+    // streams half the bytes and the exact re-rank of 512 candidates costs 0.03 ms -- taken when the model says it is cheaper
+    bool small_on_copy = false;
+    if (!h->nonfinite && nq < narrow_min && narrow_ok && have_xh && h->f16_ok && allow_f16 &&
+        (cmode == LB_CAND_F16 || (cmode == LB_CAND_AUTO && h->f16_skip.load(std::memory_order_relaxed) == 0))) {
+        const double scan_ms = 1e-6 * (double)n * ((double)h->dim * 0.00066 + 0.04);
+        const double copy_ms = route_ms(kCostNarrow16, n, h->dim, 1) + (h->dim > 1024 ? 0.0099 : 0.0030) * nq;
+        small_on_copy = cmode == LB_CAND_F16 || copy_ms < scan_ms;
+    }
+    if (h->nonfinite || (nq < (narrow_ok ? narrow_min : kGemmMinQ) && !small_on_copy)) {
         h->last_route.store(0, std::memory_order_relaxed);
         std::vector<int> all(nq);
         for (int i = 0; i < nq; i++) all[i] = i;
@@ -738,15 +750,12 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     }
 
     // ---- batched path: MFMA candidate generation + exact re-rank --------------------
-    const int cmode = h->cand_mode.load();
     const bool have_image = h->d_Xs != nullptr && h->xs_rows == h->n && h->dim % 32 == 0;
     bool f16_offer = h->f16_ok && allow_f16;
     if (f16_offer && cmode == LB_CAND_AUTO && h->f16_skip.load(std::memory_order_relaxed) > 0) {
         h->f16_skip.fetch_sub(1, std::memory_order_relaxed);
         f16_offer = false;
     }
-    // (the fp16 image serves unfiltered searches: under a filter the kernel gathers f32 rows)
-    const bool have_xh = h->d_Xh != nullptr && h->xh_rows == h->n && !rv.rowmap && !mask;
     const Route route = choose_route(nq, n, h->dim, cmode, narrow_ok, have_image, f16_offer, have_xh);
     h->last_route.store(route.kind * 10 + route.split, std::memory_order_relaxed);
 #ifdef LB_DIAG
