@@ -23,9 +23,15 @@
 // (index.hip tracks both norms at Add).
 //
 // Shape: as kernels_gemm_tall2.hip (8 waves = 4 x 2, a wave owns 64 rows x 128 queries, K-step of 32 = one 128-B line per
-// corpus row) but a stage is 256 x 128 B of corpus + 256 x 64 B of queries = 48 KB, so THREE stages fit (144 KB): the DMA
-// of stage k + 2 is requested at step k and has two whole steps to land, and the wait in front of a step is
-// s_waitcnt vmcnt(6) -- never 0 inside the loop.  16 MFMAs per wave and step.
+// corpus row).  Three kernels, one contraction:
+//   gemm_filter_tall16p_kernel   persistent (one workgroup per CU walks its corpus tiles as one flat pipeline); corpus from the
+//                                index's fp16 copy (stage 16 + 16 KB, four-stage ring, fragment reads pipelined behind a
+//                                mid-step barrier) or from the f32 rows rounded in registers (stage 32 + 16 KB, three stages)
+//   gemm_filter_narrow16p_kernel the same pipeline on a 256 x 64 tile over the fp16 copy, six stages: 1 .. 64 queries at the
+//                                copy's HBM stream
+//   gemm_filter_tall16_kernel    one workgroup per tile, f32 rows through a row map / mask: filtered searches, and batches
+//                                with more query tiles than an XCD has workgroup slots
+// What each design decision bought is in DESIGN.md 4.2 (measured with tools/experiments/dma_patterns.hip).
 #include "lb_device.h"
 
 #include <type_traits>
