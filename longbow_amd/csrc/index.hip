@@ -605,7 +605,7 @@ void scan_with_retry(lb_gpu_index *h, Workspace *w, hipStream_t s, const float *
 // the constants measured per kernel on MI355X over D in {128 .. 1536} x n in {100k .. 10M} (tools/route_grid.py; the
 // GPU test test_route_choice_is_near_the_best_forced_route checks the choice against every forced route).
 enum RouteKind { ROUTE_NARROW32 = 1, ROUTE_NARROW64 = 2, ROUTE_TALL = 3, ROUTE_WIDE = 4, ROUTE_TALL2 = 5, ROUTE_TALL16 = 6,
-                 ROUTE_NARROW16 = 7 /* the fp16 route's 64-query tile over the fp16 copy: same pipeline as TALL16, reported apart */ };
+                 ROUTE_NARROW16 = 7 /* the fp16 route's 64- / 128-query tile over the fp16 copy: same pipeline as TALL16, reported apart */ };
 struct Route {
     int kind = ROUTE_WIDE;
     int split = 0;
@@ -676,10 +676,10 @@ static Route choose_route(int nq, int64_t n, int D, int cmode, bool narrow_ok, b
     static const int f16_on = lb_tunable("LB_F16", 1);
     if (narrow_ok && f16_ok && f16_on && !image && (nq > 32 || have_f16_image) &&
         (cmode == LB_CAND_F16 || (cmode == LB_CAND_AUTO && n >= 262144))) { // (below: launch overheads decide, and the narrow tiles win)
-        if (have_f16_image && nq <= 64) {
+        if (have_f16_image && nq <= 128) { // (the 64- / 128-query tile of the persistent kernel)
             // + what the route pays per query beside the stream: twice (beyond 1024 dimensions four times) the candidates to
             // select and re-rank, and their admissions
-            const double q1 = D > 1024 ? 0.0099 : 0.0030, q2 = D > 1024 ? 0.0040 : 0.0012;
+            const double q1 = D > 1024 ? 0.0099 : 0.0030, q2 = 0.0012;
             add(ROUTE_NARROW16, 3, route_ms(kCostNarrow16, n, D, 1) + q1 * std::min(nq, 32) + q2 * std::max(nq - 32, 0));
         }
         else add(ROUTE_TALL16, 3, route_ms(have_f16_image ? kCostTall16Img : kCostTall16, n, D, tiles256));

@@ -773,15 +773,17 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
     h_wait_vmcnt<0>(); // the re-read stages behind the last tile: nothing may land in LDS after the workgroup has gone
 }
 
-// ---- up to 64 queries over the corpus's fp16 image: the pass is the image's HBM stream ---------------------------------------
-// Same persistent pipeline, tile 256 rows x 64 queries: a wave owns 32 rows x 64 queries (two MFMA tiles), stages exactly the
-// corpus rows it consumes (2 requests per stage) and an eighth of the query tile (one request, lanes 0 .. 31); a stage is
-// 16 KB + 4 KB, the ring SIX stages deep (a stage is requested five K-steps ahead: 80 KB of corpus in flight per CU), loads
-// non-temporal (every line is read once).  1M x 768: the image is 1.5 GB, the pass 0.25-0.3 ms where the f32 rows take 0.49.
-template <int METRIC>
+// ---- up to 128 queries over the corpus's fp16 image: the pass is the image's HBM stream --------------------------------------
+// Same persistent pipeline, tile 256 rows x BN queries (64 or 128): a wave owns 32 rows x BN queries (BN / 32 MFMA tiles),
+// stages exactly the corpus rows it consumes (2 requests per stage) and an eighth of the query tile (one request: lanes
+// 0 .. 31 at BN = 64, all lanes at 128); a stage is 16 KB + 4 / 8 KB, the ring SIX / FIVE stages deep (64-80 KB of corpus in
+// flight per CU), loads non-temporal (every line is read once).  1M x 768: the image is 1.5 GB, the pass 0.24-0.3 ms where
+// the f32 rows take 0.49.
+template <int METRIC, int BN>
 __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tall16Args a, int spx)
 {
-    constexpr int NST = 6, A_BYTES = H_BM * H_BK * 2, BN = 64, B_BYTES = BN * H_BK * 2, STAGE = A_BYTES + B_BYTES;
+    constexpr int TN = BN / 32;
+    constexpr int NST = BN == 64 ? 6 : 5, A_BYTES = H_BM * H_BK * 2, B_BYTES = BN * H_BK * 2, STAGE = A_BYTES + B_BYTES;
     constexpr int NPS = 3, DIST = NST - 1, H1 = 2;
     const int b = blockIdx.x;
     const int xcd = b & 7, slot = b >> 3;
@@ -818,7 +820,8 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
         }
     };
     {
-        const int row = wave * 8 + ((lane & 31) >> 2); // (lanes 32 .. 63 do not take part in the query request)
+        // BN = 64: 8 query rows per wave, lanes 32 .. 63 do not take part in the request; BN = 128: 16 rows, all lanes
+        const int row = BN == 64 ? wave * 8 + ((lane & 31) >> 2) : wave * 16 + (lane >> 2);
         const int c = (lane & 3) ^ ((row >> 2) & 3);
         const int qr = row > last_q ? last_q : row;
         srcB = reinterpret_cast<const unsigned char *>(a.Qh + (int64_t)qr * H_BK) + 16 * c;
@@ -830,9 +833,9 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
     bool cursor_new_tile = false;
     auto piece = [&](int p) {
         const uint32_t A = ring_base + (uint32_t)islot * STAGE + (uint32_t)(wave * 32 * 64);
-        const uint32_t B = ring_base + (uint32_t)islot * STAGE + A_BYTES + (uint32_t)(wave * 512);
+        const uint32_t B = ring_base + (uint32_t)islot * STAGE + A_BYTES + (uint32_t)(wave * (BN * 8));
         if (p < 2) h_dma16<true>(srcA[p] + ik * plane_bytes, A + 1024u * p);
-        else if (lane < 32) h_dma16<false>(srcB + ik * kb_stride, B);
+        else if (BN == 128 || lane < 32) h_dma16<false>(srcB + ik * kb_stride, B);
     };
     auto advance = [&]() {
         islot = islot == NST - 1 ? 0 : islot + 1;
@@ -858,9 +861,9 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
         advance();
     }
 
-    float tkc[2], qs[2], m2qs[2];
+    float tkc[TN], qs[TN], m2qs[TN];
 #pragma unroll
-    for (int tn = 0; tn < 2; tn++) {
+    for (int tn = 0; tn < TN; tn++) {
         const int qj = tn * 32 + l31;
         const int qc = qj < a.nq ? qj : a.nq - 1;
         uint64_t tau = a.boot ? 0ull : a.cs.tau[qc];
@@ -878,38 +881,39 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
     uint16_t *s_q = reinterpret_cast<uint16_t *>(s_rid + WCAP);
     uint32_t wcnt = 0;
 
-    auto load_frag = [&](int slot_, int kb, f16x8 &af, f16x8(&bf)[2]) {
+    auto load_frag = [&](int slot_, int kb, f16x8 &af, f16x8(&bf)[TN]) {
         const unsigned char *As = ring + slot_ * STAGE;
         const unsigned char *Bs = As + A_BYTES;
         af = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4 *>(As + hbswz(wave * 32 + l31, 2 * kb + h)));
 #pragma unroll
-        for (int tn = 0; tn < 2; tn++)
+        for (int tn = 0; tn < TN; tn++)
             bf[tn] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4 *>(Bs + hbswz(tn * 32 + l31, 2 * kb + h)));
     };
 
     int cslot = 0;
-    f16x8 a0, b0[2];
+    f16x8 a0, b0[TN];
     h_wait_vmcnt<NPS *(DIST - 1)>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     load_frag(0, 0, a0, b0);
     for (int i = 0; i < n_my; i++) {
         const int rt = rt_of(i);
-        f32x16 acc[2];
+        f32x16 acc[TN];
 #pragma unroll
-        for (int y = 0; y < 2; y++)
+        for (int y = 0; y < TN; y++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[y][r] = 0.f;
 
         for (int kt = 0; kt < nk; kt++) {
-            f16x8 a1, b1[2];
+            f16x8 a1, b1[TN];
             load_frag(cslot, 1, a1, b1);
             if (cursor_new_tile) { set_srcA(rt_of(it)); cursor_new_tile = false; }
             if (kt == (nk > 1 ? 1 : 0) && i + 1 < n_my) aux_request(i + 1);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0[0], acc[0], 0, 0, 0);
-            piece(0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0[1], acc[1], 0, 0, 0);
-            piece(1);
+#pragma unroll
+            for (int tn = 0; tn < TN; tn++) {
+                acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0[tn], acc[tn], 0, 0, 0);
+                if (tn < 2) piece(tn);
+            }
             // middle of the step (see the 256-query form): reads of stage kt complete, stage kt + 1 landed, barrier
             __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0)
             h_wait_vmcnt<NPS *(DIST - 2) + H1>();
@@ -917,9 +921,11 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
             asm volatile("" ::: "memory");
             const int nslot = cslot == NST - 1 ? 0 : cslot + 1;
             load_frag(nslot, 0, a0, b0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1[0], acc[0], 0, 0, 0);
-            piece(2);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1[1], acc[1], 0, 0, 0);
+#pragma unroll
+            for (int tn = 0; tn < TN; tn++) {
+                acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1[tn], acc[tn], 0, 0, 0);
+                if (tn == 0) piece(2);
+            }
             advance();
             cslot = nslot;
         }
@@ -941,7 +947,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
         }
         const uint32_t rid0 = (uint32_t)(a.row_begin + pos0);
 #pragma unroll
-        for (int tn = 0; tn < 2; tn++) {
+        for (int tn = 0; tn < TN; tn++) {
             const int qj = tn * 32 + l31;
             const bool qok = qj < a.nq;
             uint64_t *list = a.cs.lists + (size_t)(qok ? qj : 0) * a.cs.cap;
@@ -1089,18 +1095,26 @@ void launch_gemm_filter_tall16(int metric, const float *X, const float *norm2, c
     if (persist && !rowmap && !mask && spx >= 1 && a.n_q_tiles <= spx) {
         const bool img = Xh != nullptr; // (sync_f16_image: in step with the corpus, K-blocked, xh_cap rows per plane)
         static const int n16 = lb_tunable("LB_F16_NARROW", 1);
-        if (img && nq <= 64 && n16) { // the 64-query tile: the pass is the image's HBM stream
-            const size_t nshmem = (size_t)6 * (H_BM * H_BK * 2 + 64 * H_BK * 2) + 2 * 512 * sizeof(float) + 8 * 1024;
+        if (img && nq <= 128 && n16) { // the 64- / 128-query tile: the pass is the image's HBM stream
+            const bool n64 = nq <= 64;
+            const size_t nshmem = (n64 ? (size_t)6 * (H_BM * H_BK * 2 + 64 * H_BK * 2) : (size_t)5 * (H_BM * H_BK * 2 + 128 * H_BK * 2)) +
+                                  2 * 512 * sizeof(float) + 8 * 1024;
             dim3 ngrid((unsigned)(spx * 8));
-#define LB_NARROW16(M)                                                                                           \
+#define LB_NARROW16(M, N)                                                                                        \
     do {                                                                                                         \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_filter_narrow16p_kernel<M>),              \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_filter_narrow16p_kernel<M, N>),           \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)nshmem);                      \
-        hipLaunchKernelGGL((gemm_filter_narrow16p_kernel<M>), ngrid, dim3(H_THREADS), nshmem, s, a, spx);        \
+        hipLaunchKernelGGL((gemm_filter_narrow16p_kernel<M, N>), ngrid, dim3(H_THREADS), nshmem, s, a, spx);     \
     } while (0)
-            if (metric == METRIC_L2) LB_NARROW16(METRIC_L2);
-            else if (metric == METRIC_COS) LB_NARROW16(METRIC_COS);
-            else LB_NARROW16(METRIC_DOT);
+#define LB_NARROW16_M(M)              \
+    do {                              \
+        if (n64) LB_NARROW16(M, 64);  \
+        else LB_NARROW16(M, 128);     \
+    } while (0)
+            if (metric == METRIC_L2) LB_NARROW16_M(METRIC_L2);
+            else if (metric == METRIC_COS) LB_NARROW16_M(METRIC_COS);
+            else LB_NARROW16_M(METRIC_DOT);
+#undef LB_NARROW16_M
 #undef LB_NARROW16
             return;
         }
