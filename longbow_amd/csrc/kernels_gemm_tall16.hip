@@ -579,12 +579,19 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
         const float scale = __builtin_bit_cast(float, (254u << 23) - __builtin_bit_cast(uint32_t, qs[tn]));
         tkc[tn] = METRIC == METRIC_L2 ? tk : tk * scale;
     }
-    constexpr uint32_t WCAP = 100, WFLUSH = 56;
-    unsigned char *seg = reinterpret_cast<unsigned char *>(s_auxp + 2 * 512) + wave * 1024;
+    // admission segments: what is left of the LDS beside the ring (3.2 KB per wave with the fp16 copy, 1.2 KB without)
+    constexpr uint32_t WCAP = AIMG ? 272 : 104, WFLUSH = AIMG ? 176 : 60, SEG_BYTES = WCAP * 12;
+    uint32_t *s_flag = reinterpret_cast<uint32_t *>(s_auxp + 2 * 512);              // [3] "somebody wants a flush", by tile % 3
+    uint32_t *s_qn = s_flag + 4;                                                    // [H_BN] entries per query in the flush ...
+    uint32_t *s_qb = s_qn + H_BN;                                                   // [H_BN] ... and where they start in its list
+    unsigned char *seg = reinterpret_cast<unsigned char *>(s_qb + H_BN) + wave * SEG_BYTES;
     float *s_key = reinterpret_cast<float *>(seg);                // [WCAP]
     uint32_t *s_rid = reinterpret_cast<uint32_t *>(s_key + WCAP); // [WCAP]
     uint16_t *s_q = reinterpret_cast<uint16_t *>(s_rid + WCAP);   // [WCAP] query of the entry (in the tile)
+    uint16_t *s_rk = s_q + WCAP;                                  // [WCAP] its rank among the flush's entries of that query
     uint32_t wcnt = 0;                                            // entries in the segment (wave-uniform)
+    if (tid < H_BN) s_qn[tid] = 0;
+    if (tid < 3) s_flag[tid] = 0; // (the first K-step's barrier is between this and the first use)
 
     // Fragments of a K-step's two MFMA k-blocks: block 0's are read HALF A STEP EARLY -- the wait + barrier that make stage
     // kt + 1 visible sit in the middle of step kt, and its first fragments are read while step kt's second k-block runs on
@@ -756,16 +763,33 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
                 }
             }
         }
-        bool flush = !a.boot && (wcnt > WFLUSH || i + 1 == n_my);
+        // Flush.  The returned positions of the flush's atomics retire behind every request this wave has in flight (vmcnt is
+        // in order): a flush drains the wave's part of the ring, and through the barriers everybody waits for it.  So the
+        // waves flush TOGETHER, and rarely: a wave that is past WFLUSH says so in the tile's flag; a tile later (the K-steps'
+        // barriers have made the flag visible to all) every wave flushes.  Three flags in rotation: this tile's is written,
+            // the one before is read, the one after (read a tile ago by everybody) is cleared.  A flush then costs ONE global atomic
+        // per query with entries (ranks from LDS atomics): the per-entry atomics of an earlier version were ~2,300 on each query's
+        // counter per search, and their serialisation showed (0.1 ms at 128 queries).
+        if (wcnt > WFLUSH && lane == 0) s_flag[i % 3] = 1;
+        if (tid == 0) s_flag[(i + 1) % 3] = 0;
+        bool flush = !a.boot && (i + 1 == n_my || (i > 0 && s_flag[(i + 2) % 3] != 0));
 #ifdef LB_DIAG
         if (a.abl == 7) flush = false;
 #endif
-        if (flush) { // the wave's own entries, one per lane: pack, ONE returning global atomic, store -- all in flight together
+        if (flush) { // (all waves are here together) ONE returning global atomic per query with entries, then the stores
             const uint32_t total = wcnt < WCAP ? wcnt : WCAP;
+            for (uint32_t z = lane; z < total; z += 64) s_rk[z] = (uint16_t)atomicAdd(&s_qn[s_q[z]], 1u);
+            __syncthreads();
+            if (tid < H_BN) {
+                const uint32_t n = s_qn[tid];
+                s_qb[tid] = n ? atomicAdd(&a.cs.cnt[q0 + tid], n) : 0u; // (n != 0 implies a real query)
+                s_qn[tid] = 0;
+            }
+            __syncthreads();
             for (uint32_t z = lane; z < total; z += 64) {
-                const int qg = q0 + (int)s_q[z];
-                const uint32_t pos = atomicAdd(&a.cs.cnt[qg], 1u);
-                if (pos < a.cs.cap) a.cs.lists[(size_t)qg * a.cs.cap + pos] = pack_entry(s_key[z], s_rid[z]);
+                const int ql = (int)s_q[z];
+                const uint32_t pos = s_qb[ql] + (uint32_t)s_rk[z];
+                if (pos < a.cs.cap) a.cs.lists[(size_t)(q0 + ql) * a.cs.cap + pos] = pack_entry(s_key[z], s_rid[z]);
             }
             wcnt = 0;
         }
@@ -873,13 +897,21 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
         m2qs[tn] = -2.0f * qs[tn];
         const float scale = __builtin_bit_cast(float, (254u << 23) - __builtin_bit_cast(uint32_t, qs[tn]));
         tkc[tn] = METRIC == METRIC_L2 ? tk : tk * scale;
+#ifdef LB_DIAG
+        if (a.abl == 8) tkc[tn] = -__builtin_huge_valf(); // timing only: nothing is admitted
+#endif
     }
-    constexpr uint32_t WCAP = 100, WFLUSH = 56;
-    unsigned char *seg = reinterpret_cast<unsigned char *>(s_auxp + 2 * 512) + wave * 1024;
+    constexpr uint32_t WCAP = 368, WFLUSH = 248, SEG_BYTES = WCAP * 12; // (4.3 KB per wave beside the 120 KB ring)
+    uint32_t *s_flag = reinterpret_cast<uint32_t *>(s_auxp + 2 * 512); // [3] "somebody wants a flush", by tile % 3 (see the 256-query form)
+    uint32_t *s_qn = s_flag + 4, *s_qb = s_qn + 128;
+    unsigned char *seg = reinterpret_cast<unsigned char *>(s_qb + 128) + wave * SEG_BYTES;
     float *s_key = reinterpret_cast<float *>(seg);
     uint32_t *s_rid = reinterpret_cast<uint32_t *>(s_key + WCAP);
     uint16_t *s_q = reinterpret_cast<uint16_t *>(s_rid + WCAP);
+    uint16_t *s_rk = s_q + WCAP;
     uint32_t wcnt = 0;
+    if (tid < 128) s_qn[tid] = 0;
+    if (tid < 3) s_flag[tid] = 0;
 
     auto load_frag = [&](int slot_, int kb, f16x8 &af, f16x8(&bf)[TN]) {
         const unsigned char *As = ring + slot_ * STAGE;
@@ -985,11 +1017,21 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
                 }
             }
         }
-        if (!a.boot && (wcnt > WFLUSH || i + 1 == n_my)) {
+        if (wcnt > WFLUSH && lane == 0) s_flag[i % 3] = 1;
+        if (tid == 0) s_flag[(i + 1) % 3] = 0;
+        if (!a.boot && (i + 1 == n_my || (i > 0 && s_flag[(i + 2) % 3] != 0))) { // (all waves together: see the 256-query form)
             const uint32_t total = wcnt < WCAP ? wcnt : WCAP;
+            for (uint32_t z = lane; z < total; z += 64) s_rk[z] = (uint16_t)atomicAdd(&s_qn[s_q[z]], 1u);
+            __syncthreads();
+            if (tid < BN) {
+                const uint32_t n = s_qn[tid];
+                s_qb[tid] = n ? atomicAdd(&a.cs.cnt[tid], n) : 0u;
+                s_qn[tid] = 0;
+            }
+            __syncthreads();
             for (uint32_t z = lane; z < total; z += 64) {
                 const int qg = (int)s_q[z];
-                const uint32_t pos = atomicAdd(&a.cs.cnt[qg], 1u);
+                const uint32_t pos = s_qb[qg] + (uint32_t)s_rk[z];
                 if (pos < a.cs.cap) a.cs.lists[(size_t)qg * a.cs.cap + pos] = pack_entry(s_key[z], s_rid[z]);
             }
             wcnt = 0;
@@ -1098,7 +1140,7 @@ void launch_gemm_filter_tall16(int metric, const float *X, const float *norm2, c
         if (img && nq <= 128 && n16) { // the 64- / 128-query tile: the pass is the image's HBM stream
             const bool n64 = nq <= 64;
             const size_t nshmem = (n64 ? (size_t)6 * (H_BM * H_BK * 2 + 64 * H_BK * 2) : (size_t)5 * (H_BM * H_BK * 2 + 128 * H_BK * 2)) +
-                                  2 * 512 * sizeof(float) + 8 * 1024;
+                                  2 * 512 * sizeof(float) + 16 + 2 * 128 * 4 + 8 * 368 * 12; // ring, side inputs, flush flags + counters, admission segments
             dim3 ngrid((unsigned)(spx * 8));
 #define LB_NARROW16(M, N)                                                                                        \
     do {                                                                                                         \
@@ -1119,7 +1161,7 @@ void launch_gemm_filter_tall16(int metric, const float *X, const float *norm2, c
             return;
         }
         const size_t pshmem = (img ? (size_t)4 * (H_BM * H_BK * 2 + H_B_BYTES) : (size_t)H_NST * H_STAGE_BYTES) + 2 * 512 * sizeof(float) +
-                              8 * 1024; // ring, side inputs, admission segments
+                              16 + 2 * H_BN * 4 + 8 * (img ? 272 : 104) * 12; // ring, side inputs, flush flags + counters, admission segments
         const bool pnt = a.n_q_tiles <= 1;
         dim3 pgrid((unsigned)(spx * 8));
 #define LB_TALL16P(M, N, I)                                                                                       \
