@@ -619,21 +619,22 @@ struct Route {
 // Fitted to tools/route_grid.py on MI355X (D in {128, 384, 768, 1536} x n in {100k, 1M, 4M}), see DESIGN.md 3.2.
 struct RouteCost {
     double alpha, beta, hbm, first;
-    double fixed = 0; // ms per search this route spends beyond the others (fp16: the query image, twice the candidates to re-rank)
+    double fixed = 0; // ms per search whatever the corpus: launches, thresholds, select, re-rank (fp16: + the query image, twice the
+                      // candidates; the one-tile form over the fp16 copy: its re-rank is counted per query)
 };
 // (narrow tiles: one launch, the corpus tile is read from HBM once and re-used from L2 by the other query tiles)
-constexpr RouteCost kCostNarrow32{0.000323, 0.0247, 0.000640, 0.000300};   // per 32-query tile: 1.09 ms at 4M x 768, 0.27 at 4M x 128
-constexpr RouteCost kCostNarrow64{0.000527, 0.0225, 0.000640, 0.000200};   // per 64-query tile: 1.71 ms at 4M x 768, 0.36 at 4M x 128
-constexpr RouteCost kCostTallInreg{0.000687, 0.0445, 0.000640, 0.000250};  // per 128-query tile: 2.29 ms at 4M x 768, 0.53 at 4M x 128
-constexpr RouteCost kCostTallImage{0.000630, 0.0445, 0.000640, 0.000220};
-constexpr RouteCost kCostTall2Inreg{0.001260, 0.1300, 0.000640, 0.000250}; // per 256-query tile: 3.9 ms at 4M x 768, 1.16 at 4M x 128
-constexpr RouteCost kCostTall2Image{0.001150, 0.1300, 0.000640, 0.000220};
-constexpr RouteCost kCostWideF32{0.001940, 0.0600, 0.000640, 0.0};
-constexpr RouteCost kCostTall16{0.000540, 0.0800, 0.000660, 0.000140, 0.10}; // per 256-query tile, one fp16 product, persistent form: 0.49 ms per
+constexpr RouteCost kCostNarrow32{0.000323, 0.0247, 0.000640, 0.000300, 0.09};   // per 32-query tile: 1.09 ms at 4M x 768, 0.27 at 4M x 128
+constexpr RouteCost kCostNarrow64{0.000527, 0.0225, 0.000640, 0.000200, 0.09};   // per 64-query tile: 1.71 ms at 4M x 768, 0.36 at 4M x 128
+constexpr RouteCost kCostTallInreg{0.000687, 0.0445, 0.000640, 0.000250, 0.09};  // per 128-query tile: 2.29 ms at 4M x 768, 0.53 at 4M x 128
+constexpr RouteCost kCostTallImage{0.000630, 0.0445, 0.000640, 0.000220, 0.09};
+constexpr RouteCost kCostTall2Inreg{0.001260, 0.1300, 0.000640, 0.000250, 0.09}; // per 256-query tile: 3.9 ms at 4M x 768, 1.16 at 4M x 128
+constexpr RouteCost kCostTall2Image{0.001150, 0.1300, 0.000640, 0.000220, 0.09};
+constexpr RouteCost kCostWideF32{0.001940, 0.0600, 0.000640, 0.0, 0.09};
+constexpr RouteCost kCostTall16{0.000540, 0.0800, 0.000660, 0.000140, 0.19}; // per 256-query tile, one fp16 product, persistent form: 0.49 ms per
                                                                              // tile at 1M x 768, a single tile streams the corpus at 6 TB/s
-constexpr RouteCost kCostTall16Img{0.000460, 0.0500, 0.000330, 0.000040, 0.10}; // the same from the corpus's fp16 image: 0.40 ms per tile at
+constexpr RouteCost kCostTall16Img{0.000460, 0.0500, 0.000330, 0.000040, 0.19}; // the same from the corpus's fp16 image: 0.40 ms per tile at
                                                                                 // 1M x 768, never bound by the stream (1.5 GB)
-constexpr RouteCost kCostNarrow16{0.000100, 0.0300, 0.000340, 0.000030, 0.10};  // up to 64 queries over the fp16 copy: its HBM stream (6 TB/s)
+constexpr RouteCost kCostNarrow16{0.000100, 0.0300, 0.000340, 0.000030, 0.08};  // up to 64 queries over the fp16 copy: its HBM stream (6 TB/s)
 inline double route_ms(const RouteCost &c, int64_t n, int D, int tiles)
 {
     const double nd = 1e-6 * (double)n;
@@ -676,11 +677,11 @@ static Route choose_route(int nq, int64_t n, int D, int cmode, bool narrow_ok, b
     static const int f16_on = lb_tunable("LB_F16", 1);
     if (narrow_ok && f16_ok && f16_on && !image && (nq > 32 || have_f16_image) &&
         (cmode == LB_CAND_F16 || (cmode == LB_CAND_AUTO && n >= 262144))) { // (below: launch overheads decide, and the narrow tiles win)
-        if (have_f16_image && nq <= 128) { // (the 64- / 128-query tile of the persistent kernel)
+        if (have_f16_image && nq <= 128) { // (one query tile: the 64- / 128-query form of the persistent kernel)
             // + what the route pays per query beside the stream: twice (beyond 1024 dimensions four times) the candidates to
-            // select and re-rank, and their admissions
-            const double q1 = D > 1024 ? 0.0099 : 0.0030, q2 = 0.0012;
-            add(ROUTE_NARROW16, 3, route_ms(kCostNarrow16, n, D, 1) + q1 * std::min(nq, 32) + q2 * std::max(nq - 32, 0));
+            // select and re-rank
+            const double q1 = D > 1024 ? 0.0016 : 0.0007;
+            add(ROUTE_NARROW16, 3, route_ms(kCostNarrow16, n, D, 1) + q1 * nq);
         }
         else add(ROUTE_TALL16, 3, route_ms(have_f16_image ? kCostTall16Img : kCostTall16, n, D, tiles256));
     }
@@ -699,9 +700,9 @@ static Route choose_route(int nq, int64_t n, int D, int cmode, bool narrow_ok, b
         for (int i = 0; i < nc; i++)
             if (cand[i].kind == ROUTE_TALL16 || cand[i].kind == ROUTE_NARROW16) return cand[i];
     if (nq <= 32 && nc > 0 && cand[0].kind == ROUTE_NARROW32) {
-        // one pass of the 32-query tile (sample and thresholds inside the launch): 0.55 ms per 1M x 768 whatever the model
-        // above says about tile counts -- nothing is cheaper but the stream of the fp16 copy
-        cand[0].cost_ms = 1e-6 * (double)n * (double)D * 0.00072;
+        // one pass of the 32-query tile (sample and thresholds inside the launch): 0.09 ms + 0.47 ms per 1M x 768 whatever the
+        // model above says about tile counts -- nothing is cheaper but the stream of the fp16 copy
+        cand[0].cost_ms = 0.09 + 1e-6 * (double)n * (0.014 + 0.000612 * (double)D);
         for (int i = 1; i < nc; i++)
             if (cand[i].kind == ROUTE_NARROW16 && cand[i].cost_ms < cand[0].cost_ms) return cand[i];
         return cand[0];
@@ -738,7 +739,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     if (!h->nonfinite && nq < narrow_min && narrow_ok && have_xh && h->f16_ok && allow_f16 &&
         (cmode == LB_CAND_F16 || (cmode == LB_CAND_AUTO && h->f16_skip.load(std::memory_order_relaxed) == 0))) {
         const double scan_ms = 1e-6 * (double)n * ((double)h->dim * 0.00066 + 0.04);
-        const double copy_ms = route_ms(kCostNarrow16, n, h->dim, 1) + (h->dim > 1024 ? 0.0099 : 0.0030) * nq;
+        const double copy_ms = route_ms(kCostNarrow16, n, h->dim, 1) + (h->dim > 1024 ? 0.0016 : 0.0007) * nq;
         small_on_copy = cmode == LB_CAND_F16 || copy_ms < scan_ms;
     }
     if (h->nonfinite || (nq < (narrow_ok ? narrow_min : kGemmMinQ) && !small_on_copy)) {

@@ -797,18 +797,20 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
     h_wait_vmcnt<0>(); // the re-read stages behind the last tile: nothing may land in LDS after the workgroup has gone
 }
 
-// ---- up to 128 queries over the corpus's fp16 image: the pass is the image's HBM stream --------------------------------------
-// Same persistent pipeline, tile 256 rows x BN queries (64 or 128): a wave owns 32 rows x BN queries (BN / 32 MFMA tiles),
-// stages exactly the corpus rows it consumes (2 requests per stage) and an eighth of the query tile (one request: lanes
-// 0 .. 31 at BN = 64, all lanes at 128); a stage is 16 KB + 4 / 8 KB, the ring SIX / FIVE stages deep (64-80 KB of corpus in
-// flight per CU), loads non-temporal (every line is read once).  1M x 768: the image is 1.5 GB, the pass 0.24-0.3 ms where
-// the f32 rows take 0.49.
+// ---- up to 256 queries (one query tile) over the corpus's fp16 image: the pass is the image's HBM stream ---------------------
+// Same persistent pipeline, tile 256 rows x BN queries (64, 128 or 256): a wave owns 32 rows x BN queries (BN / 32 MFMA
+// tiles), stages exactly the corpus rows it consumes (2 requests per stage) and an eighth of the query tile (half a request
+// at BN = 64 -- lanes 0 .. 31 --, one at 128, two at 256); a stage is 16 KB + 4 / 8 / 16 KB, the ring SIX / FIVE / FOUR stages
+// deep (48-80 KB of corpus in flight per CU), loads non-temporal (every line is read once).  1M x 768: the image is 1.5 GB,
+// the pass 0.24-0.3 ms where the f32 rows take 0.49.
 template <int METRIC, int BN>
 __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tall16Args a, int spx)
 {
     constexpr int TN = BN / 32;
-    constexpr int NST = BN == 64 ? 6 : 5, A_BYTES = H_BM * H_BK * 2, B_BYTES = BN * H_BK * 2, STAGE = A_BYTES + B_BYTES;
-    constexpr int NPS = 3, DIST = NST - 1, H1 = 2;
+    constexpr int NST = BN == 64 ? 6 : (BN == 128 ? 5 : 4), A_BYTES = H_BM * H_BK * 2, B_BYTES = BN * H_BK * 2, STAGE = A_BYTES + B_BYTES;
+    constexpr int NPB = BN == 256 ? 2 : 1; // query requests per wave and stage
+    constexpr int NPS = 2 + NPB, DIST = NST - 1, H1 = 2;
+    constexpr bool PIPE = BN != 256; // (at 256 queries there are no registers for a third set of fragments: barrier on top)
     const int b = blockIdx.x;
     const int xcd = b & 7, slot = b >> 3;
     const int jtop = a.n_row_tiles - 1 - xcd;
@@ -830,7 +832,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
     const float *auxg = METRIC == METRIC_L2 ? a.norm2 + a.row_begin : (METRIC == METRIC_COS ? a.rnorm + a.row_begin : nullptr);
     auto rt_of = [&](int i) { return (slot + spx * i) * 8 + xcd; };
 
-    const unsigned char *srcA[2], *srcB;
+    const unsigned char *srcA[2], *srcB[NPB];
     const unsigned char *Xhb = reinterpret_cast<const unsigned char *>(a.Xh) + a.row_begin * (int64_t)(H_BK * 2);
     const int64_t plane_bytes = a.xh_cap * (int64_t)(H_BK * 2);
     auto set_srcA = [&](int rt) {
@@ -843,12 +845,13 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
             srcA[i] = Xhb + pos * (H_BK * 2) + 16 * c;
         }
     };
-    {
-        // BN = 64: 8 query rows per wave, lanes 32 .. 63 do not take part in the request; BN = 128: 16 rows, all lanes
-        const int row = BN == 64 ? wave * 8 + ((lane & 31) >> 2) : wave * 16 + (lane >> 2);
+#pragma unroll
+    for (int j = 0; j < NPB; j++) {
+        // BN = 64: 8 query rows per wave, lanes 32 .. 63 do not take part in the request; 128: 16 rows; 256: 2 x 16 rows
+        const int row = BN == 64 ? wave * 8 + ((lane & 31) >> 2) : wave * (BN / 8) + j * 16 + (lane >> 2);
         const int c = (lane & 3) ^ ((row >> 2) & 3);
         const int qr = row > last_q ? last_q : row;
-        srcB = reinterpret_cast<const unsigned char *>(a.Qh + (int64_t)qr * H_BK) + 16 * c;
+        srcB[j] = reinterpret_cast<const unsigned char *>(a.Qh + (int64_t)qr * H_BK) + 16 * c;
     }
     const int64_t kb_stride = (int64_t)a.nq * (H_BK * 2);
     const int nk = a.D / H_BK;
@@ -859,7 +862,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
         const uint32_t A = ring_base + (uint32_t)islot * STAGE + (uint32_t)(wave * 32 * 64);
         const uint32_t B = ring_base + (uint32_t)islot * STAGE + A_BYTES + (uint32_t)(wave * (BN * 8));
         if (p < 2) h_dma16<true>(srcA[p] + ik * plane_bytes, A + 1024u * p);
-        else if (BN == 128 || lane < 32) h_dma16<false>(srcB + ik * kb_stride, B);
+        else if (BN != 64 || lane < 32) h_dma16<false>(srcB[p - 2] + ik * kb_stride, B + 1024u * (p - 2));
     };
     auto advance = [&]() {
         islot = islot == NST - 1 ? 0 : islot + 1;
@@ -901,16 +904,16 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
         if (a.abl == 8) tkc[tn] = -__builtin_huge_valf(); // timing only: nothing is admitted
 #endif
     }
-    constexpr uint32_t WCAP = 368, WFLUSH = 248, SEG_BYTES = WCAP * 12; // (4.3 KB per wave beside the 120 KB ring)
+    constexpr uint32_t WCAP = BN == 256 ? 272 : 360, WFLUSH = BN == 256 ? 176 : 240, SEG_BYTES = WCAP * 12; // (what the ring leaves)
     uint32_t *s_flag = reinterpret_cast<uint32_t *>(s_auxp + 2 * 512); // [3] "somebody wants a flush", by tile % 3 (see the 256-query form)
-    uint32_t *s_qn = s_flag + 4, *s_qb = s_qn + 128;
-    unsigned char *seg = reinterpret_cast<unsigned char *>(s_qb + 128) + wave * SEG_BYTES;
+    uint32_t *s_qn = s_flag + 4, *s_qb = s_qn + 256;
+    unsigned char *seg = reinterpret_cast<unsigned char *>(s_qb + 256) + wave * SEG_BYTES;
     float *s_key = reinterpret_cast<float *>(seg);
     uint32_t *s_rid = reinterpret_cast<uint32_t *>(s_key + WCAP);
     uint16_t *s_q = reinterpret_cast<uint16_t *>(s_rid + WCAP);
     uint16_t *s_rk = s_q + WCAP;
     uint32_t wcnt = 0;
-    if (tid < 128) s_qn[tid] = 0;
+    if (tid < 256) s_qn[tid] = 0;
     if (tid < 3) s_flag[tid] = 0;
 
     auto load_frag = [&](int slot_, int kb, f16x8 &af, f16x8(&bf)[TN]) {
@@ -924,10 +927,12 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
 
     int cslot = 0;
     f16x8 a0, b0[TN];
-    h_wait_vmcnt<NPS *(DIST - 1)>();
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    load_frag(0, 0, a0, b0);
+    if (PIPE) {
+        h_wait_vmcnt<NPS *(DIST - 1)>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        load_frag(0, 0, a0, b0);
+    }
     for (int i = 0; i < n_my; i++) {
         const int rt = rt_of(i);
         f32x16 acc[TN];
@@ -937,8 +942,14 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
             for (int r = 0; r < 16; r++) acc[y][r] = 0.f;
 
         for (int kt = 0; kt < nk; kt++) {
+            if (!PIPE) {
+                h_wait_vmcnt<NPS *(DIST - 1)>();
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                load_frag(cslot, 0, a0, b0);
+            }
             f16x8 a1, b1[TN];
-            load_frag(cslot, 1, a1, b1);
+            if (PIPE) load_frag(cslot, 1, a1, b1);
             if (cursor_new_tile) { set_srcA(rt_of(it)); cursor_new_tile = false; }
             if (kt == (nk > 1 ? 1 : 0) && i + 1 < n_my) aux_request(i + 1);
 #pragma unroll
@@ -946,17 +957,19 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
                 acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0[tn], acc[tn], 0, 0, 0);
                 if (tn < 2) piece(tn);
             }
-            // middle of the step (see the 256-query form): reads of stage kt complete, stage kt + 1 landed, barrier
-            __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0)
-            h_wait_vmcnt<NPS *(DIST - 2) + H1>();
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
             const int nslot = cslot == NST - 1 ? 0 : cslot + 1;
-            load_frag(nslot, 0, a0, b0);
+            if (!PIPE) load_frag(cslot, 1, a1, b1);
+            if (PIPE) { // middle of the step (see the 256-query form): reads of stage kt complete, stage kt + 1 landed, barrier
+                __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0)
+                h_wait_vmcnt<NPS *(DIST - 2) + H1>();
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                load_frag(nslot, 0, a0, b0);
+            }
 #pragma unroll
             for (int tn = 0; tn < TN; tn++) {
                 acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1[tn], acc[tn], 0, 0, 0);
-                if (tn == 0) piece(2);
+                if (tn < NPB) piece(2 + tn);
             }
             advance();
             cslot = nslot;
@@ -1137,10 +1150,14 @@ void launch_gemm_filter_tall16(int metric, const float *X, const float *norm2, c
     if (persist && !rowmap && !mask && spx >= 1 && a.n_q_tiles <= spx) {
         const bool img = Xh != nullptr; // (sync_f16_image: in step with the corpus, K-blocked, xh_cap rows per plane)
         static const int n16 = lb_tunable("LB_F16_NARROW", 1);
-        if (img && nq <= 128 && n16) { // the 64- / 128-query tile: the pass is the image's HBM stream
-            const bool n64 = nq <= 64;
-            const size_t nshmem = (n64 ? (size_t)6 * (H_BM * H_BK * 2 + 64 * H_BK * 2) : (size_t)5 * (H_BM * H_BK * 2 + 128 * H_BK * 2)) +
-                                  2 * 512 * sizeof(float) + 16 + 2 * 128 * 4 + 8 * 368 * 12; // ring, side inputs, flush flags + counters, admission segments
+        // (the 256-query instance of this kernel measured level with the 4 x 2-wave tile below -- 0.43 ms per pass, bound by MFMA +
+        // LDS work either way -- and is not built)
+        if (img && nq <= 128 && n16) { // one query tile of 64 / 128: the pass is the image's HBM stream
+            const int bn = nq <= 64 ? 64 : 128;
+            const size_t ring_b = bn == 64 ? (size_t)6 * (H_BM * H_BK * 2 + 64 * H_BK * 2)
+                                           : (bn == 128 ? (size_t)5 * (H_BM * H_BK * 2 + 128 * H_BK * 2) : (size_t)4 * (H_BM * H_BK * 2 + 256 * H_BK * 2));
+            // ring, side inputs, flush flags + counters, admission segments
+            const size_t nshmem = ring_b + 2 * 512 * sizeof(float) + 16 + 2 * 256 * 4 + 8 * (bn == 256 ? 272 : 360) * 12;
             dim3 ngrid((unsigned)(spx * 8));
 #define LB_NARROW16(M, N)                                                                                        \
     do {                                                                                                         \
@@ -1148,10 +1165,10 @@ void launch_gemm_filter_tall16(int metric, const float *X, const float *norm2, c
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)nshmem);                      \
         hipLaunchKernelGGL((gemm_filter_narrow16p_kernel<M, N>), ngrid, dim3(H_THREADS), nshmem, s, a, spx);     \
     } while (0)
-#define LB_NARROW16_M(M)              \
-    do {                              \
-        if (n64) LB_NARROW16(M, 64);  \
-        else LB_NARROW16(M, 128);     \
+#define LB_NARROW16_M(M)                  \
+    do {                                  \
+        if (bn == 64) LB_NARROW16(M, 64); \
+        else LB_NARROW16(M, 128);         \
     } while (0)
             if (metric == METRIC_L2) LB_NARROW16_M(METRIC_L2);
             else if (metric == METRIC_COS) LB_NARROW16_M(METRIC_COS);

@@ -228,7 +228,7 @@ class Index:
 
     ROUTE_NAMES = {0: "exact scan", 1: "narrow 256x32", 2: "narrow 128x64", 3: "tall 256x128 split-bf16", 4: "wide 128x128 f32 MFMA",
                    5: "tall 256x256 split-bf16", 6: "tall 256x256 fp16 single product",
-                   7: "narrow 256x64/128 fp16 single product over the fp16 copy"}
+                   7: "one query tile (64/128) fp16 single product over the fp16 copy"}
 
     @property
     def last_route(self):

@@ -608,7 +608,7 @@ def test_fp16_persistent_tile_shapes(oracle, metric):
         idx = new_index(d, metric)
         idx.Add(None, X)
         oi, od = oracle.search_batch(metric, Q[:24], X, k, nthreads=8)
-        for nq in (1, 3, 5, 17, 40, 64, 65, 100, 128, 129, 257, 600, 1100, 1500) + ((8300,) if n == 5000 else ()):  # <= 64: the 64-query tile (with the copy)
+        for nq in (1, 3, 5, 17, 40, 64, 65, 100, 128, 129, 200, 256, 257, 600, 1100, 1500) + ((8300,) if n == 5000 else ()):  # <= 64: the 64-query tile (with the copy)
             idx.set_candidate_mode(0)
             want = idx.SearchBatch(Q[:nq], k)
             idx.set_candidate_mode(4)
