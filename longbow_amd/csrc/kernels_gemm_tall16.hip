@@ -1147,7 +1147,15 @@ void launch_gemm_filter_tall16(int metric, const float *X, const float *norm2, c
         return n;
     }();
     const int spx = cus / 8;
-    if (persist && !rowmap && !mask && spx >= 1 && a.n_q_tiles <= spx) {
+    // (the persistent kernels take nearly all of a CU's 160 KB of LDS: on a device that offers a workgroup less, the
+    // one-workgroup-per-tile kernel below serves everything)
+    static const int lds_max = [] {
+        int dev = 0, n = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMaxSharedMemoryPerBlock, dev);
+        return n;
+    }();
+    if (persist && !rowmap && !mask && spx >= 1 && a.n_q_tiles <= spx && lds_max >= 163840) {
         const bool img = Xh != nullptr; // (sync_f16_image: in step with the corpus, K-blocked, xh_cap rows per plane)
         static const int n16 = lb_tunable("LB_F16_NARROW", 1);
         // (the 256-query instance of this kernel measured level with the 4 x 2-wave tile below -- 0.43 ms per pass, bound by MFMA +
