@@ -33,7 +33,7 @@ def test_full_size_batch(oracle, corpus, metric):
     idx.add_device(N, X.data_ptr())
     dist = torch.empty((B, K), device="cuda")
     lab = torch.empty((B, K), dtype=torch.int64, device="cuda")
-    # the library default (LB_CAND_AUTO: split-bf16 candidates on the 256 x 256 tile) ...
+    # the library default (LB_CAND_AUTO: one fp16 product per element over the index's fp16 copy, 256 x 256 tiles) ...
     idx.search_device(B, Q.data_ptr(), K, dist.data_ptr(), lab.data_ptr())
     fallbacks = idx.last_fallbacks
     dist_h, lab_h = dist.cpu().numpy(), lab.cpu().numpy()
@@ -47,13 +47,25 @@ def test_full_size_batch(oracle, corpus, metric):
     assert np.all(np.diff(dist_h, axis=1) >= 0)
     assert lab_h.min() >= 0 and lab_h.max() < N
     assert all(len(np.unique(r)) == K for r in lab_h[::64])
-    # the batched (MFMA candidate + exact re-rank) path == the EXACT SCAN path, bit for bit, for ALL 1024 queries
-    # (4 queries per call: below the batched path's minimum, 0.55 ms per call)
+    # 4 queries per call, ALL 1024 queries: with the fp16 copy the one-tile candidate pass over it (0.34 ms per call) ...
     d4 = torch.empty((4, K), device="cuda")
     l4 = torch.empty((4, K), dtype=torch.int64, device="cuda")
+    assert idx.f16_image_bytes == N * D * 2
     for s in range(0, B, 4):
         idx.search_device(4, Q[s:s + 4].contiguous().data_ptr(), K, d4.data_ptr(), l4.data_ptr())
         assert np.array_equal(l4.cpu().numpy(), lab_h[s:s + 4]) and np.array_equal(d4.cpu().numpy(), dist_h[s:s + 4]), s
+    assert idx.last_route[0] == 7, idx.last_route
+    # ... and without it the EXACT SCAN path (below the batched path's minimum, 0.55 ms per call): bit for bit the batched
+    # results, for every fourth group of 4 and then, without the copy, the whole batch again on the f32-staging form
+    idx.set_f16_image(0)
+    for s in range(0, B, 16):
+        idx.search_device(4, Q[s:s + 4].contiguous().data_ptr(), K, d4.data_ptr(), l4.data_ptr())
+        assert np.array_equal(l4.cpu().numpy(), lab_h[s:s + 4]) and np.array_equal(d4.cpu().numpy(), dist_h[s:s + 4]), s
+    assert idx.last_route[0] == 0, idx.last_route
+    idx.search_device(B, Q.data_ptr(), K, dist.data_ptr(), lab.data_ptr())
+    assert np.array_equal(lab.cpu().numpy(), lab_h) and np.array_equal(dist.cpu().numpy(), dist_h)
+    fallbacks = max(fallbacks, idx.last_fallbacks)
+    idx.set_f16_image(1)
     # oracle on 64 queries spread over the batch (scalar CPU restatement: ~1 s per query per core, 16 threads)
     Xh = X.cpu().numpy()
     qs = np.arange(0, B, 16)
