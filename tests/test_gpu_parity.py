@@ -649,3 +649,29 @@ def test_fp16_image_follows_the_corpus(oracle):
     idx.set_candidate_mode(3)                  # AUTO below 262,144 rows: not on offer either
     assert idx.f16_image_bytes == 0
     idx.Close()
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_fp16_route_ties_and_duplicates(oracle, metric):
+    """thousands of exact duplicates among the nearest rows: their candidate keys tie AT the sampled threshold (the fp16
+    kernels admit key <= threshold: every tie), the lists overflow or the proof fails, and the fallbacks take over -- the answer
+    is still the oracle's (equal distances: lowest position first), from the fp16 copy and without it"""
+    gpu_or_skip()
+    rng = np.random.default_rng(4100 + metric)
+    n, d, k = 70000, 64, 20
+    X = (rng.random((n, d), dtype=F) - F(0.5))
+    v = (rng.random(d, dtype=F) - F(0.5)) * F(1.5)
+    X[1000:9000] = v                       # 8000 copies of one vector ...
+    X[30000:30100] = F(0)                  # ... and some zero rows
+    Q = np.tile(v, (200, 1)).astype(F) + (rng.random((200, d), dtype=F) - F(0.5)) * F(0.01)
+    idx = new_index(d, metric)
+    idx.Add(None, X)
+    oi, od = oracle.search_batch(metric, Q[:40], X, k, nthreads=8)
+    idx.set_candidate_mode(4)
+    for image in (1, 0):
+        idx.set_f16_image(image)
+        for nq in (3, 40, 200):
+            lab, dist = idx.SearchBatch(Q[:nq], k)
+            m = min(nq, 40)
+            assert_same(lab[:m], dist[:m], oi[:m], od[:m], f"duplicates metric={metric} image={image} nq={nq}")
+    idx.Close()
