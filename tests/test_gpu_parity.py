@@ -675,3 +675,42 @@ def test_fp16_route_ties_and_duplicates(oracle, metric):
             m = min(nq, 40)
             assert_same(lab[:m], dist[:m], oi[:m], od[:m], f"duplicates metric={metric} image={image} nq={nq}")
     idx.Close()
+
+
+def test_random_shapes_every_mode_agrees_with_the_strict_one():
+    """40 random (corpus size, dimension, batch, k, metric, data shape) draws: the fp16 routes (with the index's fp16 copy and
+    without it), the split-bf16 routes and AUTO return the strict mode's lists bit for bit (the strict mode itself is pinned to
+    the oracle by the tests above)"""
+    gpu_or_skip()
+    rng = np.random.default_rng(20261004)
+    for case in range(48):
+        big = case >= 40  # eight larger corpora: many tiles per persistent workgroup, several query tiles, AUTO's own choices
+        d = int(rng.choice([64, 128]) if big else rng.choice([32, 64, 96, 128, 160, 256, 512]))
+        n = int(rng.integers(270000, 420000) if big else rng.integers(1, 40000))
+        nq = int(rng.integers(1, 1100) if big else rng.integers(1, 700))
+        k = int(rng.integers(1, 60))
+        metric = int(rng.integers(0, 3))
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            X = rng.random((n, d), dtype=F) - F(0.5)
+        elif kind == 1:
+            X = rng.standard_normal((n, d)).astype(F) * F(rng.choice([0.05, 1.0, 30.0]))
+        elif kind == 2:  # a few tight clusters
+            c = rng.standard_normal((8, d)).astype(F)
+            X = c[rng.integers(0, 8, n)] + rng.standard_normal((n, d)).astype(F) * F(0.01)
+        else:            # blocks of exact duplicates and some zero rows
+            base = rng.standard_normal((max(1, n // 50), d)).astype(F)
+            X = base[rng.integers(0, len(base), n)].copy()
+            X[rng.integers(0, n, max(1, n // 100))] = F(0)
+        Q = X[rng.integers(0, n, nq)] + rng.standard_normal((nq, d)).astype(F) * F(0.02)
+        idx = new_index(d, metric)
+        idx.Add(None, X)
+        idx.set_candidate_mode(0)
+        want = idx.SearchBatch(Q, k)
+        for mode, image in ((4, 1), (4, 0), (2, 1), (3, 1)):
+            idx.set_candidate_mode(mode)
+            idx.set_f16_image(image)
+            lab, dist = idx.SearchBatch(Q, k)
+            assert_same(lab, dist, want[0], want[1],
+                        f"case {case}: n={n} d={d} nq={nq} k={k} metric={metric} data={kind} mode={mode} image={image}")
+        idx.Close()
