@@ -254,6 +254,9 @@ struct lb_gpu_index {
     int64_t xh_rows = 0, xh_cap = 0;
     std::atomic<int> xh_mode{1}; // lb_gpu_index_set_f16_image: 0 never, 1 when it pays and fits
     bool xh_failed = false;      // an allocation was refused: not tried again for this handle
+    // data whose neighbours the candidate keys cannot separate (tight clusters): batched searches start with the widened
+    // candidate list that proved the last such batch, for the next kc_hint_left searches (search_batch_device)
+    std::atomic<int> kc_hint{0}, kc_hint_left{0};
 
     hipStream_t add_stream = nullptr;
     void *h_stage[2] = {nullptr, nullptr};
@@ -714,7 +717,7 @@ static Route choose_route(int nq, int64_t n, int D, int cmode, bool narrow_ok, b
 }
 
 int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, const float *d_q, int k,
-                        float *d_dist, int64_t *d_lab, int kc_in, bool prof, int64_t &fallbacks, bool allow_f16 = true)
+                        float *d_dist, int64_t *d_lab, int kc_in, bool prof, int64_t &fallbacks, bool allow_f16 = true, int attempt = 0)
 {
     const int metric = h->metric, order = h->order.load();
     const RowView rv = row_view(h);
@@ -768,6 +771,10 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     // (Uniform random data is the hard case: its distances concentrate like 1/sqrt(D), so the gap shrinks with the dimension
     // while the bound does not -- beyond 1024 dimensions four times as many candidates are kept.)
     static const int f16_kc_mult = lb_tunable("LB_F16_KC_MULT", 0);
+    if (attempt == 0 && h->kc_hint_left.load(std::memory_order_relaxed) > 0) { // (see the retries at the end)
+        h->kc_hint_left.fetch_sub(1, std::memory_order_relaxed);
+        kc_in = std::max(kc_in, std::min(h->kc_hint.load(std::memory_order_relaxed), (int)(w->cap / 4)));
+    }
     int kc = kc_in;
     if (route.split == 3) kc = std::min(kc_in * (f16_kc_mult > 0 ? f16_kc_mult : (h->dim > 1024 ? 4 : 2)), (int)(w->cap / 4));
     const SamplePlan sp = sample_plan(n, kc, w->cap);
@@ -944,7 +951,18 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     }
     std::vector<int> bad;
     int nbad = collect_flagged(w, s, nq, 3u | 4u, nullptr, 0, bad, /*on_host=*/true);
+#ifdef LB_DIAG
+    if (getenv("LB_TRACE_RETRY")) {
+        uint32_t orf = 0;
+        int c1 = 0, c2 = 0, c4 = 0;
+        for (int i = 0; i < nq; i++) { orf |= w->h_flags[i]; c1 += (w->h_flags[i] & 1u) != 0; c2 += (w->h_flags[i] & 2u) != 0; c4 += (w->h_flags[i] & 4u) != 0; }
+        fprintf(stderr, "[retry] attempt %d route %d split %d kc %d sample %d m %d nbad %d flags|=%x (bit0 %d bit1 %d bit2 %d)\n", attempt, route.kind, route.split, kc,
+                (int)sp.on, sp.m, nbad, orf, c1, c2, c4);
+    }
+#endif
+    bool fused_gave_up = false;
     if (fused_epoch != 0 && (*w->h_fail == fused_epoch || g_fused_fail_next.exchange(0) != 0)) {
+        fused_gave_up = true;
         // a wait inside the fused launch gave up (its workgroups were not co-resident): every query goes the exact way,
         // and the ticket counter is re-based in case the launch did not run to completion
         bad.resize((size_t)nq);
@@ -954,17 +972,34 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         LB_HIP(hipMemsetAsync(w->d_fsync, 0, sizeof(uint32_t), s));
         w->fs_base = 0;
     }
-    if (route.split == 3 && cmode == LB_CAND_AUTO) {
-        if (nbad * 8 > nq) { // the fp16 keys are too coarse for this data: leave the route alone for a while (doubling spans)
-            const int span = h->f16_span.load();
+    const int kc_max = (int)(w->cap / 4);
+    const bool can_widen = attempt <= 2 && kc < kc_max && (int64_t)kc * 2 < n; // (up to three widenings: x4, x16, x64, capped)
+    if (route.split == 3 && cmode == LB_CAND_AUTO && attempt <= 3 && !(nbad > 8 && can_widen)) {
+        if (nbad * 8 > nq) { // the fp16 keys are too coarse for this data even with the widened list: leave the route alone
+            const int span = h->f16_span.load(); // for a while (doubling spans)
             h->f16_skip.store(span);
             h->f16_span.store(std::min(span * 2, 4096));
         } else if (nbad == 0) {
             h->f16_span.store(16);
         }
-        // more than a handful of unproven queries: one pass of the split-bf16 route over the whole batch (its keys are
-        // ~100x finer) costs less than exact scans of the unproven queries; what it cannot prove goes to the scan from there
-        if (nbad > 8) return search_batch_device(h, w, s, nq, d_q, k, d_dist, d_lab, kc_in, prof, fallbacks, /*allow_f16=*/false);
+    }
+    if (attempt >= 1 && attempt <= 3 && nbad <= 8) { // the widened list proved the batch: start the next searches there
+        h->kc_hint.store(kc_in, std::memory_order_relaxed);
+        h->kc_hint_left.store(256, std::memory_order_relaxed);
+    }
+    // More than a handful of unproven queries (each would cost an exact scan of the corpus: 0.5 ms per group of 8 at
+    // 1M x 768) and the batch is redone instead, cheapest remedy first:
+    //   1. the same route keeping FOUR TIMES the candidates (up to three times over, capped at a quarter of the list) -- the usual cause is a tight cluster (hundreds of rows whose
+    //      distances differ by less than the keys resolve): once the whole cluster is inside the list, the gap to the first
+    //      row outside it is wide and the proof goes through (1M x 768 in clusters of ~1000: 1024 queries 93 ms -> a few ms);
+    //   2. (fp16 keys) the split-bf16 route, ~100x finer keys, with the widened list;
+    //   3. the exact scan for what is still unproven.
+    if (nbad > 8 && !fused_gave_up && attempt < 4) {
+        if (can_widen)
+            return search_batch_device(h, w, s, nq, d_q, k, d_dist, d_lab, std::min(kc_in * 4, kc_max), prof, fallbacks, allow_f16,
+                                       attempt + 1);
+        if (route.split == 3 && allow_f16)
+            return search_batch_device(h, w, s, nq, d_q, k, d_dist, d_lab, kc_in, prof, fallbacks, /*allow_f16=*/false, 4);
     }
     if (nbad > 0) {
         fallbacks += (int64_t)bad.size();

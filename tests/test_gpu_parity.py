@@ -714,3 +714,28 @@ def test_random_shapes_every_mode_agrees_with_the_strict_one():
             assert_same(lab, dist, want[0], want[1],
                         f"case {case}: n={n} d={d} nq={nq} k={k} metric={metric} data={kind} mode={mode} image={image}")
         idx.Close()
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_tight_clusters_widen_the_candidate_list_instead_of_scanning(oracle, metric):
+    """clusters of ~350 rows whose distances to a query differ by less than the candidate keys resolve: the proof fails for
+    the whole batch at 256 candidates; the batch is redone with four times as many (the whole cluster inside the list, a wide
+    gap behind it) instead of one exact scan per query, the widened list is remembered for the next searches, and the
+    answers are the oracle's"""
+    gpu_or_skip()
+    rng = np.random.default_rng(5200 + metric)
+    n, d, k, nq = 70000, 96, 20, 300
+    centres = rng.standard_normal((200, d)).astype(F)
+    X = centres[rng.integers(0, 200, n)] + rng.standard_normal((n, d)).astype(F) * F(0.0005)
+    X /= np.linalg.norm(X, axis=1, keepdims=True).astype(F)
+    Q = X[rng.integers(0, n, nq)] + rng.standard_normal((nq, d)).astype(F) * F(0.0002)
+    idx = new_index(d, metric)
+    idx.Add(None, X)
+    oi, od = oracle.search_batch(metric, Q[:24], X, k, nthreads=8)
+    for mode in (3, 0, 4):
+        idx.set_candidate_mode(mode)
+        for rep in range(2):  # (the second search starts with the remembered list)
+            lab, dist = idx.SearchBatch(Q, k)
+            assert_same(lab[:24], dist[:24], oi, od, f"tight clusters metric={metric} mode={mode} rep={rep}")
+            assert idx.last_fallbacks <= 8, (mode, rep, idx.last_fallbacks)
+    idx.Close()
