@@ -678,7 +678,8 @@ static Route choose_route(int nq, int64_t n, int D, int cmode, bool narrow_ok, b
     // one fp16 product instead of three bf16 ones (split code 3): AUTO and the explicit LB_CAND_F16, while the corpus norms
     // allow it (f16_ok) and there are enough tiles to fill the chip
     static const int f16_on = lb_tunable("LB_F16", 1);
-    if (narrow_ok && f16_ok && f16_on && !image && (nq > 32 || have_f16_image) &&
+    // (over the fp16 copy the route needs neither dim % 32 == 0 nor aligned queries: both images are zero-padded planes)
+    if ((narrow_ok || have_f16_image) && f16_ok && f16_on && !image && (nq > 32 || have_f16_image) &&
         (cmode == LB_CAND_F16 || (cmode == LB_CAND_AUTO && n >= 262144))) { // (below: launch overheads decide, and the narrow tiles win)
         if (have_f16_image && nq <= 128) { // (one query tile: the 64- / 128-query form of the persistent kernel)
             // + what the route pays per query beside the stream: twice (beyond 1024 dimensions four times) the candidates to
@@ -739,13 +740,16 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     // 1 .. 4 queries: the exact scan streams the f32 corpus (0.52 ms per 1M x 768); with the fp16 copy the candidate pass
     // streams half the bytes and the exact re-rank of 512 candidates costs 0.03 ms -- taken when the model says it is cheaper
     bool small_on_copy = false;
-    if (!h->nonfinite && nq < narrow_min && narrow_ok && have_xh && h->f16_ok && allow_f16 &&
+    if (!h->nonfinite && nq < narrow_min && have_xh && h->f16_ok && allow_f16 &&
         (cmode == LB_CAND_F16 || (cmode == LB_CAND_AUTO && h->f16_skip.load(std::memory_order_relaxed) == 0))) {
         const double scan_ms = 1e-6 * (double)n * ((double)h->dim * 0.00066 + 0.04);
         const double copy_ms = route_ms(kCostNarrow16, n, h->dim, 1) + (h->dim > 1024 ? 0.0016 : 0.0007) * nq;
         small_on_copy = cmode == LB_CAND_F16 || copy_ms < scan_ms;
     }
-    if (h->nonfinite || (nq < (narrow_ok ? narrow_min : kGemmMinQ) && !small_on_copy)) {
+    // (dimensions that are not multiples of 32: the MFMA tiles over f32 rows do not apply; the fp16 copy does)
+    const bool copy_route_ok = have_xh && h->f16_ok && allow_f16 &&
+                               (cmode == LB_CAND_F16 || (cmode == LB_CAND_AUTO && h->f16_skip.load(std::memory_order_relaxed) == 0));
+    if (h->nonfinite || (nq < ((narrow_ok || copy_route_ok) ? narrow_min : kGemmMinQ) && !small_on_copy)) {
         h->last_route.store(0, std::memory_order_relaxed);
         std::vector<int> all(nq);
         for (int i = 0; i < nq; i++) all[i] = i;
@@ -815,7 +819,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     if (!use_narrow && (route.split == 1 || route.split == 2)) split_queries(); // the tall / wide split kernels take the batch as an image
     float *d_qinv = nullptr;
     if (use_tall16) { // fp16 image of the batch (scaled per query) + the inverse scales
-        const size_t img = (((size_t)nq * h->dim * 2) + 255) & ~(size_t)255, need = img + (size_t)nq * sizeof(float);
+        const size_t img = (((size_t)nq * (size_t)((h->dim + 31) & ~31) * 2) + 255) & ~(size_t)255, need = img + (size_t)nq * sizeof(float);
         if (w->d_qh_bytes < need) {
             if (w->d_qh) (void)hipFree(w->d_qh);
             w->d_qh = nullptr;
@@ -848,7 +852,10 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         if (use_narrow)
             launch_gemm_filter_narrow(metric, gx, h->d_norm2, h->d_rnorm, b, e, h->dim, gq, nq, mask, rowmap,
                                       w->cs, boot, s, tile64, nsplit);
-        else if (use_tall && boot && (wsplit == 2 || wsplit == 3) && sample_narrow)
+        else if (use_tall16 && h->dim % 32 != 0 && (rowmap || mask))
+            // the sample of a search over the fp16 copy when the dimension is not a multiple of 32: the f32 tile takes any
+            launch_gemm_filter(metric, h->d_X, h->d_norm2, h->d_rnorm, b, e, h->dim, d_q, nq, mask, rowmap, w->cs, boot, 0, s);
+        else if (use_tall && boot && (wsplit == 2 || wsplit == 3) && sample_narrow && h->dim % 32 == 0)
             // the 8192-row sample of a tall-tile search: the 64-query tile of the narrow kernel (same contraction, f32
             // operands) gets through its 24 K-steps of 32 in 31-35 us, the tall tile through its 48 of 16 in 57
             launch_gemm_filter_narrow(metric, h->d_X, h->d_norm2, h->d_rnorm, b, e, h->dim, d_q, nq, mask, rowmap, w->cs,
@@ -1281,7 +1288,7 @@ void sync_split_image(lb_gpu_index *h)
 void sync_f16_image(lb_gpu_index *h)
 {
     const int cm = h->cand_mode.load();
-    const bool want = h->xh_mode.load() != 0 && !h->xh_failed && h->dim % 32 == 0 && h->f16_ok && h->n > 0 &&
+    const bool want = h->xh_mode.load() != 0 && !h->xh_failed && h->f16_ok && h->n > 0 &&
                       (cm == LB_CAND_F16 || (cm == LB_CAND_AUTO && h->n >= 262144));
     try {
         if (!want || (h->d_Xh && (h->xh_cap < h->n || h->xh_rows > h->n))) {
@@ -1291,7 +1298,7 @@ void sync_f16_image(lb_gpu_index *h)
             if (!want) return;
         }
         if (h->d_Xh == nullptr) {
-            const size_t need = (size_t)h->capacity * (size_t)h->dim * 2;
+            const size_t need = (size_t)h->capacity * (size_t)((h->dim + 31) & ~31) * 2; // (planes of 32 dimensions, the last zero-padded)
             size_t fr = 0, tot = 0;
             LB_HIP(hipMemGetInfo(&fr, &tot));
             const size_t keep = std::max<size_t>((size_t)2 << 30, tot / 16);
@@ -1505,7 +1512,7 @@ int lb_gpu_index_set_candidate_mode(lb_gpu_index *h, int mode)
     if (!h || mode < LB_CAND_F32_MFMA || mode > LB_CAND_F16) return LB_ERR_INVALID_ARG;
     std::unique_lock<std::shared_mutex> g(h->mu);
     if (h->closed) return LB_ERR_CLOSED;
-    if ((mode == LB_CAND_SPLIT_BF16 || mode == LB_CAND_SPLIT_BF16_INREG || mode == LB_CAND_F16) && h->dim % 32 != 0) {
+    if ((mode == LB_CAND_SPLIT_BF16 || mode == LB_CAND_SPLIT_BF16_INREG) && h->dim % 32 != 0) {
         h->set_error("split-bf16 candidates need dim %% 32 == 0 (dim = %d)", h->dim);
         return LB_ERR_UNSUPPORTED;
     }
@@ -1540,7 +1547,7 @@ int lb_gpu_index_set_f16_image(lb_gpu_index *h, int mode)
 
 int64_t lb_gpu_index_f16_image_bytes(const lb_gpu_index *h)
 {
-    return h && h->d_Xh ? (int64_t)h->xh_cap * h->dim * 2 : 0;
+    return h && h->d_Xh ? (int64_t)h->xh_cap * ((h->dim + 31) & ~31) * 2 : 0;
 }
 
 int64_t lb_gpu_index_ntotal(const lb_gpu_index *h) { return h ? h->n : 0; }

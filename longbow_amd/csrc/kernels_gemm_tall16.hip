@@ -524,7 +524,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
         srcB[j] = reinterpret_cast<const unsigned char *>(a.Qh + (int64_t)qr * H_BK) + 16 * c;
     }
     const int64_t kb_stride = (int64_t)a.nq * (H_BK * 2);
-    const int nk = a.D / H_BK;
+    const int nk = AIMG ? (a.D + H_BK - 1) / H_BK : a.D / H_BK; // (both images are zero-padded to a multiple of 32 dimensions)
 
     const int krot = (qt * a.rot) % nk;
     // request cursor: the stage to be requested next = K-step ik of this workgroup's tile it, into ring slot islot
@@ -854,7 +854,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
         srcB[j] = reinterpret_cast<const unsigned char *>(a.Qh + (int64_t)qr * H_BK) + 16 * c;
     }
     const int64_t kb_stride = (int64_t)a.nq * (H_BK * 2);
-    const int nk = a.D / H_BK;
+    const int nk = (a.D + H_BK - 1) / H_BK; // (both images are zero-padded to a multiple of 32 dimensions)
 
     int it = 0, ik = 0, islot = 0;
     bool cursor_new_tile = false;
@@ -1075,7 +1075,8 @@ __global__ __launch_bounds__(256) void queries_to_f16_kernel(const float *Q, int
         scale = ldexpf(1.f, sh);
         inv = ldexpf(1.f, -sh);
     }
-    for (int i = lane; i < D; i += 64) Qh[((int64_t)(i >> 5) * nq + q) * 32 + (i & 31)] = (_Float16)(src[i] * scale);
+    const int Dp = (D + 31) & ~31; // (dimensions beyond D: zero -- they add nothing to a product)
+    for (int i = lane; i < Dp; i += 64) Qh[((int64_t)(i >> 5) * nq + q) * 32 + (i & 31)] = i < D ? (_Float16)(src[i] * scale) : (_Float16)0.f;
     if (lane == 0) qinv[q] = inv;
 }
 
@@ -1087,8 +1088,16 @@ __global__ __launch_bounds__(256) void corpus_to_f16_kernel(const float *X, int6
     const int64_t row = row_begin + (int64_t)blockIdx.x * 64 + (threadIdx.x >> 2);
     const int kb = blockIdx.y, q = threadIdx.x & 3;
     if (row >= row_end) return;
-    const f32x4 *src = reinterpret_cast<const f32x4 *>(X + row * (int64_t)D + kb * 32 + q * 8);
-    const f16x8 v = h_cvt8(src[0], src[1]);
+    const int k0 = kb * 32 + q * 8;
+    f16x8 v;
+    if (k0 + 8 <= D && (D & 3) == 0) { // (rows are 16-B aligned when D % 4 == 0)
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(X + row * (int64_t)D + k0);
+        v = h_cvt8(src[0], src[1]);
+    } else { // the last K-block of a dimension that is not a multiple of 32 (zero beyond D), or unaligned rows
+        const float *src = X + row * (int64_t)D;
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = k0 + e < D ? (_Float16)src[k0 + e] : (_Float16)0.f;
+    }
     *reinterpret_cast<f16x8 *>(Xh + ((int64_t)kb * cap + row) * 32 + q * 8) = v;
 }
 
@@ -1108,7 +1117,7 @@ void read_tall16_probe(unsigned long long out[8], bool reset)
 void launch_corpus_to_f16(const float *X, int64_t row_begin, int64_t row_end, int D, void *Xh, int64_t cap, hipStream_t s)
 {
     if (row_end <= row_begin) return;
-    dim3 grid((unsigned)((row_end - row_begin + 63) / 64), (unsigned)(D / 32));
+    dim3 grid((unsigned)((row_end - row_begin + 63) / 64), (unsigned)((D + 31) / 32));
     hipLaunchKernelGGL(corpus_to_f16_kernel, grid, dim3(256), 0, s, X, row_begin, row_end, D, reinterpret_cast<_Float16 *>(Xh), cap);
 }
 

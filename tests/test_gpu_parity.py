@@ -601,7 +601,7 @@ def test_fp16_persistent_tile_shapes(oracle, metric):
     rng = np.random.default_rng(900 + metric)
     k = 10
     saw_fp16 = 0
-    for n, d in ((300, 32), (5000, 64), (70001, 96), (33000, 768)):
+    for n, d in ((300, 32), (5000, 64), (70001, 96), (33000, 768), (5000, 100), (20000, 300), (3000, 50)):  # (the last three: zero-padded planes)
         X = (rng.random((n, d), dtype=F) - F(0.45)) * F(1.5)
         nq_max = 8300 if n == 5000 else 1500
         Q = (rng.random((nq_max, d), dtype=F) - F(0.45)) * F(1.5)
@@ -685,7 +685,7 @@ def test_random_shapes_every_mode_agrees_with_the_strict_one():
     rng = np.random.default_rng(20261004)
     for case in range(48):
         big = case >= 40  # eight larger corpora: many tiles per persistent workgroup, several query tiles, AUTO's own choices
-        d = int(rng.choice([64, 128]) if big else rng.choice([32, 64, 96, 128, 160, 256, 512]))
+        d = int(rng.choice([64, 128, 100]) if big else rng.choice([32, 64, 96, 128, 160, 256, 512, 50, 100, 300]))
         n = int(rng.integers(270000, 420000) if big else rng.integers(1, 40000))
         nq = int(rng.integers(1, 1100) if big else rng.integers(1, 700))
         k = int(rng.integers(1, 60))
@@ -708,6 +708,8 @@ def test_random_shapes_every_mode_agrees_with_the_strict_one():
         idx.set_candidate_mode(0)
         want = idx.SearchBatch(Q, k)
         for mode, image in ((4, 1), (4, 0), (2, 1), (3, 1)):
+            if mode == 2 and d % 32 != 0:
+                continue  # (the split-bf16 tiles need whole 128-B lines per K-step)
             idx.set_candidate_mode(mode)
             idx.set_f16_image(image)
             lab, dist = idx.SearchBatch(Q, k)
