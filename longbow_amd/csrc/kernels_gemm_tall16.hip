@@ -66,7 +66,8 @@ struct Tall16Args {
                          // by side, so a request of 16 query rows is ONE KiB of whole lines instead of 16 half lines: -10 %
                          // on the kernel), each query scaled by a power of two to 1 <= |q| < 2
     const float *qinv;   // [nq] 1 / that scale (exact)
-    int nq;
+    int nq;              // queries of this launch (Qh, qinv and the candidate state start at its first one)
+    int q_stride;        // query rows per K-block plane of Qh (the whole batch; a launch may cover a part of it)
     const uint8_t *mask;
     const uint32_t *rowmap;
     CandState cs;
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16_kernel(Tall16
         if (qr > last_q) qr = last_q;
         srcB[j] = reinterpret_cast<const unsigned char *>(a.Qh + (int64_t)qr * H_BK) + 16 * c - 1024 * j;
     }
-    const int64_t kb_stride = (int64_t)a.nq * (H_BK * 2); // bytes from one K-block of the query image to the next
+    const int64_t kb_stride = (int64_t)a.q_stride * (H_BK * 2); // bytes from one K-block of the query image to the next
     auto issue = [&](int kt) {
         const uint32_t A = ring_base + (uint32_t)(kt % H_NST) * H_STAGE_BYTES;
         const uint32_t B = A + H_A_BYTES;
@@ -523,7 +524,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
         if (qr > last_q) qr = last_q;
         srcB[j] = reinterpret_cast<const unsigned char *>(a.Qh + (int64_t)qr * H_BK) + 16 * c;
     }
-    const int64_t kb_stride = (int64_t)a.nq * (H_BK * 2);
+    const int64_t kb_stride = (int64_t)a.q_stride * (H_BK * 2);
     const int nk = AIMG ? (a.D + H_BK - 1) / H_BK : a.D / H_BK; // (both images are zero-padded to a multiple of 32 dimensions)
 
     const int krot = (qt * a.rot) % nk;
@@ -658,7 +659,10 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
             f16x8 a1[2], b1[4];
             if (PIPE) load_frag(cslot, 1, a1, b1); // (visible since the barrier in the middle of the step before)
             if (cursor_new_tile) { set_srcA(rt_of(it)); cursor_new_tile = false; }
-            if (kt == (nk > 1 ? 1 : 0) && i + 1 < n_my) aux_request(i + 1); // (its buffer was last read a tile ago)
+            // side input of the next tile: its buffer was last read in the epilogue a tile ago, and a barrier of THIS tile lies
+            // between that and the request (one K-step per tile: only the barrier in the middle of the step does)
+            const bool aux_now = i + 1 < n_my && kt == (nk > 1 ? 1 : 0);
+            if (aux_now && !(PIPE && nk == 1)) aux_request(i + 1);
 #pragma unroll
             for (int tn = 0; tn < 4; tn++) { // k-block 0
 #pragma unroll
@@ -675,6 +679,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
                 h_wait_vmcnt<NPS *(DIST - 2) + H1>();
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
+                if (aux_now && nk == 1) aux_request(i + 1);
                 load_frag(nslot, 0, a0, b0);
             }
 #pragma unroll
@@ -691,6 +696,14 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
 #ifdef LB_DIAG
         if (a.abl == 6) continue; // timing only: no epilogue
 #endif
+        // One K-step per tile (D <= 32): this tile's side input was asked for in the middle of the step before, which the
+        // K-steps' waits do not cover (they cover a stage asked for DIST steps earlier, and with it everything older).  By now
+        // 2 NPS - H1 (+ 1) requests are newer than it; vmcnt retires in order, the barrier publishes the other waves' parts.
+        if (PIPE && nk == 1 && METRIC != METRIC_DOT) {
+            h_wait_vmcnt<2 * NPS - H1>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
         // ---- epilogue of the tile (the next tile's first two stages are landing meanwhile) --------------------------------
         // Two VALU operations per element: the candidate key in the form that needs ONE operation (cosine / dot: acc * (-ax),
         // compared with tau_key / qs -- qs is a power of two, so this is the comparison of the keys themselves; L2:
@@ -853,7 +866,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
         const int qr = row > last_q ? last_q : row;
         srcB[j] = reinterpret_cast<const unsigned char *>(a.Qh + (int64_t)qr * H_BK) + 16 * c;
     }
-    const int64_t kb_stride = (int64_t)a.nq * (H_BK * 2);
+    const int64_t kb_stride = (int64_t)a.q_stride * (H_BK * 2);
     const int nk = (a.D + H_BK - 1) / H_BK; // (both images are zero-padded to a multiple of 32 dimensions)
 
     int it = 0, ik = 0, islot = 0;
@@ -951,7 +964,8 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
             f16x8 a1, b1[TN];
             if (PIPE) load_frag(cslot, 1, a1, b1);
             if (cursor_new_tile) { set_srcA(rt_of(it)); cursor_new_tile = false; }
-            if (kt == (nk > 1 ? 1 : 0) && i + 1 < n_my) aux_request(i + 1);
+            const bool aux_now = i + 1 < n_my && kt == (nk > 1 ? 1 : 0); // (see the 256-query form)
+            if (aux_now && !(PIPE && nk == 1)) aux_request(i + 1);
 #pragma unroll
             for (int tn = 0; tn < TN; tn++) {
                 acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0[tn], acc[tn], 0, 0, 0);
@@ -964,6 +978,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
                 h_wait_vmcnt<NPS *(DIST - 2) + H1>();
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
+                if (aux_now && nk == 1) aux_request(i + 1);
                 load_frag(nslot, 0, a0, b0);
             }
 #pragma unroll
@@ -975,6 +990,17 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
             cslot = nslot;
         }
 
+        // One or two K-steps per tile (D <= 64): the side input of this tile was asked for fewer requests ago than the ring keeps
+        // in flight (the K-steps' waits cover a stage asked for DIST steps earlier, and the side input only when it is older
+        // than that stage: from three K-steps per tile on).  Requests newer than it by now: 2 NPS - H1 (+ 1) at one K-step per
+        // tile (asked for in the middle of the step before), 3 NPS (+ 1) at two (at the top of the tile before's second step);
+        // vmcnt retires in order, and the barrier publishes the other waves' parts.
+        if (PIPE && nk <= 2 && METRIC != METRIC_DOT) {
+            if (nk == 1) h_wait_vmcnt<2 * NPS - H1>();
+            else h_wait_vmcnt<3 * NPS>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
         // ---- epilogue of the tile (as the 256-query form: 2 VALU + 1 scalar branch per element, per-wave segments) ----------
         const float *s_aux = s_auxp + (i & 1) * 512;
         float aux[4][4];
@@ -1129,15 +1155,18 @@ void launch_queries_to_f16(const float *Q, int nq, int D, void *Qh, float *qinv,
 }
 
 // Requires D % 32 == 0, 16-B aligned X / Qh; Qh / qinv from launch_queries_to_f16; X is the plain f32 corpus.
-void launch_gemm_filter_tall16(int metric, const float *X, const float *norm2, const float *rnorm, int64_t row_begin,
-                               int64_t row_end, int D, const void *Qh, const float *qinv, int nq, const uint8_t *mask,
-                               const uint32_t *rowmap, CandState cs, bool boot, hipStream_t s, const void *Xh, int64_t xh_cap)
+// One launch over a window of the batch: Qh, qinv and cs start at the window's first query, q_stride is the batch's row count
+// (the K-block planes of the query image are that far apart).
+static void tall16_window(int metric, const float *X, const float *norm2, const float *rnorm, int64_t row_begin, int64_t row_end,
+                          int D, const void *Qh, const float *qinv, int nq, int q_stride, const uint8_t *mask,
+                          const uint32_t *rowmap, CandState cs, bool boot, hipStream_t s, const void *Xh, int64_t xh_cap,
+                          bool may_split)
 {
     if (row_end <= row_begin || nq <= 0) return;
     Tall16Args a;
     a.rowmap = rowmap;
     a.X = X; a.norm2 = norm2; a.rnorm = rnorm; a.row_begin = row_begin; a.row_end = row_end; a.D = D;
-    a.Qh = reinterpret_cast<const _Float16 *>(Qh); a.qinv = qinv; a.nq = nq; a.mask = mask; a.cs = cs; a.boot = boot ? 1 : 0;
+    a.Qh = reinterpret_cast<const _Float16 *>(Qh); a.qinv = qinv; a.nq = nq; a.q_stride = q_stride; a.mask = mask; a.cs = cs; a.boot = boot ? 1 : 0;
     a.n_row_tiles = (int)((row_end - row_begin + H_BM - 1) / H_BM);
     a.n_q_tiles = (nq + H_BN - 1) / H_BN;
     a.abl = lb_tunable("LB_F16_ABL", 0);
@@ -1166,6 +1195,26 @@ void launch_gemm_filter_tall16(int metric, const float *X, const float *norm2, c
     }();
     if (persist && !rowmap && !mask && spx >= 1 && a.n_q_tiles <= spx && lds_max >= 163840) {
         const bool img = Xh != nullptr; // (sync_f16_image: in step with the corpus, K-blocked, xh_cap rows per plane)
+        // A batch that ends 1 .. 64 queries into a 256-query tile: the whole tiles on the 256-wide kernel, the rest on the
+        // one-tile kernel (a second pass over the image at its HBM rate, 0.24 ms per 1M x 768, instead of one more 256-wide
+        // query tile that is mostly padding: 0.38 ms beside the others).  1M x 768: 257 queries 1.13 -> 0.98 ms, 320: 1.00 ->
+        // 0.91, 640: 1.59 -> 1.53; a tail of 65 .. 128 on the 128-query tile measured level (384, 896) and is not split.
+        // Each launch sees its own window of the batch: the image, the scales and the candidate state from its first query
+        // on; q_stride stays the batch's.
+        const int tail = nq % H_BN;
+        static const int split_tail = lb_tunable("LB_F16_SPLIT_TAIL", 1);
+        if (img && may_split && split_tail && nq > H_BN && tail >= 1 && tail <= 64) {
+            const int head = nq - tail;
+            tall16_window(metric, X, norm2, rnorm, row_begin, row_end, D, Qh, qinv, head, q_stride, mask, rowmap, cs, boot, s, Xh,
+                          xh_cap, false);
+            CandState ct = cs;
+            ct.lists += (size_t)head * cs.cap;
+            ct.cnt += head;
+            ct.tau += head;
+            tall16_window(metric, X, norm2, rnorm, row_begin, row_end, D, reinterpret_cast<const _Float16 *>(Qh) + (size_t)head * H_BK,
+                          qinv + head, tail, q_stride, mask, rowmap, ct, boot, s, Xh, xh_cap, false);
+            return;
+        }
         static const int n16 = lb_tunable("LB_F16_NARROW", 1);
         // (the 256-query instance of this kernel measured level with the 4 x 2-wave tile below -- 0.43 ms per pass, bound by MFMA +
         // LDS work either way -- and is not built)
@@ -1270,6 +1319,13 @@ void launch_gemm_filter_tall16(int metric, const float *X, const float *norm2, c
     else LB_TALL16_M(METRIC_DOT);
 #undef LB_TALL16_M
 #undef LB_TALL16
+}
+
+void launch_gemm_filter_tall16(int metric, const float *X, const float *norm2, const float *rnorm, int64_t row_begin,
+                               int64_t row_end, int D, const void *Qh, const float *qinv, int nq, const uint8_t *mask,
+                               const uint32_t *rowmap, CandState cs, bool boot, hipStream_t s, const void *Xh, int64_t xh_cap)
+{
+    tall16_window(metric, X, norm2, rnorm, row_begin, row_end, D, Qh, qinv, nq, nq, mask, rowmap, cs, boot, s, Xh, xh_cap, true);
 }
 
 } // namespace lb

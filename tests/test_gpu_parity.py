@@ -595,7 +595,8 @@ def test_fp16_persistent_tile_shapes(oracle, metric):
     """the persistent fp16 kernel (kernels_gemm_tall16.hip) over the shapes its tile walk has to get right: one K-step per
     row (D = 32: the side input of the next tile is asked for in the only step there is), fewer corpus tiles than
     workgroups, a ragged last tile, 1 .. 6 query tiles per corpus tile (3, 5 and 6 leave workgroup slots of an XCD idle) and
-    more query tiles than an XCD has slots (the one-workgroup-per-tile form takes over) -- equal to the oracle on the
+    more query tiles than an XCD has slots (the one-workgroup-per-tile form takes over), batches that end 1 .. 64 queries into
+    a 256-query tile (257, 320, 1050: whole tiles on the 256-wide kernel, the tail on the one-tile kernel; 384, 600: not split) -- equal to the oracle on the
     first queries and to the strict mode on all of them"""
     gpu_or_skip()
     rng = np.random.default_rng(900 + metric)
@@ -608,7 +609,7 @@ def test_fp16_persistent_tile_shapes(oracle, metric):
         idx = new_index(d, metric)
         idx.Add(None, X)
         oi, od = oracle.search_batch(metric, Q[:24], X, k, nthreads=8)
-        for nq in (1, 3, 5, 17, 40, 64, 65, 100, 128, 129, 200, 256, 257, 600, 1100, 1500) + ((8300,) if n == 5000 else ()):  # <= 64: the 64-query tile (with the copy)
+        for nq in (1, 3, 5, 17, 40, 64, 65, 100, 128, 129, 200, 256, 257, 320, 384, 600, 1050, 1500) + ((8300,) if n == 5000 else ()):  # <= 64: the 64-query tile (with the copy)
             idx.set_candidate_mode(0)
             want = idx.SearchBatch(Q[:nq], k)
             idx.set_candidate_mode(4)
@@ -623,6 +624,36 @@ def test_fp16_persistent_tile_shapes(oracle, metric):
             idx.set_f16_image(1)
         idx.Close()
     assert saw_fp16 >= 16, saw_fp16
+
+
+@pytest.mark.parametrize("d", [16, 32, 64])
+def test_fp16_one_and_two_k_steps_per_tile_many_tiles(oracle, d):
+    """D <= 64 over the fp16 copy: a tile is one or two K-steps, so the side input (norms) of a tile is asked for fewer requests
+    before its use than the six-stage ring keeps in flight -- the kernel waits for it by count before the epilogue, and asks
+    for the next one only behind a barrier of the tile (round 3: found by test_random_shapes seed 12 as a run-to-run
+    difference).  Dozens of tiles per workgroup, every query-tile width, repeated: identical to the strict mode each time,
+    and to the oracle on the first queries."""
+    gpu_or_skip()
+    rng = np.random.default_rng(4300 + d)
+    n, k = 1_500_000, 10
+    X = rng.random((n, d), dtype=F)
+    Q = rng.random((300, d), dtype=F)
+    Q[0] = X[n // 2]
+    for metric in (1, 0):
+        idx = new_index(d, metric)
+        idx.Add(None, X)
+        oi, od = oracle.search_batch(metric, Q[:8], X, k, nthreads=8)
+        for nq in (6, 64, 100, 128, 300):
+            idx.set_candidate_mode(0)
+            want = idx.SearchBatch(Q[:nq], k)
+            assert_same(want[0][:8][:nq], want[1][:8][:nq], oi[:nq], od[:nq], f"strict d={d} metric={metric} nq={nq}")
+            idx.set_candidate_mode(4)
+            assert idx.f16_image_bytes > 0
+            for rep in range(4):
+                lab, dist = idx.SearchBatch(Q[:nq], k)
+                assert idx.last_route[0] in (6, 7), idx.last_route
+                assert_same(lab, dist, want[0], want[1], f"fp16 d={d} metric={metric} nq={nq} repeat {rep}")
+        idx.Close()
 
 
 def test_fp16_image_follows_the_corpus(oracle):
