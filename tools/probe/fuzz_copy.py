@@ -1,6 +1,6 @@
 """One-off randomised sweep over the routes that read the index's fp16 copy: large corpora (many tiles per persistent workgroup),
 every dimension class (one / two / many K-steps per tile, odd dimensions), every batch regime; fp16 and AUTO against the strict
-mode, each search repeated.  usage: python tools/probe/fuzz_copy.py [seed] [seconds]"""
+mode, each search repeated.  usage: python tools/probe/fuzz_copy.py [seed] [seconds]   (FUZZ_WIDE=1: dimensions 768 .. 4096, k up to 2048, the dense index's maximum)"""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np
@@ -10,10 +10,12 @@ budget = float(sys.argv[2]) if len(sys.argv) > 2 else 150.0
 rng = np.random.default_rng(seed)
 t0 = time.time(); case = 0; bad = 0
 while time.time() - t0 < budget:
-    d = int(rng.choice([4, 8, 16, 24, 32, 40, 64, 72, 96, 100, 128, 200, 256, 300, 384]))
-    n = int(rng.integers(280_000, 2_500_000 if d <= 64 else 700_000))
-    nq = int(rng.choice([1, 2, 4, 5, 6, 17, 33, 64, 65, 100, 128, 129, 200, 256, 257, 300, 320, 500, 513, 576, 700, 1024, 1100]))
-    k = int(rng.choice([1, 5, 10, 37, 100]))
+    wide = os.environ.get("FUZZ_WIDE") == "1"  # high dimensions and large k instead of many tiles
+    d = int(rng.choice([768, 1000, 1024, 1536, 2048, 4096]) if wide else rng.choice([4, 8, 16, 24, 32, 40, 64, 72, 96, 100, 128, 200, 256, 300, 384]))
+    n = int(rng.integers(263_000, 330_000) if wide else rng.integers(280_000, 2_500_000 if d <= 64 else 700_000))
+    nq = int(rng.choice([1, 4, 6, 64, 130, 300]) if wide else
+             rng.choice([1, 2, 4, 5, 6, 17, 33, 64, 65, 100, 128, 129, 200, 256, 257, 300, 320, 500, 513, 576, 700, 1024, 1100]))
+    k = int(rng.choice([1, 100, 1000, 2048]) if wide else rng.choice([1, 5, 10, 37, 100]))
     metric = int(rng.integers(0, 3))
     kind = int(rng.integers(0, 3))
     if kind == 0: X = rng.random((n, d), dtype=F)
