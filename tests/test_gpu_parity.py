@@ -682,6 +682,39 @@ def test_fp16_image_follows_the_corpus(oracle):
     idx.Close()
 
 
+def test_fp16_copy_waits_for_free_memory(oracle):
+    """memory policy of the fp16 copy (index.hip: sync_f16_image): it is taken only while that leaves max(2 GiB, 1/16 of the
+    device) free -- with the device nearly full the index comes up WITHOUT the copy (the fp16 route rounds the f32 rows in
+    registers, same results), and the next Add after memory has been released builds it"""
+    gpu_or_skip()
+    import torch
+    rng = np.random.default_rng(78)
+    d, k, nq = 64, 10, 200
+    X = (rng.random((40000, d), dtype=F) - F(0.5))
+    Q = (rng.random((nq, d), dtype=F) - F(0.5))
+    torch.cuda.empty_cache()
+    free, total = torch.cuda.mem_get_info()
+    hog = torch.empty(free - (3 << 30), dtype=torch.uint8, device="cuda")  # leaves ~3 GiB: less than the policy keeps free
+    try:
+        idx = new_index(d, 1)
+        idx.set_candidate_mode(4)
+        idx.Add(None, X[:30000])
+        assert idx.f16_image_bytes == 0, "the copy must not be taken while the device is nearly full"
+        lab, dist = idx.SearchBatch(Q, k)
+        assert idx.last_route[0] == 6, idx.last_route
+        oi, od = oracle.search_batch(1, Q, X[:30000], k, nthreads=8)
+        assert_same(lab, dist, oi, od, "fp16 route without the copy (device nearly full)")
+    finally:
+        del hog
+        torch.cuda.empty_cache()
+    idx.Add(None, X[30000:])
+    assert idx.f16_image_bytes >= 40000 * d * 2, "memory is free again: the Add builds the copy"
+    lab, dist = idx.SearchBatch(Q, k)
+    oi, od = oracle.search_batch(1, Q, X, k, nthreads=8)
+    assert_same(lab, dist, oi, od, "fp16 route over the copy built by the later Add")
+    idx.Close()
+
+
 @pytest.mark.parametrize("metric", [0, 1, 2])
 def test_fp16_route_ties_and_duplicates(oracle, metric):
     """thousands of exact duplicates among the nearest rows: their candidate keys tie AT the sampled threshold (the fp16
