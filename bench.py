@@ -216,6 +216,48 @@ def leg_pq_adc(torch, dev, lib, _lib, cores, check=True):
     return res
 
 
+def leg_concurrent_callers(lib, idx, Q, threads=8, secs=1.0):
+    """gpu.Index.Search as the reference calls it (internal/gpu/faiss_gpu.go:108-145): ONE query per call through the
+    host-pointer entry, from `threads` concurrent callers (goroutines there, host threads here; ctypes releases the GIL).
+    With request combining (the library default) overlapping calls are answered by one batched device search; without it every
+    call streams the corpus for itself."""
+    import threading
+    Qh = Q[:threads].cpu().numpy()
+    out = {}
+    for name, comb in (("combined", 1), ("each_call_on_its_own", 0)):
+        idx.set_search_combining(comb)
+        before = idx.combining_stats
+        barrier = threading.Barrier(threads)
+        res = {}
+
+        def worker(t):
+            q = np.ascontiguousarray(Qh[t])
+            od, ol = np.empty(K, np.float32), np.empty(K, np.int64)
+            for _ in range(3):
+                lib.lb_gpu_index_search(idx._h, 1, q.ctypes.data, K, od.ctypes.data, ol.ctypes.data)
+            barrier.wait()
+            t0 = time.perf_counter()
+            lat = []
+            while time.perf_counter() - t0 < secs:
+                a = time.perf_counter()
+                lib.lb_gpu_index_search(idx._h, 1, q.ctypes.data, K, od.ctypes.data, ol.ctypes.data)
+                lat.append(time.perf_counter() - a)
+            res[t] = (lat, time.perf_counter() - t0)
+
+        ths = [threading.Thread(target=worker, args=(t,)) for t in range(threads)]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        lat = sorted(x for l, _ in res.values() for x in l)
+        after = idx.combining_stats
+        out[name] = {"queries_per_s": round(sum(len(l) / dt for l, dt in res.values()), 1),
+                     "p50_ms": round(1e3 * lat[len(lat) // 2], 4), "p99_ms": round(1e3 * lat[int(len(lat) * 0.99)], 4),
+                     "combined_batches": after[0] - before[0], "requests_in_them": after[1] - before[1]}
+    idx.set_search_combining(1)
+    out["threads"] = threads
+    out["entry"] = "lb_gpu_index_search (host pointers, 1 query per call)"
+    return out
+
+
 def leg_filtered_hybrid(torch, dev, lib, _lib, cores):
     """BASELINE config 5 on ONE GPU's share: 1.25M x 1536 f32 dot, int64 metadata `< 10` (10 % of the rows),
     batch 256, dense side asks for 2k = 200 (internal/store/hybrid_search.go:62), RRF k = 60 with a synthetic
@@ -684,6 +726,10 @@ def main():
                 result["batch_sweep"] = leg_batch_sweep(torch, dev, idx, Q, rows)  # library default (AUTO)
             except Exception as e:
                 result["batch_sweep"] = {"error": str(e)}
+            try:
+                result["concurrent_single_query_callers"] = leg_concurrent_callers(lib, idx, Q)
+            except Exception as e:
+                result["concurrent_single_query_callers"] = {"error": str(e)}
 
         # ---- parity gate + CPU baseline (oracle = test/bench infrastructure, never the product) -----
         from oracle import oracle_c as oc

@@ -244,6 +244,24 @@ func (idx *HIPIndex) SetF16Image(on bool) error {
 	return nil
 }
 
+// SetSearchCombining controls whether concurrent Search calls (one query each, one goroutine each) are answered by ONE batched
+// device search when they overlap (lb_gpu_index_set_search_combining; default on).  The lists are identical either way.
+func (idx *HIPIndex) SetSearchCombining(on bool) error {
+	idx.mu.Lock()
+	defer idx.mu.Unlock()
+	if idx.closed {
+		return fmt.Errorf("index is closed")
+	}
+	m := C.int(0)
+	if on {
+		m = 1
+	}
+	if rc := C.lb_gpu_index_set_search_combining(idx.h, m); rc != C.LB_OK {
+		return hipError(idx.h, "set_search_combining", rc)
+	}
+	return nil
+}
+
 // F16ImageBytes reports the HBM that copy holds right now (0: none) -- for the memory gauge.
 func (idx *HIPIndex) F16ImageBytes() int64 {
 	idx.mu.RLock()

@@ -109,6 +109,14 @@ class Index {
         return wrap("set_f16_image", lb_gpu_index_set_f16_image(h_, on ? 1 : 0));
     }
 
+    // concurrent single-query Search calls answered by one batched search (default on; lists identical either way)
+    Error SetSearchCombining(bool on)
+    {
+        std::unique_lock<std::shared_mutex> g(mu_);
+        if (closed_) return {LB_ERR_CLOSED, "index is closed"};
+        return wrap("set_search_combining", lb_gpu_index_set_search_combining(h_, on ? 1 : 0));
+    }
+
     // The distance step of processChunkInternal (internal/store/parallel_search.go:274-364) on rows that are
     // resident on the GPU: dist[i] as simd.EuclideanDistanceBatchFlat computes it (4-accumulator order),
     // score[i] = 1/(1+dist[i]).  rows are row positions.

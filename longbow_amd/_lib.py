@@ -51,6 +51,8 @@ SIGNATURES = [
     ("lb_gpu_index_set_candidate_mode", _i, [_vp, _i]),
     ("lb_gpu_index_set_f16_image", _i, [_vp, _i]),
     ("lb_gpu_index_f16_image_bytes", _i64, [_vp]),
+    ("lb_gpu_index_set_search_combining", _i, [_vp, _i]),
+    ("lb_gpu_index_combining_stats", _i, [_vp, C.POINTER(C.c_int64)]),
     ("lb_gpu_index_ntotal", _i64, [_vp]),
     ("lb_gpu_index_dim", _i, [_vp]),
     ("lb_gpu_index_device", _i, [_vp]),

@@ -178,6 +178,20 @@ class Index:
         self._live()
         return int(self._lib.lb_gpu_index_f16_image_bytes(self._h))
 
+    def set_search_combining(self, enable):
+        """1 (default): concurrent host-pointer searches of a few queries each are answered by one batched search (lists identical
+        to the single searches'); 0: every call searches on its own"""
+        self._live()
+        _lib.check(self._lib.lb_gpu_index_set_search_combining(self._h, 1 if enable else 0), self._h, lib=self._lib)
+
+    @property
+    def combining_stats(self):
+        """(combined batches run, requests they answered)"""
+        self._live()
+        out = (C.c_int64 * 2)()
+        _lib.check(self._lib.lb_gpu_index_combining_stats(self._h, out), self._h, lib=self._lib)
+        return int(out[0]), int(out[1])
+
     def set_filter(self, mask):
         self._live()
         if mask is None:

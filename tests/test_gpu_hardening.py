@@ -132,6 +132,57 @@ def test_k_is_checked_before_any_staging_is_sized():
     idx.Close()
 
 
+def test_concurrent_single_query_searches_are_combined_and_identical(oracle):
+    """gpu.Index.Search is one query per call, from many goroutines (internal/gpu/faiss_gpu.go:108-145): calls that overlap are
+    answered by ONE batched device search (index.hip: combined_search).  Every caller must get exactly what a search on its own
+    returns -- same labels, same distance bits --, callers with another k are never mixed in, errors reach their caller only,
+    and the counters show that batches were in fact combined."""
+    gpu_or_skip()
+    rng = np.random.default_rng(515)
+    n, d = 300_000, 128
+    X = rng.random((n, d), dtype=F)
+    Q = rng.random((96, d), dtype=F)
+    idx = new_index(d, 1)
+    idx.Add(None, X)
+    ks = (10, 37)
+    idx.set_search_combining(False)
+    want = {k: [idx.Search(Q[i], k) for i in range(len(Q))] for k in ks}
+    oi, od = oracle.search_batch(1, Q[:4], X, ks[0], nthreads=8)
+    for i in range(4):
+        assert_same(want[ks[0]][i][0][None], want[ks[0]][i][1][None], oi[i][None], od[i][None], f"sequential search {i}")
+    assert idx.combining_stats == (0, 0)
+    idx.set_search_combining(True)
+    errors = []
+
+    def caller(t):
+        try:
+            k = ks[t % 2] if t >= 6 else ks[0]          # two of the eight callers ask for another k
+            for rep in range(25):
+                for i in range(t, len(Q), 8):
+                    lab, dist = idx.Search(Q[i], k)
+                    if not (np.array_equal(lab, want[k][i][0]) and np.array_equal(dist, want[k][i][1])):
+                        errors.append(f"thread {t} query {i} k {k} rep {rep}: differs from the search on its own")
+                if t == 3 and rep % 5 == 0:             # a bad call in the middle of the traffic fails alone
+                    with pytest.raises(ValueError):
+                        idx.Search(Q[0][: d - 1], k)
+        except Exception as e:  # noqa: BLE001
+            errors.append(f"thread {t}: {type(e).__name__}: {e}")
+
+    ths = [threading.Thread(target=caller, args=(t,)) for t in range(8)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errors, errors[:5]
+    batches, requests = idx.combining_stats
+    assert batches > 0 and requests >= 2 * batches, (batches, requests)
+    # a lone caller is never held back: nothing is combined when calls do not overlap
+    before = idx.combining_stats
+    for i in range(8):
+        lab, dist = idx.Search(Q[i], ks[0])
+        assert np.array_equal(lab, want[ks[0]][i][0]) and np.array_equal(dist, want[ks[0]][i][1])
+    assert idx.combining_stats == before
+    idx.Close()
+
+
 @pytest.mark.parametrize("order", [0, 1])
 def test_batch_over_slices_follows_the_reference_per_vector_rules(oracle, order):
     gpu_or_skip()
