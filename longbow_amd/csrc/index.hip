@@ -1858,12 +1858,19 @@ static int host_search_multi(lb_gpu_index *h, HostReq *const *reqs, int nreq, in
             }
         }
         LB_HIP(hipMemcpyAsync(dbuf + qoff, hb + qoff, qb, hipMemcpyHostToDevice, st->stream));
+        // Small results (a few queries: the latency path) are written by the last kernel straight into the pinned slab -- no
+        // device-to-host copy and no second wait behind it (~20 us of a 0.35 ms call); the search's own stream
+        // synchronisation is what makes them visible.  Large results go through HBM and one DMA.
+        const bool direct = db + lb_ <= ((size_t)64 << 10);
+        char *obuf = direct ? hb : dbuf;
         rc = lb_gpu_index_search_device_ctx(h, nq, reinterpret_cast<const float *>(dbuf + qoff), k,
-                                            reinterpret_cast<float *>(dbuf + doff), reinterpret_cast<int64_t *>(dbuf + loff),
+                                            reinterpret_cast<float *>(obuf + doff), reinterpret_cast<int64_t *>(obuf + loff),
                                             st->stream, ctx);
         if (rc == LB_OK) {
-            LB_HIP(hipMemcpyAsync(hb + doff, dbuf + doff, db + lb_, hipMemcpyDeviceToHost, st->stream));
-            LB_HIP(hipStreamSynchronize(st->stream));
+            if (!direct) {
+                LB_HIP(hipMemcpyAsync(hb + doff, dbuf + doff, db + lb_, hipMemcpyDeviceToHost, st->stream));
+                LB_HIP(hipStreamSynchronize(st->stream));
+            }
             size_t row = 0;
             for (int i = 0; i < nreq; i++) {
                 const size_t n = (size_t)reqs[i]->nq * k;
