@@ -294,6 +294,10 @@ int lb_gpu_pq_search_device(lb_gpu_pq *p, int64_t nq, const float *d_queries, in
 /* the same with a cancellation context, polled between the queries of the batch and the launches of one query */
 int lb_gpu_pq_search_ctx(lb_gpu_pq *p, int64_t nq, const float *queries, int k, float *dist, int64_t *labels,
                          const lb_cancel *ctx);
+/* Concurrent host-pointer ADC searches are combined like lb_gpu_index_search's (lb_gpu_index_set_search_combining): queued calls
+ * with the same k are answered by one batch, in which two queries share each pass over the codes.  On by default. */
+int lb_gpu_pq_set_search_combining(lb_gpu_pq *p, int enable);
+int lb_gpu_pq_combining_stats(const lb_gpu_pq *p, int64_t out[2]);
 int lb_gpu_pq_search_device_ctx(lb_gpu_pq *p, int64_t nq, const float *d_queries, int k, float *d_dist,
                                 int64_t *d_labels, void *stream, const lb_cancel *ctx);
 /* 1 (default): the search runs the byte-table prefilter + exact survivors; 0: the exact f32-table

@@ -66,6 +66,8 @@ SIGNATURES = [
     ("lb_simd_distance_batch", _i, [_i, _i, _i, _vp, _i, _vp, _vp, _i64, _vp]),
     ("lb_gpu_pq_search_ctx", _i, [_vp, _i64, _vp, _i, _vp, _vp, _vp]),
     ("lb_gpu_pq_search_device_ctx", _i, [_vp, _i64, _vp, _i, _vp, _vp, _vp, _vp]),
+    ("lb_gpu_pq_set_search_combining", _i, [_vp, _i]),
+    ("lb_gpu_pq_combining_stats", _i, [_vp, C.POINTER(C.c_int64)]),
     ("lb_gpu_pq_set_prefilter", _i, [_vp, _i]),
     ("lb_gpu_index_reserve", _i, [_vp, _i64]),
     ("lb_gpu_index_add", _i, [_vp, _i64, _vp, _vp]),

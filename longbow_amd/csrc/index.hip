@@ -13,8 +13,6 @@
 
 #include <algorithm>
 #include <atomic>
-#include <condition_variable>
-#include <deque>
 #include <cfloat>
 #include <cstdarg>
 #include <cstdio>
@@ -118,18 +116,6 @@ struct HostStage {
         if (h_buf) (void)hipHostFree(h_buf);
         if (stream) (void)hipStreamDestroy(stream);
     }
-};
-
-// One host-pointer search request as the combiner sees it (lb_gpu_index_search: see combined_search)
-struct HostReq {
-    const float *q;
-    int64_t nq;
-    float *dist;
-    int64_t *labels;
-    int k;
-    int rc = LB_OK;
-    bool done = false; // served by another caller's batch
-    bool lead = false; // promoted: run the next batch (its own request included)
 };
 
 } // namespace
@@ -280,15 +266,7 @@ struct lb_gpu_index {
     std::vector<std::unique_ptr<Workspace>> ws_free;
     std::vector<std::unique_ptr<HostStage>> hs_free;
 
-    // Concurrent host-pointer searches of a few queries each (the reference's Search is ONE query per call, from many
-    // goroutines) are combined: while two calls' searches are on the device, later callers queue; the first of them then runs ONE
-    // batched search for everybody who queued with the same k (combined_search).  One or two callers never wait.
-    std::mutex cb_mu;
-    std::condition_variable cb_cv;
-    int cb_active = 0; // searches of this kind on the device right now (at most kCombineLanes)
-    std::deque<HostReq *> cb_wait;
-    std::atomic<int> cb_on{1};
-    std::atomic<int64_t> cb_batches{0}, cb_requests{0}; // combined batches run / requests served by them
+    SearchCombiner combiner; // concurrent host-pointer searches of a few queries each are combined (lb_host.h)
 
     mutable std::mutex err_mu;
     std::string last_error;
@@ -1890,78 +1868,6 @@ static int host_search_multi(lb_gpu_index *h, HostReq *const *reqs, int nreq, in
     return rc;
 }
 
-// Requests of at most this many queries take part in combining; a combined batch holds at most kCombineBatch queries.
-constexpr int64_t kCombineMaxNq = 16, kCombineBatch = 256;
-// Two searches at a time: one's host work (staging, copies, wake-up: ~80 us around a 0.3 ms search) runs under the other's
-// device work, and two callers alone are served exactly as without combining (measured on 1M x 768 with one lane: two threads
-// 3.7 k -> 3.0 k queries/s, each waiting out the other's search; with two lanes no loss).
-constexpr int kCombineLanes = 2;
-
-// Hand the device to the next waiting caller, or mark it free (the caller that leaves a search does this).
-static void combine_pass_on(lb_gpu_index *h)
-{
-    std::lock_guard<std::mutex> g(h->cb_mu);
-    if (h->cb_wait.empty()) {
-        h->cb_active--;
-        return;
-    }
-    h->cb_wait.front()->lead = true; // (stays queued: it collects its batch itself)
-    h->cb_cv.notify_all();
-}
-
-// One or two callers search at once.  A caller that arrives while two searches are on the device queues; when one of them
-// ends, the first in the queue takes every queued request with its k (at most kCombineBatch queries) and answers them with ONE
-// batched search -- a batch's results are the single searches' results bit for bit, so nobody can tell except by the clock.
-static int combined_search(lb_gpu_index *h, int64_t nq, const float *queries, int k, float *dist, int64_t *labels)
-{
-    HostReq me{queries, nq, dist, labels, k};
-    HostReq *batch[kCombineBatch]; // (every request holds at least one query)
-    int nb = 0;
-    {
-        std::unique_lock<std::mutex> lk(h->cb_mu);
-        if (h->cb_active < kCombineLanes) {
-            h->cb_active++;
-        } else {
-            try {
-                h->cb_wait.push_back(&me);
-            } catch (...) { // (out of memory: search alone, beside whoever holds the device)
-                lk.unlock();
-                HostReq *one = &me;
-                return host_search_multi(h, &one, 1, k, nullptr);
-            }
-            h->cb_cv.wait(lk, [&] { return me.done || me.lead; });
-            if (me.done) return me.rc;
-            int64_t total = nq;
-            for (auto it = h->cb_wait.begin(); it != h->cb_wait.end();) {
-                HostReq *r = *it;
-                if (r == &me) {
-                    it = h->cb_wait.erase(it);
-                } else if (r->k == k && total + r->nq <= kCombineBatch) {
-                    batch[nb++] = r;
-                    total += r->nq;
-                    it = h->cb_wait.erase(it);
-                } else {
-                    ++it;
-                }
-            }
-        }
-    }
-    batch[nb++] = &me;
-    const int rc = host_search_multi(h, batch, nb, k, nullptr);
-    if (nb > 1) {
-        h->cb_batches.fetch_add(1);
-        h->cb_requests.fetch_add((int64_t)nb);
-        std::lock_guard<std::mutex> g(h->cb_mu);
-        for (int i = 0; i + 1 < nb; i++) {
-            batch[i]->rc = rc;
-            batch[i]->done = true;
-        }
-        h->cb_cv.notify_all();
-    }
-    combine_pass_on(h);
-    return rc;
-}
-
 int lb_gpu_index_search_ctx(lb_gpu_index *h, int64_t nq, const float *queries, int k, float *dist, int64_t *labels,
                             const lb_cancel *ctx)
 {
@@ -1972,8 +1878,9 @@ int lb_gpu_index_search_ctx(lb_gpu_index *h, int64_t nq, const float *queries, i
         if (h->closed) { h->set_error("index is closed"); return LB_ERR_CLOSED; }
     }
     // (a call with a cancellation context is searched on its own: its deadline is not its neighbours')
-    if (!ctx && nq <= kCombineMaxNq && k <= LB_MAX_K && h->cb_on.load() != 0) return combined_search(h, nq, queries, k, dist, labels);
     HostReq me{queries, nq, dist, labels, k};
+    if (!ctx && nq <= SearchCombiner::kMaxNq && k <= LB_MAX_K && h->combiner.on.load() != 0)
+        return h->combiner.search(me, [h](HostReq *const *reqs, int n, int kk) { return host_search_multi(h, reqs, n, kk, nullptr); });
     HostReq *one = &me;
     return host_search_multi(h, &one, 1, k, ctx);
 }
@@ -1981,15 +1888,15 @@ int lb_gpu_index_search_ctx(lb_gpu_index *h, int64_t nq, const float *queries, i
 int lb_gpu_index_set_search_combining(lb_gpu_index *h, int enable)
 {
     if (!h) return LB_ERR_INVALID_ARG;
-    h->cb_on.store(enable ? 1 : 0);
+    h->combiner.on.store(enable ? 1 : 0);
     return LB_OK;
 }
 
 int lb_gpu_index_combining_stats(const lb_gpu_index *h, int64_t out[2])
 {
     if (!h || !out) return LB_ERR_INVALID_ARG;
-    out[0] = h->cb_batches.load();
-    out[1] = h->cb_requests.load();
+    out[0] = h->combiner.batches.load();
+    out[1] = h->combiner.requests.load();
     return LB_OK;
 }
 

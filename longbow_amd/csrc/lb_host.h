@@ -10,8 +10,10 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstddef>
 #include <cstdint>
+#include <deque>
 #include <mutex>
 #include <vector>
 
@@ -180,6 +182,99 @@ inline void ctx_check(const lb_cancel *c)
     const int st = ctx_state(c);
     if (st) throw CtxErr{st};
 }
+
+// ---- combining of concurrent host-pointer searches (lb_gpu_index_search, lb_gpu_pq_search) --------------------------------
+// The reference's gpu.Index.Search is ONE query per call, from many goroutines (internal/gpu/faiss_gpu.go:108-145).  Served as
+// they come, T overlapping calls stream the corpus T times.  Instead: one or two callers search at once; a caller that arrives
+// while kLanes searches are on the device queues, and when one of them ends the first in the queue answers everybody who queued
+// with its k by ONE batched search (at most kBatch queries), then hands the device on.  A batch's lists are the single searches'
+// lists bit for bit, so nobody can tell except by the clock.  No allocation after the enqueue, nothing thrown.
+struct HostReq {
+    const float *q;
+    int64_t nq;
+    float *dist;
+    int64_t *labels;
+    int k;
+    int rc = 0;
+    bool done = false; // served by another caller's batch
+    bool lead = false; // promoted: run the next batch (its own request included)
+};
+
+class SearchCombiner {
+  public:
+    // requests of at most kMaxNq queries take part; a combined batch holds at most kBatch queries
+    static constexpr int64_t kMaxNq = 16, kBatch = 256;
+    // Two searches at a time: one's host work (staging, copies, wake-up: ~80 us around a 0.3 ms search) runs under the other's
+    // device work, and two callers alone are served as without combining.
+    static constexpr int kLanes = 2;
+    std::atomic<int> on{1};
+    std::atomic<int64_t> batches{0}, requests{0}; // combined batches run / requests served by them
+
+    // run(reqs, n, k) -> rc searches n requests with the same k as one device batch and fills every request's buffers
+    template <typename Run>
+    int search(HostReq &me, Run &&run)
+    {
+        HostReq *batch[kBatch]; // (every request holds at least one query)
+        int nb = 0;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            if (active_ < kLanes) {
+                active_++;
+            } else {
+                try {
+                    wait_.push_back(&me);
+                } catch (...) { // (out of memory: search alone, beside whoever holds the device)
+                    lk.unlock();
+                    HostReq *one = &me;
+                    return run(&one, 1, me.k);
+                }
+                cv_.wait(lk, [&] { return me.done || me.lead; });
+                if (me.done) return me.rc;
+                int64_t total = me.nq;
+                for (auto it = wait_.begin(); it != wait_.end();) {
+                    HostReq *r = *it;
+                    if (r == &me) {
+                        it = wait_.erase(it);
+                    } else if (r->k == me.k && total + r->nq <= kBatch) {
+                        batch[nb++] = r;
+                        total += r->nq;
+                        it = wait_.erase(it);
+                    } else {
+                        ++it;
+                    }
+                }
+            }
+        }
+        batch[nb++] = &me;
+        const int rc = run(batch, nb, me.k);
+        if (nb > 1) {
+            batches.fetch_add(1);
+            requests.fetch_add((int64_t)nb);
+            std::lock_guard<std::mutex> g(mu_);
+            for (int i = 0; i + 1 < nb; i++) {
+                batch[i]->rc = rc;
+                batch[i]->done = true;
+            }
+            cv_.notify_all();
+        }
+        { // hand the device to the next waiting caller, or mark the lane free
+            std::lock_guard<std::mutex> g(mu_);
+            if (wait_.empty()) {
+                active_--;
+            } else {
+                wait_.front()->lead = true; // (stays queued: it collects its batch itself)
+                cv_.notify_all();
+            }
+        }
+        return rc;
+    }
+
+  private:
+    std::mutex mu_;
+    std::condition_variable cv_;
+    int active_ = 0; // searches of this kind on the device right now (at most kLanes)
+    std::deque<HostReq *> wait_;
+};
 
 inline bool device_ok(int device)
 {

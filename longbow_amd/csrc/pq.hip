@@ -51,6 +51,7 @@ struct lb_gpu_pq {
     std::atomic<int> profiling{0};
     std::atomic<int> prefilter{1}; // 0 = exact f32-table pass only (lb_gpu_pq_set_prefilter; both are exact)
     std::atomic<int> pair_pass{1}; // 0 = one query per pass over the codes even in batches (A/B, diagnostic build)
+    SearchCombiner combiner;       // concurrent host-pointer searches of a few queries each are combined (lb_host.h)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float prof_ms[2] = {0.f, 0.f};
     void set_error(const char *fmt, ...)
@@ -690,27 +691,79 @@ int lb_gpu_pq_search(lb_gpu_pq *p, int64_t nq, const float *queries, int k, floa
     return lb_gpu_pq_search_ctx(p, nq, queries, k, dist, labels, nullptr);
 }
 
-int lb_gpu_pq_search_ctx(lb_gpu_pq *p, int64_t nq, const float *queries, int k, float *dist, int64_t *labels,
-                         const lb_cancel *ctx)
+// Host-pointer search of one or several requests with the same k as ONE device batch (two queries share a pass over the
+// codes): borrowed host buffers -> pooled pinned slab -> HBM, results back through the slab -- small ones (the latency path)
+// written into it by the last kernel itself.
+static int pq_host_search_multi(lb_gpu_pq *p, HostReq *const *reqs, int nreq, int k, const lb_cancel *ctx)
 {
-    if (!p || nq < 0 || k <= 0 || (nq > 0 && (!queries || !dist || !labels))) return LB_ERR_INVALID_ARG;
-    if (nq == 0) return LB_OK;
+    int64_t nq = 0;
+    for (int i = 0; i < nreq; i++) nq += reqs[i]->nq;
     if (k > 4096) { p->set_error("k=%d exceeds the supported maximum 4096", k); return LB_ERR_UNSUPPORTED; }
     if (nq > 65536) { p->set_error("nq=%lld exceeds 65536 queries per call", (long long)nq); return LB_ERR_UNSUPPORTED; }
     int rc = LB_OK;
     try {
         LBP_HIP(hipSetDevice(p->device));
-        Lease dq(p->device, (size_t)nq * p->dims * 4), dd(p->device, (size_t)nq * k * 4), dl(p->device, (size_t)nq * k * 8);
-        LBP_HIP(hipMemcpy(dq.p, queries, (size_t)nq * p->dims * 4, hipMemcpyHostToDevice));
-        rc = lb_gpu_pq_search_device_ctx(p, nq, dq.as<float>(), k, dd.as<float>(), dl.as<int64_t>(), nullptr, ctx);
+        const size_t qb = (size_t)nq * p->dims * 4, db = (((size_t)nq * k * 4) + 15) & ~(size_t)15, lbb = (size_t)nq * k * 8;
+        const size_t doff = (qb + 15) & ~(size_t)15, loff = doff + db, total = loff + lbb;
+        const bool direct = db + lbb <= ((size_t)64 << 10);
+        Lease hs(p->device, total, /*pinned=*/true), dq(p->device, direct ? qb : total);
+        char *hb = hs.as<char>(), *dbuf = dq.as<char>();
+        size_t off = 0;
+        for (int i = 0; i < nreq; i++) {
+            const size_t b = (size_t)reqs[i]->nq * p->dims * 4;
+            std::memcpy(hb + off, reqs[i]->q, b);
+            off += b;
+        }
+        LBP_HIP(hipMemcpy(dbuf, hb, qb, hipMemcpyHostToDevice));
+        char *obuf = direct ? hb : dbuf;
+        rc = lb_gpu_pq_search_device_ctx(p, nq, reinterpret_cast<const float *>(dbuf), k, reinterpret_cast<float *>(obuf + doff),
+                                         reinterpret_cast<int64_t *>(obuf + loff), nullptr, ctx);
         if (rc == LB_OK) {
-            LBP_HIP(hipMemcpy(dist, dd.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
-            LBP_HIP(hipMemcpy(labels, dl.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost));
+            if (!direct) LBP_HIP(hipMemcpy(hb + doff, dbuf + doff, db + lbb, hipMemcpyDeviceToHost));
+            size_t row = 0;
+            for (int i = 0; i < nreq; i++) {
+                const size_t n = (size_t)reqs[i]->nq * k;
+                std::memcpy(reqs[i]->dist, hb + doff + row * 4, n * 4);
+                std::memcpy(reqs[i]->labels, hb + loff + row * 8, n * 8);
+                row += n;
+            }
         }
     } catch (const HipErrP &e) {
         rc = pq_fail(p, e);
+    } catch (...) {
+        p->set_error("internal error (exception)");
+        rc = LB_ERR_INTERNAL;
     }
     return rc;
+}
+
+int lb_gpu_pq_search_ctx(lb_gpu_pq *p, int64_t nq, const float *queries, int k, float *dist, int64_t *labels,
+                         const lb_cancel *ctx)
+{
+    if (!p || nq < 0 || k <= 0 || (nq > 0 && (!queries || !dist || !labels))) return LB_ERR_INVALID_ARG;
+    if (nq == 0) return LB_OK;
+    HostReq me{queries, nq, dist, labels, k};
+    // (concurrent calls of a few queries each are answered together: two queries share a pass over the codes, 1.48x the
+    // queries per second of one call after the other; a call with a cancellation context is searched on its own)
+    if (!ctx && nq <= SearchCombiner::kMaxNq && k <= 4096 && p->combiner.on.load() != 0)
+        return p->combiner.search(me, [p](HostReq *const *reqs, int n, int kk) { return pq_host_search_multi(p, reqs, n, kk, nullptr); });
+    HostReq *one = &me;
+    return pq_host_search_multi(p, &one, 1, k, ctx);
+}
+
+int lb_gpu_pq_set_search_combining(lb_gpu_pq *p, int enable)
+{
+    if (!p) return LB_ERR_INVALID_ARG;
+    p->combiner.on.store(enable ? 1 : 0);
+    return LB_OK;
+}
+
+int lb_gpu_pq_combining_stats(const lb_gpu_pq *p, int64_t out[2])
+{
+    if (!p || !out) return LB_ERR_INVALID_ARG;
+    out[0] = p->combiner.batches.load();
+    out[1] = p->combiner.requests.load();
+    return LB_OK;
 }
 
 } // extern "C"

@@ -128,6 +128,19 @@ class PQEncoder:
         """True (default): byte-table prefilter + exact survivors; False: exact f32-table pass only.  Same results."""
         _lib.check(self._lib.lb_gpu_pq_set_prefilter(self._h, 1 if on else 0), self._h, pq=True, lib=self._lib)
 
+    def set_search_combining(self, enable):
+        """1 (default): concurrent Search calls of a few queries each are answered by one batch (pairs of queries share a pass
+        over the codes); 0: every call on its own.  Same results."""
+        _lib.check(self._lib.lb_gpu_pq_set_search_combining(self._h, 1 if enable else 0), self._h, pq=True, lib=self._lib)
+
+    @property
+    def combining_stats(self):
+        """(combined batches run, requests they answered)"""
+        import ctypes as C
+        out = (C.c_int64 * 2)()
+        _lib.check(self._lib.lb_gpu_pq_combining_stats(self._h, out), self._h, pq=True, lib=self._lib)
+        return int(out[0]), int(out[1])
+
     def Search(self, queries, k, ctx=None):
         queries = np.ascontiguousarray(queries, np.float32)
         if queries.ndim == 1:

@@ -252,3 +252,44 @@ def test_two_queries_per_code_pass_equal_single_passes(oracle):
     lab1, dist1 = enc.Search(Qb[1:2], k)
     assert np.array_equal(lab[1], lab1[0]) and np.array_equal(dist[1], dist1[0], equal_nan=True)
     enc.Close()
+
+
+def test_concurrent_adc_searches_are_combined_and_identical(oracle):
+    """single-query ADC searches from several host threads: calls that overlap are answered by one batch (pairs of queries
+    share a pass over the codes) -- every caller gets exactly its own single search's lists; counters move; off = untouched"""
+    gpu_or_skip()
+    import threading
+    from longbow_amd import pq
+    rng = np.random.default_rng(321)
+    M, dims, n, k = 16, 128, 2_000_000, 20
+    cb = rng.random((M, 256, dims // M), dtype=F)
+    codes = rng.integers(0, 256, (n, M), dtype=np.uint8)
+    enc = pq.PQEncoder(pq.serialize_codebooks(cb))
+    enc.add_codes(codes)
+    Q = rng.random((24, dims), dtype=F)
+    enc.set_search_combining(False)
+    want = [enc.Search(Q[i], k) for i in range(len(Q))]
+    d = oracle.adc_batch(oracle.build_adc_table(cb, Q[0]), codes)
+    oi, od, _ = oracle.topk_canonical(d, k)
+    assert np.array_equal(want[0][0][0], oi) and np.array_equal(want[0][1][0], od)
+    assert enc.combining_stats == (0, 0)
+    enc.set_search_combining(True)
+    errors = []
+
+    def caller(t):
+        try:
+            for rep in range(12):
+                for i in range(t, len(Q), 6):
+                    lab, dist = enc.Search(Q[i], k)
+                    if not (np.array_equal(lab, want[i][0]) and np.array_equal(dist, want[i][1])):
+                        errors.append(f"thread {t} query {i} rep {rep}")
+        except Exception as e:  # noqa: BLE001
+            errors.append(f"thread {t}: {type(e).__name__}: {e}")
+
+    ths = [threading.Thread(target=caller, args=(t,)) for t in range(6)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errors, errors[:5]
+    batches, requests = enc.combining_stats
+    assert batches > 0 and requests >= 2 * batches, (batches, requests)
+    enc.Close()
