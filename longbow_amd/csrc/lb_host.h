@@ -204,8 +204,8 @@ class SearchCombiner {
   public:
     // requests of at most kMaxNq queries take part; a combined batch holds at most kBatch queries
     static constexpr int64_t kMaxNq = 16, kBatch = 256;
-    // Two searches at a time: one's host work (staging, copies, wake-up: ~80 us around a 0.3 ms search) runs under the other's
-    // device work, and two callers alone are served as without combining.
+    // Two searches at a time while nothing is queued: one's host work (staging, copies, wake-up: ~80 us around a 0.3 ms search)
+    // runs under the other's device work, and two callers alone are served as without combining.
     static constexpr int kLanes = 2;
     std::atomic<int> on{1};
     std::atomic<int64_t> batches{0}, requests{0}; // combined batches run / requests served by them
@@ -218,7 +218,10 @@ class SearchCombiner {
         int nb = 0;
         {
             std::unique_lock<std::mutex> lk(mu_);
-            if (active_ < kLanes) {
+            // (two lanes while callers come one or two at a time; ONE under load: two batches side by side would halve each
+            // other's share of the HBM stream, one batch of everybody does not)
+            const int lanes = (recent_ > 1 || !wait_.empty()) ? 1 : kLanes;
+            if (!gathering_ && active_ < lanes) {
                 active_++;
             } else {
                 try {
@@ -228,51 +231,74 @@ class SearchCombiner {
                     HostReq *one = &me;
                     return run(&one, 1, me.k);
                 }
+                if (gathering_) cv_.notify_all(); // (the gathering caller counts the queue)
                 cv_.wait(lk, [&] { return me.done || me.lead; });
                 if (me.done) return me.rc;
-                int64_t total = me.nq;
-                for (auto it = wait_.begin(); it != wait_.end();) {
-                    HostReq *r = *it;
-                    if (r == &me) {
-                        it = wait_.erase(it);
-                    } else if (r->k == me.k && total + r->nq <= kBatch) {
-                        batch[nb++] = r;
-                        total += r->nq;
-                        it = wait_.erase(it);
-                    } else {
-                        ++it;
-                    }
-                }
+                for (auto it = wait_.begin(); it != wait_.end(); ++it) // (promoted: the lane is mine; leave the queue)
+                    if (*it == &me) { wait_.erase(it); break; }
             }
+            // Under load the callers of a combined batch come back together: the first of them would search alone and the
+            // rest would wait out its whole search (8 callers: batches of 1 and 7 in turn, half the possible rate).  After a
+            // combined batch the caller that gets the lane therefore gives the others a moment -- until as many have queued as
+            // the last batch held, at most kGatherUs -- and takes them along.  A lone caller (the last batch was its own)
+            // never waits.
+            if (recent_ > 1 && (int)wait_.size() < recent_ - 1) {
+                gathering_ = true;
+                const int want = recent_ - 1;
+                cv_.wait_for(lk, std::chrono::microseconds(kGatherUs), [&] { return (int)wait_.size() >= want; });
+                gathering_ = false;
+            }
+            nb = take_same_k(me, batch);
         }
         batch[nb++] = &me;
         const int rc = run(batch, nb, me.k);
         if (nb > 1) {
             batches.fetch_add(1);
             requests.fetch_add((int64_t)nb);
+        }
+        {
             std::lock_guard<std::mutex> g(mu_);
+            recent_ = nb;
             for (int i = 0; i + 1 < nb; i++) {
                 batch[i]->rc = rc;
                 batch[i]->done = true;
             }
-            cv_.notify_all();
-        }
-        { // hand the device to the next waiting caller, or mark the lane free
-            std::lock_guard<std::mutex> g(mu_);
-            if (wait_.empty()) {
-                active_--;
-            } else {
-                wait_.front()->lead = true; // (stays queued: it collects its batch itself)
-                cv_.notify_all();
-            }
+            // hand the device to the next waiting caller, or mark the lane free
+            HostReq *next = nullptr;
+            for (HostReq *r : wait_)
+                if (!r->done && !r->lead) { next = r; break; }
+            if (next && active_ > 1) next = nullptr; // (callers are queueing: one lane -- the other search's caller serves them)
+            if (next) next->lead = true; // (stays queued until it wakes; the lane is its)
+            else active_--;
+            if (nb > 1 || next) cv_.notify_all();
         }
         return rc;
     }
 
   private:
+    static constexpr int kGatherUs = 50;
+    // every queued request with me's k (at most kBatch queries with me's) leaves the queue for me's batch
+    int take_same_k(HostReq &me, HostReq **batch)
+    {
+        int nb = 0;
+        int64_t total = me.nq;
+        for (auto it = wait_.begin(); it != wait_.end();) {
+            HostReq *r = *it;
+            if (!r->lead && r->k == me.k && total + r->nq <= kBatch) {
+                batch[nb++] = r;
+                total += r->nq;
+                it = wait_.erase(it);
+            } else {
+                ++it;
+            }
+        }
+        return nb;
+    }
     std::mutex mu_;
     std::condition_variable cv_;
-    int active_ = 0; // searches of this kind on the device right now (at most kLanes)
+    int active_ = 0;          // searches of this kind on the device right now (at most kLanes)
+    int recent_ = 1;          // requests in the batch that ended last
+    bool gathering_ = false; // a caller with a free lane is gathering the others of the last batch
     std::deque<HostReq *> wait_;
 };
 
