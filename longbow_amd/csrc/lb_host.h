@@ -198,6 +198,8 @@ struct HostReq {
     int rc = 0;
     bool done = false; // served by another caller's batch
     bool lead = false; // promoted: run the next batch (its own request included)
+    std::condition_variable cv; // this caller's own wake-up (no herd: a finishing search wakes its batch and one successor)
+    HostReq(const float *q_, int64_t nq_, float *dist_, int64_t *labels_, int k_) : q(q_), nq(nq_), dist(dist_), labels(labels_), k(k_) {}
 };
 
 class SearchCombiner {
@@ -221,7 +223,7 @@ class SearchCombiner {
             // (two lanes while callers come one or two at a time; ONE under load: two batches side by side would halve each
             // other's share of the HBM stream, one batch of everybody does not)
             const int lanes = (recent_ > 1 || !wait_.empty()) ? 1 : kLanes;
-            if (!gathering_ && active_ < lanes) {
+            if (!gatherer_ && active_ < lanes) {
                 active_++;
             } else {
                 try {
@@ -231,8 +233,8 @@ class SearchCombiner {
                     HostReq *one = &me;
                     return run(&one, 1, me.k);
                 }
-                if (gathering_) cv_.notify_all(); // (the gathering caller counts the queue)
-                cv_.wait(lk, [&] { return me.done || me.lead; });
+                if (gatherer_) gatherer_->cv.notify_one(); // (the gathering caller counts the queue)
+                me.cv.wait(lk, [&] { return me.done || me.lead; });
                 if (me.done) return me.rc;
                 for (auto it = wait_.begin(); it != wait_.end(); ++it) // (promoted: the lane is mine; leave the queue)
                     if (*it == &me) { wait_.erase(it); break; }
@@ -243,10 +245,10 @@ class SearchCombiner {
             // the last batch held, at most kGatherUs -- and takes them along.  A lone caller (the last batch was its own)
             // never waits.
             if (recent_ > 1 && (int)wait_.size() < recent_ - 1) {
-                gathering_ = true;
+                gatherer_ = &me;
                 const int want = recent_ - 1;
-                cv_.wait_for(lk, std::chrono::microseconds(kGatherUs), [&] { return (int)wait_.size() >= want; });
-                gathering_ = false;
+                me.cv.wait_for(lk, std::chrono::microseconds(kGatherUs), [&] { return (int)wait_.size() >= want; });
+                if (gatherer_ == &me) gatherer_ = nullptr;
             }
             nb = take_same_k(me, batch);
         }
@@ -262,15 +264,19 @@ class SearchCombiner {
             for (int i = 0; i + 1 < nb; i++) {
                 batch[i]->rc = rc;
                 batch[i]->done = true;
+                batch[i]->cv.notify_one(); // (the waiter re-checks under the lock we hold: it cannot be gone before we let go)
             }
             // hand the device to the next waiting caller, or mark the lane free
             HostReq *next = nullptr;
             for (HostReq *r : wait_)
                 if (!r->done && !r->lead) { next = r; break; }
             if (next && active_ > 1) next = nullptr; // (callers are queueing: one lane -- the other search's caller serves them)
-            if (next) next->lead = true; // (stays queued until it wakes; the lane is its)
-            else active_--;
-            if (nb > 1 || next) cv_.notify_all();
+            if (next) {
+                next->lead = true; // (stays queued until it wakes; the lane is its)
+                next->cv.notify_one();
+            } else {
+                active_--;
+            }
         }
         return rc;
     }
@@ -295,10 +301,9 @@ class SearchCombiner {
         return nb;
     }
     std::mutex mu_;
-    std::condition_variable cv_;
-    int active_ = 0;          // searches of this kind on the device right now (at most kLanes)
-    int recent_ = 1;          // requests in the batch that ended last
-    bool gathering_ = false; // a caller with a free lane is gathering the others of the last batch
+    int active_ = 0;              // searches of this kind on the device right now (at most kLanes)
+    int recent_ = 1;              // requests in the batch that ended last
+    HostReq *gatherer_ = nullptr; // the caller that holds the lane and is gathering the others of the last batch
     std::deque<HostReq *> wait_;
 };
 
