@@ -235,11 +235,13 @@ class CommSearcher:
         self._cb = None
         if transport == "rccl":
             uid = (C.c_char * 128)()
-            if rank == 0:
-                _lib.check(lib.lb_gpu_comm_get_unique_id(uid))
-            box = [bytes(uid)]
+            rc0 = lib.lb_gpu_comm_get_unique_id(uid) if rank == 0 else 0
+            # (rank 0 takes part in the broadcast even when it has no id to give: its peers are already waiting in it)
+            box = [bytes(uid) if rc0 == 0 else b""]
             if world_size > 1:
                 dist.broadcast_object_list(box, src=0, group=group)
+            if len(box[0]) != 128:
+                raise _lib.LongbowGPUError(rc0 or 7, "rank 0 could not create the RCCL unique id (lb_gpu_comm_get_unique_id)")
             buf = C.create_string_buffer(box[0], 128)
             h = lib.lb_gpu_comm_init_rank(device_index, world_size, rank, buf, C.byref(st))
         elif transport == "host":
