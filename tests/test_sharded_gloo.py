@@ -71,3 +71,49 @@ def test_two_rank_sharded_search_equals_global(metric, oracle):
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
     assert sum(n for _, _, n in res) == 4000
+
+
+class _NoRcclLib:
+    """stand-in for liblongbow_gpu.so on a host where RCCL cannot be loaded: the id call fails, init must never be reached"""
+
+    def lb_gpu_comm_get_unique_id(self, buf):
+        return 6  # LB_ERR_UNSUPPORTED
+
+    def lb_gpu_comm_init_rank(self, *a):
+        raise AssertionError("init_rank reached without a unique id")
+
+
+def _uid_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from longbow_amd import _lib
+    from longbow_amd.sharded import CommSearcher
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        try:
+            CommSearcher(None, rank, world, transport="rccl", lib=_NoRcclLib())
+            raised = False
+        except _lib.LongbowGPUError:
+            raised = True
+        # the ranks are still in step: the agreement all-reduce bench.py's make_searcher does next goes through
+        ok = torch.tensor([0 if raised else 1])
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        q.put((rank, raised, int(ok.item())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_unique_id_failure_on_rank0_is_raised_on_every_rank_without_a_hang():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_uid_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True, 0), (1, True, 0)], res
