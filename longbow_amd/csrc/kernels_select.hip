@@ -463,8 +463,14 @@ __device__ __forceinline__ void rerank_finish(const RerankArgs &a, int qi, int t
             for (int i = 0; i < D; i++) nq2 += sq[i] * sq[i];
             const float nqn = sqrtf(nq2) * 1.000001f;
             // d^2 space: key error go*|x|^2 + 2*ga*|q||x| for each of c_last and the outsider;
-            // exact side relative go on each of the two d^2 values
-            T = w * (1.0f - 3.0f * go) - 2.2f * (go * xmax2 + 2.0f * ga * nqn * xmax);
+            // exact side relative go on each of the two d^2 values.
+            // The key errors only have to cover rows up to the norm R = |q| + d(c_last): a row beyond it is farther than
+            // c_last whatever its key says (d(y) >= |y| - |q| > sqrt(w), and its computed d^2 stays above w >= T through the
+            // relative slack below), and c_last itself lies inside (|c| <= |q| + d(c)).  With a few rows of a much larger norm
+            // than the rest -- unnormalised data -- the corpus maximum would inflate the bound for every query.
+            float xe = xmax;
+            if (w >= 0.0f && w < FLT_MAX) xe = fminf(xmax, (nqn * 1.001f + sqrtf(w) * (1.001f + 2.0f * go)) * 1.001f);
+            T = w * (1.0f - 3.0f * go) - 2.2f * (go * xe * xe + 2.0f * ga * nqn * xe);
         } else if (METRIC == METRIC_COS) {
             T = w - 2.2f * (ga + 2.8f * go);
             skip = (na == 0.0f); // all distances are exactly 1.0; selection by row is exact

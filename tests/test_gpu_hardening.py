@@ -313,3 +313,30 @@ def test_a_failing_rank_still_takes_part_in_the_exchange():
     assert c1 == 7 and c0 == 7, res                  # LB_ERR_INTERNAL on the failing rank AND on its peer
     assert "rank 1" in m0, m0
     assert same0 and same1
+
+
+def test_l2_proof_is_not_inflated_by_a_few_rows_of_a_much_larger_norm(oracle):
+    """unnormalised data: five rows 4096 times longer than the rest.  The containment bound of the L2 metric covers key errors
+    only up to the norm |q| + d(c_last) (a longer row is farther than c_last by the triangle inequality), so the corpus'
+    maximum norm no longer sends every query to the exact scan; the answers are the oracle's either way."""
+    gpu_or_skip()
+    rng = np.random.default_rng(5)
+    n, d, k = 300_000, 128, 10
+    X = rng.random((n, d), dtype=F)
+    X[rng.integers(0, n, 5)] *= F(4096.0)
+    Q = rng.random((64, d), dtype=F)
+    idx = new_index(d, 0)
+    idx.Add(None, X)
+    for nq in (8, 64):
+        lab, dist = idx.SearchBatch(Q[:nq], k)
+        oi, od = oracle.search_batch(0, Q[:nq], X, k, nthreads=8)
+        assert_same(lab, dist, oi, od, f"nq={nq}")
+        assert idx.last_fallbacks == 0, (nq, idx.last_fallbacks)
+    # a query that IS one of the long rows: its neighbours are the other long rows, far away -- still exact
+    long_rows = np.argsort(-np.einsum("ij,ij->i", X, X))[:5]
+    Ql = np.ascontiguousarray(X[long_rows[:2]] * F(0.999))
+    Qm = np.concatenate([Ql, Q[:6]])
+    lab, dist = idx.SearchBatch(Qm, k)
+    oi, od = oracle.search_batch(0, Qm, X, k, nthreads=8)
+    assert_same(lab, dist, oi, od, "long-row queries")
+    idx.Close()
