@@ -340,3 +340,54 @@ def test_l2_proof_is_not_inflated_by_a_few_rows_of_a_much_larger_norm(oracle):
     oi, od = oracle.search_batch(0, Qm, X, k, nthreads=8)
     assert_same(lab, dist, oi, od, "long-row queries")
     idx.Close()
+
+
+def test_searches_during_adds_see_a_whole_prefix_of_the_corpus(oracle):
+    """the reference's gpu.Index serialises Add and Search with one mutex (internal/gpu/faiss_gpu.go:76-145): a search that runs
+    while another goroutine adds rows answers for the corpus as it stood between two Adds, never for half a chunk.  One writer
+    adds 24 chunks while three readers search; every answer must equal the oracle's over SOME whole prefix whose length lies
+    between the index size read before and after the call."""
+    gpu_or_skip()
+    rng = np.random.default_rng(77)
+    d, k, chunk, nchunks = 32, 10, 6000, 24
+    X = rng.random((chunk * nchunks, d), dtype=F)
+    Q = rng.random((5, d), dtype=F)
+    prefix = {m: oracle.search_batch(0, Q, X[:m * chunk], k, nthreads=8) for m in range(1, nchunks + 1)}
+    idx = new_index(d, 0)
+    idx.Add(None, X[:chunk])
+    errs, seen = [], set()
+    stop = threading.Event()
+
+    def reader(t):
+        try:
+            while not stop.is_set():
+                nq = (1, 3, 5)[t]
+                n0 = idx.ntotal
+                lab, dist = idx.SearchBatch(Q[:nq], k)
+                n1 = idx.ntotal
+                ok = False
+                for m in range(n0 // chunk, n1 // chunk + 1):
+                    oi, od = prefix[m]
+                    if np.array_equal(lab, oi[:nq]) and np.array_equal(dist, od[:nq]):
+                        ok = True
+                        seen.add(m)
+                        break
+                if not ok:
+                    errs.append((t, n0, n1, lab[0, :3].tolist()))
+                    return
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    ths = [threading.Thread(target=reader, args=(t,)) for t in range(3)]
+    [t.start() for t in ths]
+    for m in range(1, nchunks):
+        idx.Add(None, X[m * chunk:(m + 1) * chunk])
+        time.sleep(0.002)
+    stop.set()
+    [t.join() for t in ths]
+    assert not errs, errs[:3]
+    assert idx.ntotal == chunk * nchunks
+    lab, dist = idx.SearchBatch(Q, k)
+    assert_same(lab, dist, *prefix[nchunks], "after the last Add")
+    assert len(seen) >= 2, seen  # the readers did overlap the writer
+    idx.Close()
