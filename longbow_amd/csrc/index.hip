@@ -847,6 +847,9 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     if (!light_sample && !fused) launch_init_cand(w->cs, nullptr, nq, s);
     if (metric == LB_METRIC_COSINE && !norm_riders) launch_query_norms(order, d_q, nullptr, nq, h->dim, w->d_qna, s);
     static const bool sample_narrow = lb_tunable("LB_TALL_SAMPLE_NARROW", 1) != 0;
+    // (fp16 route, several 256-query tiles: the sample goes through the fp16 kernel itself -- 32 row tiles x nq/256 workgroups
+    // against nq/64 x 64 of the narrow tile; 1024 queries: 1.94 -> 1.88 ms, 512: 1.015 -> 1.00; tools/probe/sample_route_probe.py)
+    static const int sample_narrow_maxq = lb_tunable("LB_TALL_SAMPLE_NARROW_MAXQ", 384);
     auto candidates = [&](int64_t b, int64_t e, const uint32_t *rowmap, bool boot) {
         if (w->ctx && !boot) LB_HIP(hipStreamSynchronize(s)); // a cancellable call waits for the work in front of every corpus pass
         ctx_check(w->ctx);
@@ -857,7 +860,8 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         else if (use_tall16 && h->dim % 32 != 0 && (rowmap || mask))
             // the sample of a search over the fp16 copy when the dimension is not a multiple of 32: the f32 tile takes any
             launch_gemm_filter(metric, h->d_X, h->d_norm2, h->d_rnorm, b, e, h->dim, d_q, nq, mask, rowmap, w->cs, boot, 0, s);
-        else if (use_tall && boot && (wsplit == 2 || wsplit == 3) && sample_narrow && h->dim % 32 == 0)
+        else if (use_tall && boot && (wsplit == 2 || wsplit == 3) && sample_narrow && h->dim % 32 == 0 &&
+                 !(use_tall16 && nq > sample_narrow_maxq))
             // the 8192-row sample of a tall-tile search: the 64-query tile of the narrow kernel (same contraction, f32
             // operands) gets through its 24 K-steps of 32 in 31-35 us, the tall tile through its 48 of 16 in 57
             launch_gemm_filter_narrow(metric, h->d_X, h->d_norm2, h->d_rnorm, b, e, h->dim, d_q, nq, mask, rowmap, w->cs,
