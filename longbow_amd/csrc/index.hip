@@ -1556,7 +1556,12 @@ int64_t lb_gpu_index_f16_image_bytes(const lb_gpu_index *h)
     return h && h->d_Xh ? (int64_t)h->xh_cap * ((h->dim + 31) & ~31) * 2 : 0;
 }
 
-int64_t lb_gpu_index_ntotal(const lb_gpu_index *h) { return h ? h->n : 0; }
+int64_t lb_gpu_index_ntotal(const lb_gpu_index *h)
+{
+    if (!h) return 0;
+    std::shared_lock<std::shared_mutex> g(const_cast<lb_gpu_index *>(h)->mu); // (Add commits its rows under the writer lock)
+    return h->n;
+}
 int lb_gpu_index_dim(const lb_gpu_index *h) { return h ? h->dim : 0; }
 int lb_gpu_index_device(const lb_gpu_index *h) { return h ? h->device : -1; }
 

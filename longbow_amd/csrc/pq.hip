@@ -246,7 +246,12 @@ const char *lb_gpu_pq_last_error(const lb_gpu_pq *p)
 
 int lb_gpu_pq_m(const lb_gpu_pq *p) { return p ? p->M : 0; }
 int lb_gpu_pq_dims(const lb_gpu_pq *p) { return p ? p->dims : 0; }
-int64_t lb_gpu_pq_ntotal(const lb_gpu_pq *p) { return p ? p->n : 0; }
+int64_t lb_gpu_pq_ntotal(const lb_gpu_pq *p)
+{
+    if (!p) return 0;
+    std::shared_lock<std::shared_mutex> g(const_cast<lb_gpu_pq *>(p)->mu); // (add_codes / add_vectors commit under the writer lock)
+    return p->n;
+}
 
 int lb_gpu_pq_reserve(lb_gpu_pq *p, int64_t n_total)
 {
