@@ -1553,7 +1553,9 @@ int lb_gpu_index_set_f16_image(lb_gpu_index *h, int mode)
 
 int64_t lb_gpu_index_f16_image_bytes(const lb_gpu_index *h)
 {
-    return h && h->d_Xh ? (int64_t)h->xh_cap * ((h->dim + 31) & ~31) * 2 : 0;
+    if (!h) return 0;
+    std::shared_lock<std::shared_mutex> g(const_cast<lb_gpu_index *>(h)->mu); // (the copy is built and dropped under the writer lock)
+    return h->d_Xh ? (int64_t)h->xh_cap * ((h->dim + 31) & ~31) * 2 : 0;
 }
 
 int64_t lb_gpu_index_ntotal(const lb_gpu_index *h)
