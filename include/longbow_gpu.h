@@ -122,6 +122,8 @@ int64_t lb_gpu_index_f16_image_bytes(const lb_gpu_index *h); /* HBM held by that
  * default; 0 switches it off for the handle.  stats: out[0] = combined batches run, out[1] = requests they answered. */
 int lb_gpu_index_set_search_combining(lb_gpu_index *h, int enable);
 int lb_gpu_index_combining_stats(const lb_gpu_index *h, int64_t out[2]);
+/* rows committed so far; safe beside Add / Search from other threads (read under the handle's reader lock, so it waits out an Add
+ * in progress and never reports half a chunk) */
 int64_t lb_gpu_index_ntotal(const lb_gpu_index *h);
 int lb_gpu_index_dim(const lb_gpu_index *h);
 int lb_gpu_index_device(const lb_gpu_index *h); /* GPUConfig.DeviceID (interface.go:15-19); -1 on NULL */
