@@ -1,0 +1,70 @@
+"""Numeric range of the candidate contractions (f32 MFMA, split-bf16, one fp16 product): corpora whose row norms span many
+binades, a few rows far longer than the rest, sparse rows, a large common offset.  Every candidate mode must return the strict
+mode's lists bit for bit, and the strict mode the oracle's (reference semantics: internal/simd/simd.go:131-163,365-479 through
+BruteForceIndex.SearchVectors, internal/store/adaptive_index.go:159-230).  The long sweep is tools/probe/fuzz_scales.py."""
+import numpy as np
+import pytest
+
+from tests.gpu_util import assert_same, gpu_or_skip, new_index
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+def _corpus(kind, n, d, rng):
+    base = rng.standard_normal((n, d)).astype(F)
+    if kind == "row_binades":
+        X = base * np.exp2(rng.integers(-10, 11, (n, 1))).astype(F)
+    elif kind == "dim_binades":
+        X = base * np.exp2(rng.integers(-6, 7, (1, d))).astype(F)
+    elif kind == "few_long_rows":
+        X = base * F(2.0 ** -6)
+        X[rng.integers(0, n, 3)] *= F(2.0 ** 16)
+    elif kind == "sparse":
+        X = base * (rng.random((n, d)) < 0.05).astype(F)
+    elif kind == "offset":
+        X = base * F(0.01) + F(100.0)
+    else:
+        raise ValueError(kind)
+    return np.ascontiguousarray(X, dtype=F)
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("kind", ["row_binades", "dim_binades", "few_long_rows", "sparse", "offset"])
+def test_every_candidate_mode_equals_the_strict_mode_and_the_oracle(oracle, metric, kind):
+    gpu_or_skip()
+    rng = np.random.default_rng(1000 * metric + sum(kind.encode()))
+    n, d, k = 270_000, 64, 10
+    X = _corpus(kind, n, d, rng)
+    rows = rng.integers(0, n, 130)
+    Q = np.ascontiguousarray(X[rows] + rng.standard_normal((130, d)).astype(F) * F(0.02) * np.abs(X[rows]).mean(1, keepdims=True).astype(F))
+    idx = new_index(d, metric)
+    idx.Add(None, X)
+    idx.set_candidate_mode(0)
+    want = {nq: idx.SearchBatch(Q[:nq], k) for nq in (4, 64, 130)}
+    oi, od = oracle.search_batch(metric, Q[:4], X, k, nthreads=8)
+    assert_same(want[4][0], want[4][1], oi, od, f"strict mode vs oracle, {kind}")
+    for mode in (3, 4, 2, 1):
+        idx.set_candidate_mode(mode)
+        for nq in (4, 64, 130):
+            lab, dist = idx.SearchBatch(Q[:nq], k)
+            assert_same(lab, dist, want[nq][0], want[nq][1], f"mode {mode} nq {nq} {kind} route {idx.last_route}")
+    idx.Close()
+
+
+def test_l2_fast_routes_survive_row_norms_over_twenty_binades(oracle):
+    """the property the L2 proof's norm limit buys (kernels_select.hip rerank_finish): no query of these batches is left to the
+    exact scan although the corpus' largest norm is a million times the typical one"""
+    gpu_or_skip()
+    rng = np.random.default_rng(11)
+    n, d, k = 270_000, 64, 10
+    X = _corpus("row_binades", n, d, rng)
+    rows = rng.integers(0, n, 64)
+    Q = np.ascontiguousarray(X[rows] * F(1.01))
+    idx = new_index(d, 0)
+    idx.Add(None, X)
+    lab, dist = idx.SearchBatch(Q, k)
+    oi, od = oracle.search_batch(0, Q[:6], X, k, nthreads=8)
+    assert_same(lab[:6], dist[:6], oi, od, "row binades")
+    assert idx.last_fallbacks <= 2, idx.last_fallbacks
+    idx.Close()
