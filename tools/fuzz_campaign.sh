@@ -23,6 +23,7 @@ echo "# tools/fuzz_campaign.sh $S $T on $(date -u +%FT%TZ), $(python3 -c 'import
 run fuzz_copy_seed$S python3 tools/probe/fuzz_copy.py $S $T
 run fuzz_copy_seed$((S + 1)) python3 tools/probe/fuzz_copy.py $((S + 1)) $T
 FUZZ_WIDE=1 run fuzz_copy_wide_seed$((S + 2)) python3 tools/probe/fuzz_copy.py $((S + 2)) $T
+run fuzz_scales_seed$((S + 3)) python3 tools/probe/fuzz_scales.py $((S + 3)) $T
 for r in $((S)) $((S + 1)) $((S + 2)); do
     LB_FUZZ_ROUND=$r run pytest_fuzz_round$r python3 -m pytest tests/test_gpu_fuzz.py -q -m gpu -x
 done
