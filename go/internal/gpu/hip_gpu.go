@@ -181,18 +181,26 @@ func (idx *HIPIndex) SearchBatchContext(ctx context.Context, queries []float32, 
 	if cc == nil {
 		return nil, nil, fmt.Errorf("out of memory")
 	}
-	defer C.lb_cancel_free(cc)
 	if dl, ok := ctx.Deadline(); ok {
 		C.lb_cancel_set_deadline_ms(cc, C.int64_t(max(time.Until(dl).Milliseconds(), 0)))
 	}
 	done := make(chan struct{})
-	defer close(done)
+	exited := make(chan struct{})
 	go func() { // fires the library-side flag when the context ends before the call does
+		defer close(exited)
 		select {
 		case <-ctx.Done():
 			C.lb_cancel_fire(cc)
 		case <-done:
 		}
+	}()
+	// The token is freed only after the watcher has LEFT: a caller's `defer cancel()` fires right after this function
+	// returns, the watcher may then pick ctx.Done() over done (select is random when both are ready), and a fire on a
+	// freed token would be a store into freed memory.  One deferred function, in this order: stop, join, free.
+	defer func() {
+		close(done)
+		<-exited
+		C.lb_cancel_free(cc)
 	}()
 	distances := make([]float32, nq*k)
 	labels := make([]int64, nq*k)

@@ -35,6 +35,8 @@ constexpr int kScanMaxQ = 8;          // queries per scan launch (register accum
 constexpr int kGemmMinQ = 17;         // below this the exact scan path is used for everything
 constexpr int kMaxBatch = 4096;       // queries per internal batch (workspace sizing)
 constexpr size_t kStageBytes = 32u << 20; // pinned staging slab (x2)
+constexpr int kFinishSplitMaxQ = 16;      // largest batch the finish launch serves with several workgroups per query
+constexpr uint32_t kFinishSmaxMax = 4096; // most members (rows re-ranked exactly) a query may have
 
 struct Event {
     hipEvent_t a = nullptr, b = nullptr;
@@ -55,7 +57,9 @@ struct Workspace {
     int *d_qsel = nullptr;
     int *d_iota = nullptr;       // [nq_cap] 0,1,2,...: the slot list of "every query", filled once
     uint32_t *d_smap = nullptr;  // [cap] sampled rows of the first pass
-    uint32_t *d_done = nullptr;  // [nq_cap] arrival tickets of the split re-rank (zero between launches)
+    uint32_t *d_done = nullptr;  // [nq_cap] arrival tickets of the finish launch's split form (zero between launches)
+    uint32_t *d_xcnt = nullptr;  // [nq_cap] members handed in per query by that form (zero between launches)
+    void *d_xscratch = nullptr;  // its per-query result blocks (finish_scratch_bytes)
     // fused sample (kernels_gemm_narrow.hip, FUSED): [0] = ticket counter that only grows, [1 ..] = ready epochs per slot
     uint32_t *d_fsync = nullptr;
     uint32_t fs_base = 0, fs_epoch = 0; // host mirror of the ticket counter; last epoch used
@@ -87,6 +91,8 @@ struct Workspace {
         if (d_iota) (void)hipFree(d_iota);
         if (d_smap) (void)hipFree(d_smap);
         if (d_done) (void)hipFree(d_done);
+        if (d_xcnt) (void)hipFree(d_xcnt);
+        if (d_xscratch) (void)hipFree(d_xscratch);
         if (d_fsync) (void)hipFree(d_fsync);
         if (h_fail) (void)hipHostFree(h_fail);
         if (h_flags) (void)hipHostFree(h_flags);
@@ -335,6 +341,9 @@ std::unique_ptr<Workspace> acquire_ws(lb_gpu_index *h, int nq, uint32_t cap)
     LB_HIP(hipMalloc(&w->cs.flags, (size_t)w->nq_cap * sizeof(uint32_t)));
     LB_HIP(hipMalloc(&w->d_done, (size_t)w->nq_cap * sizeof(uint32_t)));
     LB_HIP(hipMemset(w->d_done, 0, (size_t)w->nq_cap * sizeof(uint32_t)));
+    LB_HIP(hipMalloc(&w->d_xcnt, (size_t)w->nq_cap * sizeof(uint32_t)));
+    LB_HIP(hipMemset(w->d_xcnt, 0, (size_t)w->nq_cap * sizeof(uint32_t)));
+    LB_HIP(hipMalloc(&w->d_xscratch, finish_scratch_bytes(kFinishSplitMaxQ, kFinishSmaxMax)));
     LB_HIP(hipMalloc(&w->d_fsync, (size_t)(1 + w->nq_cap) * sizeof(uint32_t)));
     LB_HIP(hipMemset(w->d_fsync, 0, (size_t)(1 + w->nq_cap) * sizeof(uint32_t)));
     LB_HIP(hipMemset(w->cs.flags, 0, (size_t)w->nq_cap * sizeof(uint32_t)));
@@ -844,6 +853,10 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     const bool light_sample = sp.on && !fused && nq <= light_max;
     static const int riders_max = lb_tunable("LB_NORM_RIDERS_MAXQ", 384);
     const bool norm_riders = sp.on && nq <= riders_max && metric == LB_METRIC_COSINE;
+    // the last launch: key-space pruning + exact re-rank + proof in one (kernels_finish.hip); beta: how far beyond one error
+    // bound the cut lies (the proof itself never depends on it)
+    static const bool use_finish = lb_tunable("LB_FINISH", 1) != 0;
+    static const float finish_beta = 0.01f * (float)lb_tunable("LB_FINISH_BETA_PCT", 25);
     if (!light_sample && !fused) launch_init_cand(w->cs, nullptr, nq, s);
     if (metric == LB_METRIC_COSINE && !norm_riders) launch_query_norms(order, d_q, nullptr, nq, h->dim, w->d_qna, s);
     static const bool sample_narrow = lb_tunable("LB_TALL_SAMPLE_NARROW", 1) != 0;
@@ -939,7 +952,8 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         } else {
             candidates(0, sp.span, rv.rowmap, /*boot=*/false);
         }
-        {
+        // (one span covers the view: the finish launch prunes the raw list itself -- everything below tau is in it)
+        if (sp.span < n || !use_finish) {
             ProfScope p(w, s, prof, 1);
             launch_select(w->cs, nullptr, nq, kc, 0u, s, false, (uint32_t)kc, nullptr, false, /*unsorted=*/true);
         }
@@ -959,8 +973,16 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     }
     {
         ProfScope p(w, s, prof, 2);
-        launch_rerank(metric, order, h->d_X, h->dim, d_q, nq, w->d_qna, w->cs, kc, k, h->d_maxnorm2, gamma,
-                      h->has_ids ? h->d_ids : nullptr, d_dist, d_lab, s, w->h_flags, w->d_done);
+        if (use_finish) {
+            // members a query may have: twice the results wanted, at least 1024 (the lists hold up to cap entries below tau)
+            const uint32_t smax = std::min<uint32_t>(kFinishSmaxMax, std::max<uint32_t>(1024u, 2u * next_pow2_host((uint32_t)k)));
+            launch_finish(metric, order, h->d_X, h->dim, d_q, nq, w->d_qna, w->cs, k, h->d_maxnorm2, gamma, finish_beta,
+                          h->has_ids ? h->d_ids : nullptr, nullptr, d_dist, d_lab, s, w->h_flags, w->d_done, w->d_xcnt,
+                          w->d_xscratch, kFinishSplitMaxQ, smax);
+        } else {
+            launch_rerank(metric, order, h->d_X, h->dim, d_q, nq, w->d_qna, w->cs, kc, k, h->d_maxnorm2, gamma,
+                          h->has_ids ? h->d_ids : nullptr, d_dist, d_lab, s, w->h_flags, w->d_done);
+        }
     }
     std::vector<int> bad;
     int nbad = collect_flagged(w, s, nq, 3u | 4u, nullptr, 0, bad, /*on_host=*/true);

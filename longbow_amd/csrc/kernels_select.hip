@@ -10,6 +10,7 @@
 //          result (rigorous rounding-error bound), write results.
 // merge:   store.MergeSortedStreams (internal/store/result_merger.go:34-101) for S shards.
 #include "lb_device.h"
+#include "lb_select.h"
 
 #include <float.h>
 #include <algorithm>
@@ -17,36 +18,6 @@
 #pragma clang fp contract(off)
 
 namespace lb {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int SEL_THREADS = 256;
-
-__device__ __forceinline__ uint32_t next_pow2(uint32_t v)
-{
-    if (v <= 2) return 2;
-    return 1u << (32 - __builtin_clz(v - 1));
-}
-
-// In-LDS bitonic sort of P (power of two) u64 keys, ascending, by the whole workgroup.
-__device__ __forceinline__ void bitonic_sort_u64(uint64_t *sh, uint32_t P, int tid, int nthreads)
-{
-    for (uint32_t k = 2; k <= P; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = tid; t < (P >> 1); t += nthreads) {
-                const uint32_t i = 2 * t - (t & (j - 1));
-                const uint32_t l = i + j;
-                const uint64_t a = sh[i], b = sh[l];
-                const bool up = (i & k) == 0;
-                if ((a > b) == up) {
-                    sh[i] = b;
-                    sh[l] = a;
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
 
 __global__ void init_cand_kernel(CandState cs, const int *qsel, int nsel)
 {
@@ -81,16 +52,6 @@ static void allow_big_lds(K kernel, size_t bytes)
 //               entry exactly (entries are unique: the row is part of the key), the <= pivot
 //               entries are compacted and only those kc are sorted.
 // LDS: entries u64[P] | hist u32[256] | wave sums u32[4] | scalars
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
-{
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t t = __shfl_up(v, off);
-        if (lane >= off) v += t;
-    }
-    return v;
-}
-
 // lane permutes on the DPP path (no LDS round trip): OR / AND of a u64 over the 64 lanes, result in lane 63
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ uint64_t dpp_u64(uint64_t v)
@@ -392,34 +353,6 @@ void launch_select(CandState cs, const int *qsel, int nsel, int kc, uint32_t boo
 }
 
 // ---------------------------------------------------------------------------
-// exact-order accumulators (same as kernels_scan.hip)
-template <int ORDER>
-struct AccR {
-    float s[ORDER == ORDER_UNROLL4 ? 4 : 1];
-    __device__ __forceinline__ void zero()
-    {
-#pragma unroll
-        for (int i = 0; i < (ORDER == ORDER_UNROLL4 ? 4 : 1); i++) s[i] = 0.f;
-    }
-    template <int T>
-    __device__ __forceinline__ void add(float v)
-    {
-        if (ORDER == ORDER_UNROLL4) s[T] = s[T] + v;
-        else s[0] = s[0] + v;
-    }
-    __device__ __forceinline__ void add_tail(float v) { s[0] = s[0] + v; }
-    __device__ __forceinline__ float total() const
-    {
-        if (ORDER == ORDER_UNROLL4) {
-            float t = s[0] + s[1];
-            t = t + s[2];
-            t = t + s[3];
-            return t;
-        }
-        return s[0];
-    }
-};
-
 struct RerankArgs {
     const float *X;
     int D;

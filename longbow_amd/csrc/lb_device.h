@@ -249,6 +249,16 @@ void launch_rerank(int metric, int order, const float *X, int D, const float *Q,
                    const int64_t *ids, float *out_dist, int64_t *out_labels, hipStream_t s, uint32_t *flags_host = nullptr,
                    uint32_t *done = nullptr);
 
+// The last launch of a batched search (kernels_finish.hip): members of each query's candidate list within the key-space cut
+// a_k + (1 + beta) E are re-ranked in the exact order, proven (or flagged: bit 1) and written.  posmap (or null): the lists
+// carry positions of this row list.  done / xcnt: [nq] words that are zero between launches; xscratch: finish_scratch_bytes
+// for the split form (up to nq_split_max queries); smax: members a query may have (power of two, >= 1024).
+size_t finish_scratch_bytes(int nq_split_max, uint32_t smax);
+void launch_finish(int metric, int order, const float *X, int D, const float *Q, int nq, const float *qna, CandState cs, int k,
+                   const uint32_t *d_maxnorm2, float gamma, float beta, const int64_t *ids, const uint32_t *posmap, float *out_dist,
+                   int64_t *out_labels, hipStream_t s, uint32_t *flags_host, uint32_t *done, uint32_t *xcnt, void *xscratch,
+                   int nq_split_max, uint32_t smax);
+
 // ||q||^2 per selected query slot in the requested accumulation order (cosine).
 void launch_query_norms(int order, const float *Q, const int *qsel, int nsel, int D, float *qna,
                         hipStream_t s);

@@ -92,6 +92,38 @@ def test_cancel_and_deadline(oracle):
     idx.Close()
 
 
+def test_cancel_token_fire_races_the_return(oracle):
+    """The lifetime pattern of hip_gpu.go: SearchBatchContext (round-3 advisor, use-after-free): a watcher thread may fire
+    the token at any moment around the return of the call; the token is freed only after the watcher has been joined.
+    Many short searches, the watcher's fire placed right at the return: answers stay right, nothing crashes, and a token
+    fired after the return has no effect on that call's results."""
+    gpu_or_skip()
+    from longbow_amd import gpu
+    rng = np.random.default_rng(18)
+    n, d, k = 20_000, 64, 5
+    X = rng.random((n, d), dtype=F)
+    q = rng.random((1, d), dtype=F)
+    idx = new_index(d, 0)
+    idx.Add(None, X)
+    want = idx.SearchBatch(q, k)
+    for it in range(200):
+        c = gpu.Cancel(deadline_ms=60_000)
+        returned = threading.Event()
+
+        def watcher(c=c, returned=returned):
+            returned.wait()
+            c.fire()              # "defer cancel()" of the caller, racing the binding's clean-up
+
+        th = threading.Thread(target=watcher)
+        th.start()
+        lab, dist = idx.SearchBatch(q, k, ctx=c)
+        returned.set()
+        th.join()                  # stop, JOIN, then free: the order hip_gpu.go keeps
+        c.close()
+        assert np.array_equal(lab, want[0]) and np.array_equal(dist, want[1]), it
+    idx.Close()
+
+
 def test_pq_search_cancel(oracle):
     gpu_or_skip()
     from longbow_amd import gpu, pq
