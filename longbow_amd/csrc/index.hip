@@ -839,7 +839,8 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
             w->d_qh_bytes = need;
         }
         d_qinv = reinterpret_cast<float *>(static_cast<char *>(w->d_qh) + img);
-        launch_queries_to_f16(d_q, nq, h->dim, w->d_qh, d_qinv, s);
+        // one launch: the image, the scales, the exact query norms (cosine) and the reset of the candidate state
+        launch_query_prep(d_q, nq, h->dim, w->d_qh, d_qinv, metric == LB_METRIC_COSINE ? w->d_qna : nullptr, order, w->cs, s);
     }
     if (!use_narrow && route.split == 1) {
         gx = h->d_Xs;
@@ -849,16 +850,20 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     // in kernels_gemm_narrow.hip: 19-34 us of sample + 13 us of threshold kernel off the critical path).
     static const int fused_max = lb_tunable("LB_FUSED_SAMPLE_MAXQ", 32); // (33-64 queries, the 64-query tile: measured level)
     const bool fused = sp.on && use_narrow && nsplit && nq <= fused_max && nq <= 64;
+    // over the fp16 copy the sample goes through the persistent kernel itself: 512 granules of 16 consecutive rows, evenly
+    // spaced over the span (whole KiB of the K-blocked image; every workgroup takes a share of them)
+    static const bool granule_on = lb_tunable("LB_GRANULE_SAMPLE", 1) != 0;
+    const bool granule_sample = sp.on && use_tall16 && have_xh && granule_on && sp.count % 16 == 0;
     static const int light_max = lb_tunable("LB_LIGHT_SAMPLE_MAXQ", 8);
-    const bool light_sample = sp.on && !fused && nq <= light_max;
+    const bool light_sample = sp.on && !fused && !granule_sample && nq <= light_max;
     static const int riders_max = lb_tunable("LB_NORM_RIDERS_MAXQ", 384);
-    const bool norm_riders = sp.on && nq <= riders_max && metric == LB_METRIC_COSINE;
+    const bool norm_riders = sp.on && nq <= riders_max && metric == LB_METRIC_COSINE && !use_tall16; // (fp16 route: query_prep)
     // the last launch: key-space pruning + exact re-rank + proof in one (kernels_finish.hip); beta: how far beyond one error
     // bound the cut lies (the proof itself never depends on it)
     static const bool use_finish = lb_tunable("LB_FINISH", 1) != 0;
     static const float finish_beta = 0.01f * (float)lb_tunable("LB_FINISH_BETA_PCT", 25);
-    if (!light_sample && !fused) launch_init_cand(w->cs, nullptr, nq, s);
-    if (metric == LB_METRIC_COSINE && !norm_riders) launch_query_norms(order, d_q, nullptr, nq, h->dim, w->d_qna, s);
+    if (!light_sample && !fused && !use_tall16) launch_init_cand(w->cs, nullptr, nq, s);
+    if (metric == LB_METRIC_COSINE && !norm_riders && !use_tall16) launch_query_norms(order, d_q, nullptr, nq, h->dim, w->d_qna, s);
     static const bool sample_narrow = lb_tunable("LB_TALL_SAMPLE_NARROW", 1) != 0;
     // (fp16 route, several 256-query tiles: the sample goes through the fp16 kernel itself -- 32 row tiles x nq/256 workgroups
     // against nq/64 x 64 of the narrow tile; 1024 queries: 1.94 -> 1.88 ms, 512: 1.015 -> 1.00; tools/probe/sample_route_probe.py)
@@ -903,6 +908,15 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
                                  w->cs, nullptr, s, h->d_norm2, h->d_rnorm);
             launch_sample_tau(w->cs, nullptr, nq, sp.count, sp.m, false, s, d_q, h->dim,
                               norm_riders ? w->d_qna : nullptr, order);
+        } else if (granule_sample) {
+            {
+                ctx_check(w->ctx);
+                ProfScope p(w, s, prof, 0);
+                launch_gemm_filter_tall16(metric, h->d_X, h->d_norm2, h->d_rnorm, 0, sp.count, h->dim, w->d_qh, d_qinv, nq, nullptr,
+                                          nullptr, w->cs, /*boot=*/true, s, h->d_Xh, h->xh_cap, (uint32_t)(sp.span / (int64_t)(sp.count / 16)));
+            }
+            ProfScope p(w, s, prof, 1);
+            launch_sample_tau(w->cs, nullptr, nq, sp.count, sp.m, false, s);
         } else {
             {
                 std::lock_guard<std::mutex> g(h->smap_mu);

@@ -77,7 +77,27 @@ struct Tall16Args {
     int rot; // persistent form: the query tiles of a corpus tile walk K rotated by rot K-steps against each other
     const _Float16 *Xh; // or null: fp16 image of the corpus, K-blocked [D / 32][xh_cap][32] (index.hip: sync_f16_image)
     int64_t xh_cap;     // rows per K-block plane of Xh
+    uint32_t gstride;   // persistent forms, sample pass: 0 = position p is row row_begin + p; else the positions are granules of 16
+                        // consecutive rows, granule j starting at row row_begin + j * gstride (an evenly spaced sample whose
+                        // requests are still whole KiB of the K-blocked image)
 };
+
+// Persistent forms: the launch's positions [0, n_pos) are dealt to the workgroups (narrow form) / workgroup groups (256-query
+// form) as CONTIGUOUS ranges whose bounds are multiples of 16 -- every range takes the same time whatever n_pos is (tiles dealt
+// round-robin left 16 tiles to some workgroups and 15 to others at 1M rows: 4 % of the pass), and a short launch (the 8192-row
+// sample) spreads over all of them.  A range's last tile is partial: positions beyond it read its last row again (L2 hits)
+// and carry a NaN side input.
+__device__ __forceinline__ void h_range(uint32_t n_pos, int gi, int ng, uint32_t &lo, uint32_t &hi)
+{
+    const uint32_t q = n_pos / (uint32_t)ng, r = n_pos % (uint32_t)ng; // n_pos gi / ng = q gi + r gi / ng (no 64-bit division)
+    lo = (q * (uint32_t)gi + (r * (uint32_t)gi) / (uint32_t)ng) & ~15u;
+    hi = gi + 1 < ng ? ((q * (uint32_t)(gi + 1) + (r * (uint32_t)(gi + 1)) / (uint32_t)ng) & ~15u) : n_pos;
+    // (the divisions run on the vector unit: tell the compiler the results are wave-uniform -- loop counts and the M0
+    // operands of the LDS-DMA requests derive from them)
+    lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
+    hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)hi);
+}
+__device__ __forceinline__ uint32_t h_rowof(uint32_t pos, uint32_t gstride) { return gstride ? (pos >> 4) * gstride + (pos & 15u) : pos; }
 
 // corpus rows: 128 B, eight 16-B chunks, chunk c of row r at position c ^ ((r >> 1) & 7)   (byte offset in the A region)
 __device__ __forceinline__ int haswz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -462,7 +482,8 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16_kernel(Tall16
 // queries, the ring FOUR stages deep and a stage is requested three K-steps ahead -- half the corpus bytes to stage, and
 // a third more time for a line that four CUs ask for at once to arrive.  The image is K-blocked like the
 // query image: the 64 B a K-step needs of 16 consecutive rows are one KiB of whole lines.
-template <int METRIC, bool NT, bool AIMG>
+// BOOT: the launch stores every position's entry (bootstrap chunk of the classic schedule, or -- gstride != 0 -- the sample pass)
+template <int METRIC, bool NT, bool AIMG, bool BOOT>
 __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall16Args a, int spx)
 {
     constexpr int NST = AIMG ? 4 : 3;                       // ring stages
@@ -494,11 +515,12 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
     const int l31 = lane & 31, h = lane >> 5;
     const int q0 = qt * H_BN;
     const int last_q = a.nq - 1;
-    const int64_t last_pos = a.row_end - a.row_begin - 1; // positions of this launch: corpus row = row_begin + position
+    const uint32_t last_pos = (uint32_t)(a.row_end - a.row_begin - 1); // positions of this launch: corpus row = row_begin + position (sample pass: h_rowof)
+    const uint32_t gstride = BOOT ? a.gstride : 0u;
     const unsigned char *Xb = reinterpret_cast<const unsigned char *>(a.X + a.row_begin * (int64_t)a.D);
     const int64_t row_bytes = (int64_t)a.D * 4;
     const float *auxg = METRIC == METRIC_L2 ? a.norm2 + a.row_begin : (METRIC == METRIC_COS ? a.rnorm + a.row_begin : nullptr);
-    auto rt_of = [&](int i) { return (group + gpx * i) * 8 + xcd; };
+    auto rt_of = [&](int i) { return (uint32_t)((group + gpx * i) * 8 + xcd) * H_BM; }; // first position of tile i
 
     // request sources.  Corpus: request i < 4 of this wave fills local rows 32 wave + 8 i .. + 7 (lane l: row l / 8, chunk
     // position l % 8) -- from the image: request i < 2 fills rows 32 wave + 16 i .. + 15 (lane l: row l / 4, chunk position
@@ -506,14 +528,15 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
     const unsigned char *srcA[4], *srcB[2];
     const unsigned char *Xhb = reinterpret_cast<const unsigned char *>(a.Xh) + a.row_begin * (int64_t)(H_BK * 2);
     const int64_t plane_bytes = a.xh_cap * (int64_t)(H_BK * 2);
-    auto set_srcA = [&](int rt) {
+    auto set_srcA = [&](uint32_t rt) {
 #pragma unroll
         for (int i = 0; i < NPA; i++) {
             const int row = AIMG ? wave * 32 + i * 16 + (lane >> 2) : wave * 32 + i * 8 + (lane >> 3);
             const int c = AIMG ? (lane & 3) ^ ((row >> 2) & 3) : (lane & 7) ^ ((row >> 1) & 7);
-            int64_t pos = (int64_t)rt * H_BM + row;
+            uint32_t pos = rt + (uint32_t)row;
             if (pos > last_pos) pos = last_pos;
-            srcA[i] = AIMG ? Xhb + pos * (H_BK * 2) + 16 * c : Xb + pos * row_bytes + 16 * c;
+            pos = h_rowof(pos, gstride);
+            srcA[i] = AIMG ? Xhb + (int64_t)pos * (H_BK * 2) + 16 * c : Xb + (int64_t)pos * row_bytes + 16 * c;
         }
     };
 #pragma unroll
@@ -546,11 +569,11 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
     };
     auto aux_request = [&](int i) { // side input of tile i -> buffer i & 1 (every wave asks for 64 rows: entries 256 .. 511 repeat 0 .. 255)
         if (METRIC == METRIC_DOT) return;
-        int64_t pos = (int64_t)rt_of(i) * H_BM + ((wave & 3) * 64 + lane);
+        uint32_t pos = rt_of(i) + (uint32_t)((wave & 3) * 64 + lane);
         if (pos > last_pos) pos = last_pos;
         uint32_t save;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(save) : "v"(auxg + pos), "s"(aux_base + (uint32_t)(i & 1) * 2048u + (uint32_t)wave * 256u));
+                     : "=&s"(save) : "v"(auxg + h_rowof(pos, gstride)), "s"(__builtin_amdgcn_readfirstlane((int)(aux_base + (uint32_t)(i & 1) * 2048u + (uint32_t)wave * 256u))));
     };
 
     set_srcA(rt_of(0));
@@ -572,7 +595,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
     for (int tn = 0; tn < 4; tn++) {
         const int qj = q0 + wc * 128 + tn * 32 + l31;
         const int qc = qj < a.nq ? qj : a.nq - 1;
-        uint64_t tau = a.boot ? 0ull : a.cs.tau[qc];
+        uint64_t tau = BOOT ? 0ull : a.cs.tau[qc];
         if (qj >= a.nq) tau = 0ull;
         const float tk = tau_key_of(tau);
         qs[tn] = a.qinv[qc];
@@ -640,7 +663,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
         load_frag(0, 0, a0, b0);
     }
     for (int i = 0; i < n_my; i++) {
-        const int rt = rt_of(i);
+        const uint32_t rt = rt_of(i);
         f32x16 acc[2][4];
 #pragma unroll
         for (int x = 0; x < 2; x++)
@@ -720,7 +743,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
 #pragma unroll
         for (int tm = 0; tm < 2; tm++) {
             float aux[4][4]; // cosine: -1/|x|, dot: -1, L2: |x|^2; NaN for a row beyond the range
-            const int64_t pos0 = (int64_t)rt * H_BM + wr * 64 + tm * 32 + 4 * h; // position of element (g, e): pos0 + 8 g + e
+            const uint32_t pos0 = rt + (uint32_t)(wr * 64 + tm * 32 + 4 * h); // position of element (g, e): pos0 + 8 g + e
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const int lr = wr * 64 + tm * 32 + 8 * g + 4 * h;
@@ -729,24 +752,24 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const float v = METRIC == METRIC_L2 ? av[e] : -av[e];
-                    aux[g][e] = pos0 + 8 * g + e <= last_pos ? v : __builtin_nanf("");
+                    aux[g][e] = pos0 + (uint32_t)(8 * g + e) <= last_pos ? v : __builtin_nanf("");
                 }
             }
-            const uint32_t rid0 = (uint32_t)(a.row_begin + pos0);
+            const uint32_t rid0 = (uint32_t)a.row_begin + pos0;
 #pragma unroll
             for (int tn = 0; tn < 4; tn++) {
                 const int qj = q0 + wc * 128 + tn * 32 + l31;
                 const bool qok = qj < a.nq;
                 uint64_t *list = a.cs.lists + (size_t)(qok ? qj : 0) * a.cs.cap;
-                if (a.boot) { // sample pass: the entry of position p goes to list[p] (rows beyond the range: none)
+                if (BOOT) { // sample pass: the entry of position p goes to list[p] (rows beyond the range: none)
                     if (qok) {
 #pragma unroll
                         for (int x = 0; x < 16; x++) {
                             const float kp = METRIC == METRIC_L2 ? fmaf(acc[tm][tn][x], m2qs[tn], aux[x >> 2][x & 3])
                                                                  : acc[tm][tn][x] * aux[x >> 2][x & 3];
-                            if (pos0 + 8 * (x >> 2) + (x & 3) <= last_pos)
-                                list[pos0 + 8 * (x >> 2) + (x & 3)] =
-                                    pack_entry(METRIC == METRIC_L2 ? kp : kp * qs[tn], rid0 + 8 * (x >> 2) + (x & 3));
+                            const uint32_t px = pos0 + (uint32_t)(8 * (x >> 2) + (x & 3));
+                            if (px <= last_pos)
+                                list[px] = pack_entry(METRIC == METRIC_L2 ? kp : kp * qs[tn], (uint32_t)a.row_begin + h_rowof(px, gstride));
                         }
                     }
                     continue;
@@ -785,7 +808,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
         // counter per search, and their serialisation showed (0.1 ms at 128 queries).
         if (wcnt > WFLUSH && lane == 0) s_flag[i % 3] = 1;
         if (tid == 0) s_flag[(i + 1) % 3] = 0;
-        bool flush = !a.boot && (i + 1 == n_my || (i > 0 && s_flag[(i + 2) % 3] != 0));
+        bool flush = !BOOT && (i + 1 == n_my || (i > 0 && s_flag[(i + 2) % 3] != 0));
 #ifdef LB_DIAG
         if (a.abl == 7) flush = false;
 #endif
@@ -816,7 +839,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
 // at BN = 64 -- lanes 0 .. 31 --, one at 128, two at 256); a stage is 16 KB + 4 / 8 / 16 KB, the ring SIX / FIVE / FOUR stages
 // deep (48-80 KB of corpus in flight per CU), loads non-temporal (every line is read once).  1M x 768: the image is 1.5 GB,
 // the pass 0.24-0.3 ms where the f32 rows take 0.49.
-template <int METRIC, int BN>
+template <int METRIC, int BN, bool BOOT>
 __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tall16Args a, int spx)
 {
     constexpr int TN = BN / 32;
@@ -824,11 +847,11 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
     constexpr int NPB = BN == 256 ? 2 : 1; // query requests per wave and stage
     constexpr int NPS = 2 + NPB, DIST = NST - 1, H1 = 2;
     constexpr bool PIPE = BN != 256; // (at 256 queries there are no registers for a third set of fragments: barrier on top)
-    const int b = blockIdx.x;
-    const int xcd = b & 7, slot = b >> 3;
-    const int jtop = a.n_row_tiles - 1 - xcd;
-    if (jtop < 0 || slot > (jtop >> 3)) return;
-    const int n_my = ((jtop >> 3) - slot) / spx + 1; // corpus tiles of this workgroup: 8 (slot + spx i) + xcd
+    (void)spx;
+    uint32_t lo, hi; // this workgroup's positions
+    h_range((uint32_t)(a.row_end - a.row_begin), (int)blockIdx.x, (int)gridDim.x, lo, hi);
+    if (hi <= lo) return;
+    const int n_my = (int)((hi - lo + H_BM - 1) / H_BM); // its tiles: positions lo + 256 i ..
 
     extern __shared__ __attribute__((aligned(16))) unsigned char hlds[];
     unsigned char *ring = hlds;
@@ -841,21 +864,22 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
     const int last_q = a.nq - 1;
-    const int64_t last_pos = a.row_end - a.row_begin - 1;
+    const uint32_t last_pos = hi - 1;
+    const uint32_t gstride = BOOT ? a.gstride : 0u;
     const float *auxg = METRIC == METRIC_L2 ? a.norm2 + a.row_begin : (METRIC == METRIC_COS ? a.rnorm + a.row_begin : nullptr);
-    auto rt_of = [&](int i) { return (slot + spx * i) * 8 + xcd; };
+    auto rt_of = [&](int i) { return lo + (uint32_t)i * H_BM; }; // first position of tile i
 
     const unsigned char *srcA[2], *srcB[NPB];
     const unsigned char *Xhb = reinterpret_cast<const unsigned char *>(a.Xh) + a.row_begin * (int64_t)(H_BK * 2);
     const int64_t plane_bytes = a.xh_cap * (int64_t)(H_BK * 2);
-    auto set_srcA = [&](int rt) {
+    auto set_srcA = [&](uint32_t rt) {
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             const int row = wave * 32 + i * 16 + (lane >> 2);
             const int c = (lane & 3) ^ ((row >> 2) & 3);
-            int64_t pos = (int64_t)rt * H_BM + row;
+            uint32_t pos = rt + (uint32_t)row;
             if (pos > last_pos) pos = last_pos;
-            srcA[i] = Xhb + pos * (H_BK * 2) + 16 * c;
+            srcA[i] = Xhb + (int64_t)h_rowof(pos, gstride) * (H_BK * 2) + 16 * c;
         }
     };
 #pragma unroll
@@ -884,11 +908,11 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
     };
     auto aux_request = [&](int i) {
         if (METRIC == METRIC_DOT) return;
-        int64_t pos = (int64_t)rt_of(i) * H_BM + ((wave & 3) * 64 + lane);
+        uint32_t pos = rt_of(i) + (uint32_t)((wave & 3) * 64 + lane);
         if (pos > last_pos) pos = last_pos;
         uint32_t save;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(save) : "v"(auxg + pos), "s"(aux_base + (uint32_t)(i & 1) * 2048u + (uint32_t)wave * 256u));
+                     : "=&s"(save) : "v"(auxg + h_rowof(pos, gstride)), "s"(__builtin_amdgcn_readfirstlane((int)(aux_base + (uint32_t)(i & 1) * 2048u + (uint32_t)wave * 256u))));
     };
 
     set_srcA(rt_of(0));
@@ -906,7 +930,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
     for (int tn = 0; tn < TN; tn++) {
         const int qj = tn * 32 + l31;
         const int qc = qj < a.nq ? qj : a.nq - 1;
-        uint64_t tau = a.boot ? 0ull : a.cs.tau[qc];
+        uint64_t tau = BOOT ? 0ull : a.cs.tau[qc];
         if (qj >= a.nq) tau = 0ull;
         const float tk = tau_key_of(tau);
         qs[tn] = a.qinv[qc];
@@ -947,7 +971,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
         load_frag(0, 0, a0, b0);
     }
     for (int i = 0; i < n_my; i++) {
-        const int rt = rt_of(i);
+        const uint32_t rt = rt_of(i);
         f32x16 acc[TN];
 #pragma unroll
         for (int y = 0; y < TN; y++)
@@ -1004,7 +1028,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
         // ---- epilogue of the tile (as the 256-query form: 2 VALU + 1 scalar branch per element, per-wave segments) ----------
         const float *s_aux = s_auxp + (i & 1) * 512;
         float aux[4][4];
-        const int64_t pos0 = (int64_t)rt * H_BM + wave * 32 + 4 * h;
+        const uint32_t pos0 = rt + (uint32_t)(wave * 32 + 4 * h);
 #pragma unroll
         for (int g = 0; g < 4; g++) {
             const int lr = wave * 32 + 8 * g + 4 * h;
@@ -1013,22 +1037,23 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const float v = METRIC == METRIC_L2 ? av[e] : -av[e];
-                aux[g][e] = pos0 + 8 * g + e <= last_pos ? v : __builtin_nanf("");
+                aux[g][e] = pos0 + (uint32_t)(8 * g + e) <= last_pos ? v : __builtin_nanf("");
             }
         }
-        const uint32_t rid0 = (uint32_t)(a.row_begin + pos0);
+        const uint32_t rid0 = (uint32_t)a.row_begin + pos0;
 #pragma unroll
         for (int tn = 0; tn < TN; tn++) {
             const int qj = tn * 32 + l31;
             const bool qok = qj < a.nq;
             uint64_t *list = a.cs.lists + (size_t)(qok ? qj : 0) * a.cs.cap;
-            if (a.boot) {
+            if (BOOT) {
                 if (qok) {
 #pragma unroll
                     for (int x = 0; x < 16; x++) {
                         const float kp = METRIC == METRIC_L2 ? fmaf(acc[tn][x], m2qs[tn], aux[x >> 2][x & 3]) : acc[tn][x] * aux[x >> 2][x & 3];
-                        if (pos0 + 8 * (x >> 2) + (x & 3) <= last_pos)
-                            list[pos0 + 8 * (x >> 2) + (x & 3)] = pack_entry(METRIC == METRIC_L2 ? kp : kp * qs[tn], rid0 + 8 * (x >> 2) + (x & 3));
+                        const uint32_t px = pos0 + (uint32_t)(8 * (x >> 2) + (x & 3));
+                        if (px <= last_pos)
+                            list[px] = pack_entry(METRIC == METRIC_L2 ? kp : kp * qs[tn], (uint32_t)a.row_begin + h_rowof(px, gstride));
                     }
                 }
                 continue;
@@ -1058,7 +1083,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
         }
         if (wcnt > WFLUSH && lane == 0) s_flag[i % 3] = 1;
         if (tid == 0) s_flag[(i + 1) % 3] = 0;
-        if (!a.boot && (i + 1 == n_my || (i > 0 && s_flag[(i + 2) % 3] != 0))) { // (all waves together: see the 256-query form)
+        if (!BOOT && (i + 1 == n_my || (i > 0 && s_flag[(i + 2) % 3] != 0))) { // (all waves together: see the 256-query form)
             const uint32_t total = wcnt < WCAP ? wcnt : WCAP;
             for (uint32_t z = lane; z < total; z += 64) s_rk[z] = (uint16_t)atomicAdd(&s_qn[s_q[z]], 1u);
             __syncthreads();
@@ -1160,10 +1185,11 @@ void launch_queries_to_f16(const float *Q, int nq, int D, void *Qh, float *qinv,
 static void tall16_window(int metric, const float *X, const float *norm2, const float *rnorm, int64_t row_begin, int64_t row_end,
                           int D, const void *Qh, const float *qinv, int nq, int q_stride, const uint8_t *mask,
                           const uint32_t *rowmap, CandState cs, bool boot, hipStream_t s, const void *Xh, int64_t xh_cap,
-                          bool may_split)
+                          bool may_split, uint32_t gstride)
 {
     if (row_end <= row_begin || nq <= 0) return;
     Tall16Args a;
+    a.gstride = gstride;
     a.rowmap = rowmap;
     a.X = X; a.norm2 = norm2; a.rnorm = rnorm; a.row_begin = row_begin; a.row_end = row_end; a.D = D;
     a.Qh = reinterpret_cast<const _Float16 *>(Qh); a.qinv = qinv; a.nq = nq; a.q_stride = q_stride; a.mask = mask; a.cs = cs; a.boot = boot ? 1 : 0;
@@ -1206,13 +1232,13 @@ static void tall16_window(int metric, const float *X, const float *norm2, const 
         if (img && may_split && split_tail && nq > H_BN && tail >= 1 && tail <= 64) {
             const int head = nq - tail;
             tall16_window(metric, X, norm2, rnorm, row_begin, row_end, D, Qh, qinv, head, q_stride, mask, rowmap, cs, boot, s, Xh,
-                          xh_cap, false);
+                          xh_cap, false, gstride);
             CandState ct = cs;
             ct.lists += (size_t)head * cs.cap;
             ct.cnt += head;
             ct.tau += head;
             tall16_window(metric, X, norm2, rnorm, row_begin, row_end, D, reinterpret_cast<const _Float16 *>(Qh) + (size_t)head * H_BK,
-                          qinv + head, tail, q_stride, mask, rowmap, ct, boot, s, Xh, xh_cap, false);
+                          qinv + head, tail, q_stride, mask, rowmap, ct, boot, s, Xh, xh_cap, false, gstride);
             return;
         }
         static const int n16 = lb_tunable("LB_F16_NARROW", 1);
@@ -1225,16 +1251,21 @@ static void tall16_window(int metric, const float *X, const float *norm2, const 
             // ring, side inputs, flush flags + counters, admission segments
             const size_t nshmem = ring_b + 2 * 512 * sizeof(float) + 16 + 2 * 256 * 4 + 8 * (bn == 256 ? 272 : 360) * 12;
             dim3 ngrid((unsigned)(spx * 8));
-#define LB_NARROW16(M, N)                                                                                        \
-    do {                                                                                                         \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_filter_narrow16p_kernel<M, N>),           \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)nshmem);                      \
-        hipLaunchKernelGGL((gemm_filter_narrow16p_kernel<M, N>), ngrid, dim3(H_THREADS), nshmem, s, a, spx);     \
+#define LB_NARROW16(M, N, B)                                                                                        \
+    do {                                                                                                            \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_filter_narrow16p_kernel<M, N, B>),           \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)nshmem);                         \
+        hipLaunchKernelGGL((gemm_filter_narrow16p_kernel<M, N, B>), ngrid, dim3(H_THREADS), nshmem, s, a, spx);     \
     } while (0)
-#define LB_NARROW16_M(M)                  \
-    do {                                  \
-        if (bn == 64) LB_NARROW16(M, 64); \
-        else LB_NARROW16(M, 128);         \
+#define LB_NARROW16_M(M)                                 \
+    do {                                                 \
+        if (boot) {                                      \
+            if (bn == 64) LB_NARROW16(M, 64, true);      \
+            else LB_NARROW16(M, 128, true);              \
+        } else {                                         \
+            if (bn == 64) LB_NARROW16(M, 64, false);     \
+            else LB_NARROW16(M, 128, false);             \
+        }                                                \
     } while (0)
             if (metric == METRIC_L2) LB_NARROW16_M(METRIC_L2);
             else if (metric == METRIC_COS) LB_NARROW16_M(METRIC_COS);
@@ -1247,21 +1278,24 @@ static void tall16_window(int metric, const float *X, const float *norm2, const 
                               16 + 2 * H_BN * 4 + 8 * (img ? 272 : 104) * 12; // ring, side inputs, flush flags + counters, admission segments
         const bool pnt = a.n_q_tiles <= 1;
         dim3 pgrid((unsigned)(spx * 8));
-#define LB_TALL16P(M, N, I)                                                                                       \
-    do {                                                                                                          \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_filter_tall16p_kernel<M, N, I>),           \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)pshmem);                       \
-        hipLaunchKernelGGL((gemm_filter_tall16p_kernel<M, N, I>), pgrid, dim3(H_THREADS), pshmem, s, a, spx);     \
+#define LB_TALL16P(M, N, I, B)                                                                                       \
+    do {                                                                                                             \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_filter_tall16p_kernel<M, N, I, B>),           \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)pshmem);                          \
+        hipLaunchKernelGGL((gemm_filter_tall16p_kernel<M, N, I, B>), pgrid, dim3(H_THREADS), pshmem, s, a, spx);     \
     } while (0)
-#define LB_TALL16P_M(M)                          \
-    do {                                         \
-        if (img) {                               \
-            if (pnt) LB_TALL16P(M, true, true);  \
-            else LB_TALL16P(M, false, true);     \
-        } else {                                 \
-            if (pnt) LB_TALL16P(M, true, false); \
-            else LB_TALL16P(M, false, false);    \
-        }                                        \
+#define LB_TALL16P_M(M)                                        \
+    do {                                                       \
+        if (boot) { /* (a short launch: the cache policy does not matter) */ \
+            if (img) LB_TALL16P(M, false, true, true);         \
+            else LB_TALL16P(M, false, false, true);            \
+        } else if (img) {                                      \
+            if (pnt) LB_TALL16P(M, true, true, false);         \
+            else LB_TALL16P(M, false, true, false);            \
+        } else {                                               \
+            if (pnt) LB_TALL16P(M, true, false, false);        \
+            else LB_TALL16P(M, false, false, false);           \
+        }                                                      \
     } while (0)
         if (metric == METRIC_L2) LB_TALL16P_M(METRIC_L2);
         else if (metric == METRIC_COS) LB_TALL16P_M(METRIC_COS);
@@ -1323,9 +1357,12 @@ static void tall16_window(int metric, const float *X, const float *norm2, const 
 
 void launch_gemm_filter_tall16(int metric, const float *X, const float *norm2, const float *rnorm, int64_t row_begin,
                                int64_t row_end, int D, const void *Qh, const float *qinv, int nq, const uint8_t *mask,
-                               const uint32_t *rowmap, CandState cs, bool boot, hipStream_t s, const void *Xh, int64_t xh_cap)
+                               const uint32_t *rowmap, CandState cs, bool boot, hipStream_t s, const void *Xh, int64_t xh_cap,
+                               uint32_t gstride)
 {
-    tall16_window(metric, X, norm2, rnorm, row_begin, row_end, D, Qh, qinv, nq, nq, mask, rowmap, cs, boot, s, Xh, xh_cap, true);
+    // (the granule-strided sample view exists in the persistent forms only: unfiltered, over the fp16 image or the f32 rows)
+    if (gstride != 0 && (rowmap || mask || !boot)) return;
+    tall16_window(metric, X, norm2, rnorm, row_begin, row_end, D, Qh, qinv, nq, nq, mask, rowmap, cs, boot, s, Xh, xh_cap, true, gstride);
 }
 
 } // namespace lb

@@ -481,6 +481,54 @@ __device__ __forceinline__ float exact_sq_norm_lds(const float *sq, int D)
     return a.total();
 }
 
+// Everything a batched search over the fp16 route needs from its queries, in one launch (one wave per query): the fp16
+// image [D / 32][nq][32] (each query scaled by the power of two that brings its norm into [1, 2); qinv[q] = 1 / scale, exact),
+// the exact ||q||^2 in the reference's order (cosine: the re-rank divides by it, internal/simd/simd.go:138-152), and the
+// reset of the query's candidate state.  (A zero or non-finite query keeps scale 1: the exact scan answers it anyway.)
+__global__ __launch_bounds__(64) void query_prep_kernel(const float *Q, int nq, int D, _Float16 *Qh, float *qinv, float *qna, int order,
+                                                        CandState cs)
+{
+    extern __shared__ __attribute__((aligned(16))) float sq[];
+    const int q = blockIdx.x, lane = threadIdx.x;
+    const float *src = Q + (int64_t)q * D;
+    const int Dpad = (D + 3) & ~3;
+    float s = 0.f;
+    for (int i = lane; i < Dpad; i += 64) {
+        const float v = i < D ? src[i] : 0.f;
+        sq[i] = v;
+        s += v * v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    float scale = 1.f, inv = 1.f;
+    if (s > 0.f && s < 3.0e38f) {
+        const float nrm = sqrtf(s);
+        int ex;
+        (void)frexpf(nrm, &ex); // nrm = m * 2^ex, 0.5 <= m < 1  ->  nrm * 2^(1 - ex) in [1, 2)
+        int sh = 1 - ex;
+        sh = sh < -120 ? -120 : (sh > 120 ? 120 : sh);
+        scale = ldexpf(1.f, sh);
+        inv = ldexpf(1.f, -sh);
+    }
+    __syncthreads();
+    const int Dp = (D + 31) & ~31; // (dimensions beyond D: zero -- they add nothing to a product)
+    for (int i = lane; i < Dp; i += 64) Qh[((int64_t)(i >> 5) * nq + q) * 32 + (i & 31)] = i < D ? (_Float16)(sq[i] * scale) : (_Float16)0.f;
+    if (lane == 0) {
+        qinv[q] = inv;
+        cs.cnt[q] = 0;
+        cs.tau[q] = kEntryMax;
+        cs.flags[q] = 0;
+        if (qna) qna[q] = order == ORDER_UNROLL4 ? exact_sq_norm_lds<ORDER_UNROLL4>(sq, D) : exact_sq_norm_lds<ORDER_SEQ>(sq, D);
+    }
+}
+
+void launch_query_prep(const float *Q, int nq, int D, void *Qh, float *qinv, float *qna, int order, CandState cs, hipStream_t s)
+{
+    if (nq <= 0) return;
+    hipLaunchKernelGGL(query_prep_kernel, dim3((unsigned)nq), dim3(64), (size_t)((D + 3) & ~3) * sizeof(float), s, Q, nq, D,
+                       reinterpret_cast<_Float16 *>(Qh), qinv, qna, order, cs);
+}
+
 // R = sampled rows per wave: every query chunk fetched from L2 is used for R rows (with 32 query
 // slots and R = 1 the launch is bound by 8192 x 96 KB of L2 reads: 97 us; R = 4: a quarter of that)
 template <int METRIC, int R>
@@ -644,8 +692,8 @@ void launch_sample_scores(int metric, int order, const float *X, int D, int64_t 
 }
 
 // tau[q] = m-th smallest of the first `count` entries of list q (row bits saturated), cnt[q] = 0.
-// m is small (8..32): m rounds of a workgroup-wide minimum over register-resident entries beat a
-// radix select by 3-4x here.  The wave-level minimum runs on DPP lane permutes (no LDS round trips).
+// m is small (8..64): pops of a minimum over register-resident, pre-sorted entries beat a radix select here.
+// The wave-level minimum runs on DPP lane permutes (no LDS round trips).
 constexpr int ST_THREADS = 1024;
 constexpr int ST_PER = 8;
 
@@ -653,7 +701,7 @@ __global__ __launch_bounds__(ST_THREADS) void sample_tau_kernel(CandState cs, co
                                                                 int zero_stripes, const float *Q, int D, float *qna, int order)
 {
     extern __shared__ __attribute__((aligned(16))) float sq[];
-    __shared__ uint64_t wmin[2][ST_THREADS / 64];
+    __shared__ uint64_t wl[ST_THREADS / 64][20]; // (m <= 64: r1 <= 20)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if ((int)blockIdx.x >= nsel) { // optional riders (qna != null): exact ||q||^2 of slot blockIdx.x - nsel
         const int j = (int)blockIdx.x - nsel;
@@ -684,19 +732,32 @@ __global__ __launch_bounds__(ST_THREADS) void sample_tau_kernel(CandState cs, co
     LB_CE(5, 6) LB_CE(0, 4) LB_CE(3, 7) LB_CE(1, 5) LB_CE(2, 6) LB_CE(1, 4) LB_CE(3, 6) LB_CE(2, 4) LB_CE(3, 5)
     LB_CE(3, 4)
 #undef LB_CE
-    uint64_t kth = kEntryMax;
-    for (int r = 0; r < m; r++) {
-        uint64_t v = wave_min_u64(e[0]);
-        if (lane == 0) wmin[r & 1][wave] = v;
-        __syncthreads();
-        static_assert(ST_THREADS / 64 == 16, "one row of 16 lanes reduces the per-wave minima");
-        v = row16_min_u64(wmin[r & 1][lane & 15]);
-        kth = v;
-        if (v == kEntryMax) break; // fewer than m visible sample rows: no threshold
-        if (e[0] == v) {           // entries are unique: exactly one thread pops its head
+    // Two levels, one barrier.  Level 1: every wave pops its own r smallest entries (wave-wide minimum on DPP lane permutes,
+    // no LDS round trip, no barrier) into wl[wave][0 .. r) -- ascending.  Level 2: one wave merges the 16 sorted runs, m pops.
+    // r = min(m, 4 + m / 4) < m for m > 5: should one wave hold more than r of the m smallest entries, the merge runs out
+    // of that wave's run and returns a LARGER value than the m-th smallest -- a looser threshold, which admits a few more
+    // rows and is as valid as the exact one (tau is only a filter; P ~ 1e-4 per search at m = 19).
+    const int r1 = m < 4 + m / 4 ? m : 4 + m / 4;
+    for (int r = 0; r < r1; r++) {
+        const uint64_t v = wave_min_u64(e[0]);
+        if (lane == 0) wl[wave][r] = v;
+        if (e[0] == v && v != kEntryMax) { // entries are unique: exactly one lane pops its head
 #pragma unroll
             for (int i = 0; i + 1 < ST_PER; i++) e[i] = e[i + 1];
             e[ST_PER - 1] = kEntryMax;
+        }
+    }
+    __syncthreads();
+    uint64_t kth = kEntryMax;
+    if (wave == 0) {
+        static_assert(ST_THREADS / 64 == 16, "one row of 16 lanes merges the per-wave runs");
+        int ptr = 0; // lanes 0 .. 15: the head of wave `lane`'s run
+        for (int r = 0; r < m; r++) {
+            const uint64_t head = (lane < 16 && ptr < r1) ? wl[lane][ptr] : kEntryMax;
+            const uint64_t v = row16_min_u64(head); // (rows 1 .. 3 of the wave hold kEntryMax)
+            kth = __shfl(v, 0);
+            if (kth == kEntryMax) break; // fewer than m visible sample rows, or every run used up: no threshold
+            if (lane < 16 && head == kth) ptr++;
         }
     }
     if (tid == 0) {

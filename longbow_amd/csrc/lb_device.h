@@ -200,12 +200,17 @@ void launch_gemm_filter_tall2(int metric, const float *X, const float *norm2, co
 // ONE fp16 product per (row, query, k) on 256 x 256 tiles (kernels_gemm_tall16.hip): Qh / qinv from launch_queries_to_f16
 // (fp16 image of the batch, each query scaled by a power of two to a norm in [1, 2); qinv = 1 / scale); X = f32 corpus
 void launch_queries_to_f16(const float *Q, int nq, int D, void *Qh, float *qinv, hipStream_t s);
+// the same image and scales, plus the exact ||q||^2 in `order` (qna, or null) and the reset of the queries' candidate state:
+// one launch for what a search over this route needs from its batch (kernels_scan.hip)
+void launch_query_prep(const float *Q, int nq, int D, void *Qh, float *qinv, float *qna, int order, CandState cs, hipStream_t s);
 // Xh (or null): the corpus's K-blocked fp16 image [D / 32][xh_cap][32] from launch_corpus_to_f16, in step with X; used by
 // unfiltered searches (half the bytes to stage, a four-stage ring)
 void launch_gemm_filter_tall16(int metric, const float *X, const float *norm2, const float *rnorm, int64_t row_begin,
                                int64_t row_end, int D, const void *Qh, const float *qinv, int nq, const uint8_t *mask,
                                const uint32_t *rowmap, CandState cs, bool boot, hipStream_t s, const void *Xh = nullptr,
-                               int64_t xh_cap = 0);
+                               int64_t xh_cap = 0,
+                               uint32_t gstride = 0); // boot launches of the persistent forms: positions = granules of 16 rows,
+                                                     // gstride rows apart (an evenly spaced sample read in whole KiB)
 void launch_corpus_to_f16(const float *X, int64_t row_begin, int64_t row_end, int D, void *Xh, int64_t cap, hipStream_t s);
 
 // per query: sort the list, keep the best kc, tau = kc-th entry (or max), flag overflow.
