@@ -387,6 +387,20 @@ func NewNodeIndex(devices []int, cfg HIPConfig) (*NodeIndex, error) {
 	return n, nil
 }
 
+// Prepare sizes the exchange buffers for searches of up to nqMax queries and kMax results (lb_gpu_comm_prepare): after it
+// a search within that size allocates nothing between the shard searches and the exchange.
+func (n *NodeIndex) Prepare(nqMax, kMax int) error {
+	n.mu.Lock()
+	defer n.mu.Unlock()
+	if n.comm == nil {
+		return fmt.Errorf("index is closed")
+	}
+	if rc := C.lb_gpu_comm_prepare(n.comm, C.int64_t(nqMax), C.int(kMax)); rc != C.LB_OK {
+		return fmt.Errorf("comm prepare failed with code %d (%s)", int(rc), C.GoString(C.lb_gpu_comm_last_error(n.comm)))
+	}
+	return nil
+}
+
 // Add appends vectors to one shard (ids are the global VectorIDs; they travel with the results).
 func (n *NodeIndex) Add(shard int, ids []int64, vectors []float32) error {
 	if shard < 0 || shard >= len(n.shards) {

@@ -349,6 +349,12 @@ void lb_gpu_comm_free(lb_gpu_comm *c);
 int lb_gpu_comm_nranks(const lb_gpu_comm *c);
 int lb_gpu_comm_rank(const lb_gpu_comm *c);
 const char *lb_gpu_comm_last_error(const lb_gpu_comm *c);
+/* Size the exchange buffers (device blocks, pinned host blocks of the host transport, per-device query buffers of init_all)
+ * for searches of up to nq_max queries and k_max results.  NOT collective: each rank calls it on its own, right after init,
+ * and acts on its return code before any search is issued.  A search within the prepared size allocates nothing between
+ * the shard search and the exchange, so an out-of-memory condition on one rank cannot leave its peers waiting in the
+ * all-gather.  (A larger search still grows the buffers on the fly, with that risk.) */
+int lb_gpu_comm_prepare(lb_gpu_comm *c, int64_t nq_max, int k_max);
 /* init_rank / init_host communicators: this rank's shard h, the same nq queries on every rank (device
  * pointer), global top-k on every rank.  Collective: every rank must call it with the same nq and k. */
 int lb_gpu_comm_search_device(lb_gpu_comm *c, lb_gpu_index *h, int64_t nq, const float *d_queries, int k, float *d_dist,
@@ -404,6 +410,12 @@ int lb_gpu_fill_codes_device(int device, uint8_t *d_dst, int64_t n, uint64_t see
  * a ring-partitioned corpus holds (bench.py) */
 int lb_gpu_fill_uniform_rows_device(int device, float *d_dst, const int64_t *d_ids, int64_t nrows, int dim, uint64_t seed,
                                     void *stream);
+
+/* Shader clock of `device` right now, in MHz: every CU spins for `spin_us` microseconds and compares its cycle counter
+ * (s_memtime) with the constant 100 MHz counter (s_memrealtime).  bench.py calls it straight behind its timed steps so a
+ * line says at which clock state it was measured (the same search runs 1.67-1.95 ms by clock state on one box).
+ * Returns a negative status code (-LB_ERR_*) on failure. */
+double lb_gpu_shader_clock_mhz(int device, int spin_us);
 
 /* ---- instrumentation (bench.py roofline leg) ----------------------------------------
  * HIP-event timing of the dominant kernels of the most recent search on this handle,

@@ -117,6 +117,7 @@ SIGNATURES = [
     ("lb_gpu_fill_uniform_device", _i, [_i, _vp, _i64, _u64, _i64, _vp]),
     ("lb_gpu_fill_codes_device", _i, [_i, _vp, _i64, _u64, _i64, _vp]),
     ("lb_gpu_fill_uniform_rows_device", _i, [_i, _vp, _vp, _i64, _i, _u64, _vp]),
+    ("lb_gpu_shader_clock_mhz", C.c_double, [_i, _i]),
     ("lb_flight_datasets_new", _vp, []),
     ("lb_flight_datasets_free", None, [_vp]),
     ("lb_flight_datasets_put", _i, [_vp, C.c_char_p, _vp]),
@@ -129,6 +130,7 @@ SIGNATURES = [
     ("lb_gpu_comm_init_rank", _vp, [_i, _i, _i, _vp, _ip]),
     ("lb_gpu_comm_init_host", _vp, [_i, _i, _i, _vp, _vp, _ip]),
     ("lb_gpu_comm_free", None, [_vp]),
+    ("lb_gpu_comm_prepare", _i, [_vp, _i64, _i]),
     ("lb_gpu_comm_nranks", _i, [_vp]),
     ("lb_gpu_comm_rank", _i, [_vp]),
     ("lb_gpu_comm_last_error", C.c_char_p, [_vp]),

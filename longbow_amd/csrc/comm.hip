@@ -108,6 +108,7 @@ struct lb_gpu_comm {
     void *fn_ctx = nullptr;
     std::vector<Peer> peers;
     void *h_send = nullptr, *h_recv = nullptr; // pinned (host transport)
+    uint64_t *h_status = nullptr;              // pinned: this rank's status word on its way into the packed block
     size_t h_send_bytes = 0, h_recv_bytes = 0;
     std::mutex mu; // one search at a time per communicator (a collective is an ordered sequence)
     std::string last_error;
@@ -255,12 +256,57 @@ void lb_gpu_comm_free(lb_gpu_comm *c)
     for (auto &p : c->peers) free_peer(p);
     if (c->h_send) (void)hipHostFree(c->h_send);
     if (c->h_recv) (void)hipHostFree(c->h_recv);
+    if (c->h_status) (void)hipHostFree(c->h_status);
     delete c;
 }
 
 int lb_gpu_comm_nranks(const lb_gpu_comm *c) { return c ? c->nranks : 0; }
 int lb_gpu_comm_rank(const lb_gpu_comm *c) { return c ? c->rank : -1; }
 const char *lb_gpu_comm_last_error(const lb_gpu_comm *c) { return c ? c->last_error.c_str() : "null handle"; }
+
+// pinned host blocks of the host transport, sized for a block of `bs` bytes per rank
+static void ensure_host_blocks(lb_gpu_comm *c, size_t bs)
+{
+    if (c->h_send_bytes < bs) {
+        if (c->h_send) (void)hipHostFree(c->h_send);
+        c->h_send = nullptr;
+        c->h_send_bytes = 0;
+        LB_HIP(hipHostMalloc(&c->h_send, bs, hipHostMallocDefault));
+        c->h_send_bytes = bs;
+    }
+    if (c->h_recv_bytes < bs * (size_t)c->nranks) {
+        if (c->h_recv) (void)hipHostFree(c->h_recv);
+        c->h_recv = nullptr;
+        c->h_recv_bytes = 0;
+        LB_HIP(hipHostMalloc(&c->h_recv, bs * (size_t)c->nranks, hipHostMallocDefault));
+        c->h_recv_bytes = bs * (size_t)c->nranks;
+    }
+}
+
+int lb_gpu_comm_prepare(lb_gpu_comm *c, int64_t nq_max, int k_max)
+{
+    if (!c || nq_max <= 0 || k_max <= 0) return LB_ERR_INVALID_ARG;
+    if (k_max > 2048 || (int64_t)c->nranks * k_max > 16384) return LB_ERR_UNSUPPORTED;
+    if (nq_max > ((int64_t)1 << 32) / k_max) return LB_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    try {
+        const size_t bs = block_bytes(nq_max, k_max) + kStatusBytes;
+        for (size_t i = 0; i < c->peers.size(); i++) {
+            Peer &p = c->peers[i];
+            LB_HIP(hipSetDevice(p.device));
+            ensure_blocks(p, (c->mode == 2 && i != 0) ? 1 : c->nranks, nq_max, k_max);
+        }
+        if (c->mode == 1) ensure_host_blocks(c, bs);
+        if (!c->h_status) LB_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_status), sizeof(uint64_t), hipHostMallocDefault));
+    } catch (const HipErr &e) {
+        (void)hipGetLastError();
+        c->last_error = std::string("HIP error in ") + e.what + " (lb_gpu_comm_prepare)";
+        return e.e == hipErrorOutOfMemory ? LB_ERR_OOM : LB_ERR_HIP;
+    } catch (...) {
+        return LB_ERR_INTERNAL;
+    }
+    return LB_OK;
+}
 
 int lb_gpu_comm_search_device(lb_gpu_comm *c, lb_gpu_index *h, int64_t nq, const float *d_queries, int k, float *d_dist,
                               int64_t *d_labels, void *stream)
@@ -280,13 +326,15 @@ int lb_gpu_comm_search_device(lb_gpu_comm *c, lb_gpu_index *h, int64_t nq, const
         hipStream_t s = stream ? (hipStream_t)stream : p.stream;
         const int64_t nk = nq * k;
         const size_t bb = block_bytes(nq, k), bs = bb + kStatusBytes;
-        try {
+        try { // (no-ops after lb_gpu_comm_prepare with this size: nothing below allocates before the exchange)
             ensure_blocks(p, c->nranks, nq, k);
+            if (c->mode == 1 && c->nranks > 1) ensure_host_blocks(c, bs);
+            if (!c->h_status) LB_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_status), sizeof(uint64_t), hipHostMallocDefault));
         } catch (const HipErr &e) {
-            // no room for the exchange buffers: this rank cannot take part at all.  The peers' all-gather will
-            // fail or time out at the transport level; nothing here can repair that.
+            // no room for the exchange buffers of a search larger than what lb_gpu_comm_prepare sized: this rank cannot take
+            // part at all.  The peers' all-gather will fail or time out at the transport level; nothing here can repair that.
             (void)hipGetLastError();
-            c->last_error = std::string("HIP error in ") + e.what + " (exchange buffers)";
+            c->last_error = std::string("HIP error in ") + e.what + " (exchange buffers: call lb_gpu_comm_prepare after init)";
             return e.e == hipErrorOutOfMemory ? LB_ERR_OOM : LB_ERR_HIP;
         }
         char *mine = static_cast<char *>(p.d_mine);
@@ -298,28 +346,14 @@ int lb_gpu_comm_search_device(lb_gpu_comm *c, lb_gpu_index *h, int64_t nq, const
             c->last_error = lb_gpu_last_error(h);
             launch_fill_empty(reinterpret_cast<float *>(mine + nk * 8), reinterpret_cast<int64_t *>(mine), nk, s);
         }
-        const uint64_t status = (uint64_t)(uint32_t)local_rc;
-        LB_HIP(hipMemcpyAsync(mine + bb, &status, sizeof status, hipMemcpyHostToDevice, s));
+        *c->h_status = (uint64_t)(uint32_t)local_rc; // (pinned word: the copy below stages nothing)
+        LB_HIP(hipMemcpyAsync(mine + bb, c->h_status, sizeof(uint64_t), hipMemcpyHostToDevice, s));
         if (c->nranks == 1) {
             LB_HIP(hipMemcpyAsync(p.d_all, p.d_mine, bs, hipMemcpyDeviceToDevice, s));
         } else if (c->mode == 0) { // RCCL over xGMI: the one exchange step of the path
             const int nrc = rccl().AllGather(p.d_mine, p.d_all, bs, kNcclChar, p.comm, s);
             if (nrc != kNcclSuccess) { set_err(c, "ncclAllGather", nrc); return LB_ERR_HIP; }
         } else { // host transport: D2H, the host's all-gather, H2D
-            if (c->h_send_bytes < bs) {
-                if (c->h_send) (void)hipHostFree(c->h_send);
-                c->h_send = nullptr;
-                c->h_send_bytes = 0;
-                LB_HIP(hipHostMalloc(&c->h_send, bs, hipHostMallocDefault));
-                c->h_send_bytes = bs;
-            }
-            if (c->h_recv_bytes < bs * c->nranks) {
-                if (c->h_recv) (void)hipHostFree(c->h_recv);
-                c->h_recv = nullptr;
-                c->h_recv_bytes = 0;
-                LB_HIP(hipHostMalloc(&c->h_recv, bs * c->nranks, hipHostMallocDefault));
-                c->h_recv_bytes = bs * c->nranks;
-            }
             LB_HIP(hipMemcpyAsync(c->h_send, p.d_mine, bs, hipMemcpyDeviceToHost, s));
             LB_HIP(hipStreamSynchronize(s));
             const int frc = c->fn(c->fn_ctx, c->h_send, c->h_recv, bs);

@@ -260,6 +260,7 @@ struct lb_gpu_index {
     int64_t xh_rows = 0, xh_cap = 0;
     std::atomic<int> xh_mode{1}; // lb_gpu_index_set_f16_image: 0 never, 1 when it pays and fits
     bool xh_failed = false;      // an allocation was refused: not tried again for this handle
+    bool xh_shed = false;        // the copy was given back to let an Add through: retaken only with twice the margin free
     // data whose neighbours the candidate keys cannot separate (tight clusters): batched searches start with the widened
     // candidate list that proved the last such batch, for the next kc_hint_left searches (search_batch_device)
     std::atomic<int> kc_hint{0}, kc_hint_left{0};
@@ -829,6 +830,8 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     };
     if (!use_narrow && (route.split == 1 || route.split == 2)) split_queries(); // the tall / wide split kernels take the batch as an image
     float *d_qinv = nullptr;
+    static const int riders_max = lb_tunable("LB_NORM_RIDERS_MAXQ", 384);
+    const bool prep_riders = sp.on && nq <= riders_max; // (cosine: the exact query norms come out of the threshold launch)
     if (use_tall16) { // fp16 image of the batch (scaled per query) + the inverse scales
         const size_t img = (((size_t)nq * (size_t)((h->dim + 31) & ~31) * 2) + 255) & ~(size_t)255, need = img + (size_t)nq * sizeof(float);
         if (w->d_qh_bytes < need) {
@@ -840,7 +843,10 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         }
         d_qinv = reinterpret_cast<float *>(static_cast<char *>(w->d_qh) + img);
         // one launch: the image, the scales, the exact query norms (cosine) and the reset of the candidate state
-        launch_query_prep(d_q, nq, h->dim, w->d_qh, d_qinv, metric == LB_METRIC_COSINE ? w->d_qna : nullptr, order, w->cs, s);
+        // (the exact norm is a serial chain of D additions, 3.5 us at 768: up to 384 queries it rides in the threshold launch
+        // instead, where nothing waits for it)
+        launch_query_prep(d_q, nq, h->dim, w->d_qh, d_qinv, (metric == LB_METRIC_COSINE && !prep_riders) ? w->d_qna : nullptr, order,
+                          w->cs, s);
     }
     if (!use_narrow && route.split == 1) {
         gx = h->d_Xs;
@@ -853,17 +859,17 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     // over the fp16 copy the sample goes through the persistent kernel itself: 512 granules of 16 consecutive rows, evenly
     // spaced over the span (whole KiB of the K-blocked image; every workgroup takes a share of them)
     static const bool granule_on = lb_tunable("LB_GRANULE_SAMPLE", 1) != 0;
-    const bool granule_sample = sp.on && use_tall16 && have_xh && granule_on && sp.count % 16 == 0;
+    // (up to 8 queries the wave-per-row kernel over the f32 rows is 5 us quicker: every load of a row in flight at once)
     static const int light_max = lb_tunable("LB_LIGHT_SAMPLE_MAXQ", 8);
+    const bool granule_sample = sp.on && use_tall16 && have_xh && granule_on && sp.count % 16 == 0 && nq > light_max;
     const bool light_sample = sp.on && !fused && !granule_sample && nq <= light_max;
-    static const int riders_max = lb_tunable("LB_NORM_RIDERS_MAXQ", 384);
-    const bool norm_riders = sp.on && nq <= riders_max && metric == LB_METRIC_COSINE && !use_tall16; // (fp16 route: query_prep)
+    const bool norm_riders = prep_riders && metric == LB_METRIC_COSINE;
     // the last launch: key-space pruning + exact re-rank + proof in one (kernels_finish.hip); beta: how far beyond one error
     // bound the cut lies (the proof itself never depends on it)
     static const bool use_finish = lb_tunable("LB_FINISH", 1) != 0;
     static const float finish_beta = 0.01f * (float)lb_tunable("LB_FINISH_BETA_PCT", 25);
     if (!light_sample && !fused && !use_tall16) launch_init_cand(w->cs, nullptr, nq, s);
-    if (metric == LB_METRIC_COSINE && !norm_riders && !use_tall16) launch_query_norms(order, d_q, nullptr, nq, h->dim, w->d_qna, s);
+    if (metric == LB_METRIC_COSINE && !norm_riders && !use_tall16) launch_query_norms(order, d_q, nullptr, nq, h->dim, w->d_qna, s); // (fp16 route: query_prep)
     static const bool sample_narrow = lb_tunable("LB_TALL_SAMPLE_NARROW", 1) != 0;
     // (fp16 route, several 256-query tiles: the sample goes through the fp16 kernel itself -- 32 row tiles x nq/256 workgroups
     // against nq/64 x 64 of the narrow tile; 1024 queries: 1.94 -> 1.88 ms, 512: 1.015 -> 1.00; tools/probe/sample_route_probe.py)
@@ -878,10 +884,12 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         else if (use_tall16 && h->dim % 32 != 0 && (rowmap || mask))
             // the sample of a search over the fp16 copy when the dimension is not a multiple of 32: the f32 tile takes any
             launch_gemm_filter(metric, h->d_X, h->d_norm2, h->d_rnorm, b, e, h->dim, d_q, nq, mask, rowmap, w->cs, boot, 0, s);
-        else if (use_tall && boot && (wsplit == 2 || wsplit == 3) && sample_narrow && h->dim % 32 == 0 &&
+        else if (use_tall && boot && (wsplit == 2 || wsplit == 3) && sample_narrow && narrow_ok &&
                  !(use_tall16 && nq > sample_narrow_maxq))
             // the 8192-row sample of a tall-tile search: the 64-query tile of the narrow kernel (same contraction, f32
             // operands) gets through its 24 K-steps of 32 in 31-35 us, the tall tile through its 48 of 16 in 57
+            // (narrow_ok: that kernel reads the f32 queries in 16-B pieces -- a batch pointer that is not 16-B aligned stays
+            // on the fp16 kernel below, which reads its own image of the batch)
             launch_gemm_filter_narrow(metric, h->d_X, h->d_norm2, h->d_rnorm, b, e, h->dim, d_q, nq, mask, rowmap, w->cs,
                                       true, s, /*tile64=*/true, /*split=*/true);
         else if (use_tall16)
@@ -911,12 +919,12 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         } else if (granule_sample) {
             {
                 ctx_check(w->ctx);
-                ProfScope p(w, s, prof, 0);
+                ProfScope p(w, s, prof, 1); // (timing class "select": threshold work, so that class "gemm" is the corpus pass alone)
                 launch_gemm_filter_tall16(metric, h->d_X, h->d_norm2, h->d_rnorm, 0, sp.count, h->dim, w->d_qh, d_qinv, nq, nullptr,
                                           nullptr, w->cs, /*boot=*/true, s, h->d_Xh, h->xh_cap, (uint32_t)(sp.span / (int64_t)(sp.count / 16)));
             }
             ProfScope p(w, s, prof, 1);
-            launch_sample_tau(w->cs, nullptr, nq, sp.count, sp.m, false, s);
+            launch_sample_tau(w->cs, nullptr, nq, sp.count, sp.m, false, s, d_q, h->dim, norm_riders ? w->d_qna : nullptr, order);
         } else {
             {
                 std::lock_guard<std::mutex> g(h->smap_mu);
@@ -1055,6 +1063,22 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         scan_with_retry(h, w, s, d_q, nq, bad, k, d_dist, d_lab, prof);
     }
     return LB_OK;
+}
+
+// one wave per CU spins for `ticks` of the constant 100 MHz counter and adds (shader cycles, ticks) to out[0 .. 1]
+__global__ void clock_probe_kernel(unsigned long long *out, unsigned long long ticks)
+{
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < ticks) {
+        __builtin_amdgcn_s_sleep(8);
+        r1 = __builtin_amdgcn_s_memrealtime();
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) {
+        atomicAdd(&out[0], c1 - c0);
+        atomicAdd(&out[1], r1 - r0);
+    }
 }
 
 __global__ void fill_empty_kernel(float *dist, int64_t *lab, int64_t n)
@@ -1215,6 +1239,34 @@ int grow(lb_gpu_index *h, int64_t need)
 void sync_split_image(lb_gpu_index *h);
 void sync_f16_image(lb_gpu_index *h);
 
+// grow(), giving the accelerator copies back first when the device is full.  The fp16 copy (half the corpus's bytes again)
+// and the split-bf16 image (all of them again) only speed searches up; the rows are the index.  An Add / reserve that runs
+// out of memory while either is resident frees them and tries once more before it reports LB_ERR_OOM; the copy is then
+// taken again only when twice the usual margin is free (sync_f16_image), so an index at the edge does not rebuild it per Add.
+int grow_or_shed(lb_gpu_index *h, int64_t need)
+{
+    try {
+        return grow(h, need);
+    } catch (const HipErr &e) {
+        if (e.e != hipErrorOutOfMemory || (!h->d_Xh && !h->d_Xs)) throw;
+        (void)hipGetLastError();
+        if (h->d_Xh) {
+            (void)hipFree(h->d_Xh);
+            h->d_Xh = nullptr;
+            h->xh_rows = h->xh_cap = 0;
+            h->xh_shed = true;
+        }
+        if (h->d_Xs) { // (the explicit split-image mode cannot be kept: back to the default routes)
+            (void)hipFree(h->d_Xs);
+            h->d_Xs = nullptr;
+            h->xs_rows = 0;
+            h->cand_mode.store(LB_CAND_AUTO);
+        }
+        buf_pool().trim(h->device);
+        return grow(h, need);
+    }
+}
+
 // Recompute the visible-row list from d_mask (caller holds the exclusive lock).  The list is used
 // by searches when at most LB_ROWMAP_MAX_PCT % of the corpus is visible (default 95; measured on
 // 1.25M x 1536: time scales with the visible fraction all the way up -- 8.6 ms unfiltered, 7.8 ms at
@@ -1343,7 +1395,7 @@ void sync_f16_image(lb_gpu_index *h)
             const size_t need = (size_t)h->capacity * (size_t)((h->dim + 31) & ~31) * 2; // (planes of 32 dimensions, the last zero-padded)
             size_t fr = 0, tot = 0;
             LB_HIP(hipMemGetInfo(&fr, &tot));
-            const size_t keep = std::max<size_t>((size_t)2 << 30, tot / 16);
+            const size_t keep = std::max<size_t>((size_t)2 << 30, tot / 16) * (h->xh_shed ? 2 : 1);
             if (fr < need + keep) return; // (not remembered: memory may be free again at the next Add)
             if (hipMalloc(&h->d_Xh, need) != hipSuccess) {
                 (void)hipGetLastError();
@@ -1579,7 +1631,7 @@ int lb_gpu_index_set_f16_image(lb_gpu_index *h, int mode)
         if (h->closed) return LB_ERR_CLOSED;
         if (hipSetDevice(h->device) != hipSuccess) { (void)hipGetLastError(); return LB_ERR_HIP; }
         h->xh_mode.store(mode);
-        if (mode) h->xh_failed = false;
+        if (mode) h->xh_failed = h->xh_shed = false;
         sync_f16_image(h);
     } catch (...) {
         return LB_ERR_INTERNAL;
@@ -1610,7 +1662,7 @@ int lb_gpu_index_reserve(lb_gpu_index *h, int64_t n_total)
     if (h->closed) return LB_ERR_CLOSED;
     try {
         LB_HIP(hipSetDevice(h->device));
-        return grow(h, n_total);
+        return grow_or_shed(h, n_total);
     } catch (const HipErr &e) {
         return fail_hip(h, e);
     }
@@ -1625,7 +1677,7 @@ int lb_gpu_index_add(lb_gpu_index *h, int64_t n, const float *vectors, const int
     if (h->n + n > (int64_t)0xffffffffll) { h->set_error("more than 2^32 rows per device"); return LB_ERR_UNSUPPORTED; }
     try {
         LB_HIP(hipSetDevice(h->device));
-        grow(h, h->n + n);
+        grow_or_shed(h, h->n + n);
         for (int i = 0; i < 2; i++) {
             if (!h->h_stage[i]) LB_HIP(hipHostMalloc(&h->h_stage[i], kStageBytes, hipHostMallocDefault));
             if (!h->stage_ev[i]) LB_HIP(hipEventCreateWithFlags(&h->stage_ev[i], hipEventDisableTiming));
@@ -1682,7 +1734,7 @@ int lb_gpu_index_add_device(lb_gpu_index *h, int64_t n, const float *d_vectors, 
     if (h->n + n > (int64_t)0xffffffffll) { h->set_error("more than 2^32 rows per device"); return LB_ERR_UNSUPPORTED; }
     try {
         LB_HIP(hipSetDevice(h->device));
-        grow(h, h->n + n);
+        grow_or_shed(h, h->n + n);
         LB_HIP(hipMemcpyAsync(h->d_X + (size_t)h->n * h->dim, d_vectors, (size_t)n * h->dim * sizeof(float),
                               hipMemcpyDeviceToDevice, h->add_stream));
         finish_add(h, n, d_ids, true);
@@ -2260,6 +2312,32 @@ int lb_gpu_fill_uniform_rows_device(int device, float *d_dst, const int64_t *d_i
     launch_fill_uniform_rows(d_dst, d_ids, nrows, dim, seed, (hipStream_t)stream);
     if (hipGetLastError() != hipSuccess) return LB_ERR_HIP;
     return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? LB_OK : LB_ERR_HIP;
+}
+
+double lb_gpu_shader_clock_mhz(int device, int spin_us)
+{
+    if (spin_us <= 0 || spin_us > 1000000) return -(double)LB_ERR_INVALID_ARG;
+    if (!device_ok(device)) return -(double)LB_ERR_NO_DEVICE;
+    try {
+        LB_HIP(hipSetDevice(device));
+        int cus = 0;
+        LB_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+        if (cus <= 0) cus = 1;
+        Lease d(device, 2 * sizeof(unsigned long long)), hbuf(device, 2 * sizeof(unsigned long long), true);
+        LB_HIP(hipMemset(d.p, 0, 2 * sizeof(unsigned long long)));
+        hipLaunchKernelGGL(clock_probe_kernel, dim3((unsigned)cus), dim3(64), 0, nullptr, d.as<unsigned long long>(),
+                           (unsigned long long)spin_us * 100ull);
+        LB_LAUNCH_CHECK();
+        LB_HIP(hipMemcpy(hbuf.p, d.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        const unsigned long long *v = hbuf.as<unsigned long long>();
+        if (v[1] == 0) return -(double)LB_ERR_INTERNAL;
+        return 100.0 * (double)v[0] / (double)v[1];
+    } catch (const HipErr &e) {
+        (void)hipGetLastError();
+        return -(double)(e.e == hipErrorOutOfMemory ? LB_ERR_OOM : LB_ERR_HIP);
+    } catch (...) {
+        return -(double)LB_ERR_INTERNAL;
+    }
 }
 
 int lb_gpu_fill_codes_device(int device, uint8_t *d_dst, int64_t n, uint64_t seed, int64_t offset, void *stream)

@@ -241,12 +241,12 @@ __global__ __launch_bounds__(FN_THREADS) void finish_kernel(FinishArgs a)
     const uint64_t *list = a.cs.lists + (size_t)qi * a.cs.cap;
     uint32_t flags = raw > a.cs.cap ? 1u : 0u;
 
-    auto emit = [&](uint32_t nsorted, uint32_t fl) { // the sorted prefix skey[0 .. nsorted) -> the query's k results
+    auto emit = [&](const uint64_t *sorted, uint32_t nsorted, uint32_t fl) { // the sorted prefix -> the query's k results
         for (int r = tid; r < k; r += FN_THREADS) {
             float d = FLT_MAX;
             int64_t lab = -1;
             if ((uint32_t)r < nsorted) {
-                const uint64_t en = skey[r];
+                const uint64_t en = sorted[r];
                 d = entry_key(en);
                 const uint32_t row = entry_row(en);
                 lab = a.ids ? a.ids[row] : (int64_t)row;
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(FN_THREADS) void finish_kernel(FinishArgs a)
         }
     };
     if (n == 0) { // nothing was admitted: an empty view -- or a threshold that was too tight (the query is redone)
-        if (g == 0) emit(0u, tau != kEntryMax ? 4u : 0u);
+        if (g == 0) emit(skey, 0u, tau != kEntryMax ? 4u : 0u);
         return;
     }
 
@@ -374,34 +374,58 @@ __global__ __launch_bounds__(FN_THREADS) void finish_kernel(FinishArgs a)
                 __syncthreads();
                 if (d0 + FN_SD < D) load_stage(d0 + FN_SD);
                 if (worker) {
+                    // the chains are serial (one addition per element, in order), so what can be hidden is the LDS latency:
+                    // 32 elements' reads are issued together, then their 32 chain steps run (one read + wait per group of
+                    // four cost 17 us per 768-float row instead of 3)
                     const int nel = min(D, d0 + FN_SD) - d0;
                     const float *xr = &tile[myr * FN_LD16];
                     if (QUAD) {
-#pragma unroll 8
-                        for (int el = myt; el < nel; el += 4) {
-                            const float xv = xr[el], qv = qs[el];
-                            if (METRIC == METRIC_COS) b0 = b0 + xv * xv;
-                            if (METRIC == METRIC_L2) {
-                                const float d = qv - xv;
-                                a0 = a0 + d * d;
-                            } else {
-                                a0 = a0 + qv * xv;
+                        const int mine_n = (nel - myt + 3) >> 2; // elements myt, myt + 4, ...
+                        for (int j0 = 0; j0 < mine_n; j0 += 16) {
+                            float xv[16], qv[16];
+#pragma unroll
+                            for (int u = 0; u < 16; u++) {
+                                const int el = myt + 4 * (j0 + u < mine_n ? j0 + u : mine_n - 1);
+                                xv[u] = xr[el];
+                                qv[u] = qs[el];
+                            }
+#pragma unroll
+                            for (int u = 0; u < 16; u++) {
+                                if (j0 + u < mine_n) {
+                                    if (METRIC == METRIC_COS) b0 = b0 + xv[u] * xv[u];
+                                    if (METRIC == METRIC_L2) {
+                                        const float d = qv[u] - xv[u];
+                                        a0 = a0 + d * d;
+                                    } else {
+                                        a0 = a0 + qv[u] * xv[u];
+                                    }
+                                }
                             }
                         }
                     } else {
-#pragma unroll 4
-                        for (int gq = 0; gq < (nel >> 2); gq++) {
-                            const f32x4 xv = *reinterpret_cast<const f32x4 *>(&xr[gq * 4]);
-                            const f32x4 qv = *reinterpret_cast<const f32x4 *>(&qs[gq * 4]);
-                            const float xe4[4] = {xv.x, xv.y, xv.z, xv.w}, qe4[4] = {qv.x, qv.y, qv.z, qv.w};
+                        const int ng = nel >> 2;
+                        for (int g0 = 0; g0 < ng; g0 += 8) {
+                            f32x4 xv[8], qv[8];
 #pragma unroll
-                            for (int u = 0; u < 4; u++) {
-                                if (METRIC == METRIC_COS) b0 = b0 + xe4[u] * xe4[u];
-                                if (METRIC == METRIC_L2) {
-                                    const float d = qe4[u] - xe4[u];
-                                    a0 = a0 + d * d;
-                                } else {
-                                    a0 = a0 + qe4[u] * xe4[u];
+                            for (int u = 0; u < 8; u++) {
+                                const int gq = g0 + u < ng ? g0 + u : ng - 1;
+                                xv[u] = *reinterpret_cast<const f32x4 *>(&xr[gq * 4]);
+                                qv[u] = *reinterpret_cast<const f32x4 *>(&qs[gq * 4]);
+                            }
+#pragma unroll
+                            for (int u = 0; u < 8; u++) {
+                                if (g0 + u < ng) {
+                                    const float xe4[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w}, qe4[4] = {qv[u].x, qv[u].y, qv[u].z, qv[u].w};
+#pragma unroll
+                                    for (int c4 = 0; c4 < 4; c4++) {
+                                        if (METRIC == METRIC_COS) b0 = b0 + xe4[c4] * xe4[c4];
+                                        if (METRIC == METRIC_L2) {
+                                            const float d = qe4[c4] - xe4[c4];
+                                            a0 = a0 + d * d;
+                                        } else {
+                                            a0 = a0 + qe4[c4] * xe4[c4];
+                                        }
+                                    }
                                 }
                             }
                         }
@@ -548,14 +572,30 @@ __global__ __launch_bounds__(FN_THREADS) void finish_kernel(FinishArgs a)
     } else if (nm_raw > smax) {
         flags |= 2u;
     }
-    const uint32_t P = next_pow2(ns > 0 ? ns : 1);
-    for (uint32_t c = ns + tid; c < P; c += FN_THREADS) {
-        skey[c] = kEntryMax;
-        scmp[c] = FLT_MAX;
-    }
+    // order the members by (distance, row).  Up to 512: every thread ranks two entries against all (broadcast LDS reads, no
+    // barrier per stage: 2 us where the 45 stages of a bitonic sort take 4.5) and scatters them; beyond: bitonic sort.
+    const uint64_t *sorted = skey;
     if (tid == 0) scal[3] = 0;
-    __syncthreads();
-    bitonic_sort_u64(skey, P, tid, FN_THREADS);
+    if (ns <= 512u) {
+        uint64_t *srt = reinterpret_cast<uint64_t *>(s_rows); // (the row list is not needed any more; smax >= 1024: 4 KB)
+        __syncthreads();
+        const uint64_t e0 = (uint32_t)tid < ns ? skey[tid] : kEntryMax, e1 = (uint32_t)tid + 256u < ns ? skey[tid + 256] : kEntryMax;
+        uint32_t r0 = 0, r1 = 0;
+        for (uint32_t j = 0; j < ns; j++) {
+            const uint64_t ej = skey[j];
+            r0 += ej < e0 ? 1u : 0u;
+            r1 += ej < e1 ? 1u : 0u;
+        }
+        if ((uint32_t)tid < ns) srt[r0] = e0; // (entries are unique: the ranks are a permutation)
+        if ((uint32_t)tid + 256u < ns) srt[r1] = e1;
+        sorted = srt;
+        __syncthreads();
+    } else {
+        const uint32_t P = next_pow2(ns);
+        for (uint32_t c = ns + tid; c < P; c += FN_THREADS) skey[c] = kEntryMax;
+        __syncthreads();
+        bitonic_sort_u64(skey, P, tid, FN_THREADS);
+    }
 
     // ---- proof --------------------------------------------------------------------------------------------------------
     if (!complete) {
@@ -569,7 +609,7 @@ __global__ __launch_bounds__(FN_THREADS) void finish_kernel(FinishArgs a)
         const bool skip = METRIC == METRIC_COS && na == 0.0f; // (every distance is exactly 1.0: selection by row is exact)
         if (METRIC == METRIC_L2) {
             const uint32_t kx = (ns < (uint32_t)k ? ns : (uint32_t)k);
-            dk = kx > 0 ? entry_key(skey[kx - 1]) : FLT_MAX;
+            dk = kx > 0 ? entry_key(sorted[kx - 1]) : FLT_MAX;
         }
         const float slack = out_slack<METRIC>(cutf, dk, nq2, nqn, xmax, ga, go);
         if (METRIC == METRIC_L2) T = (cutf + nq2) - slack;
@@ -584,7 +624,7 @@ __global__ __launch_bounds__(FN_THREADS) void finish_kernel(FinishArgs a)
         __syncthreads();
         if (!skip && scal[3] < (unsigned int)k) flags |= 2u;
     }
-    emit(ns, flags);
+    emit(sorted, ns, flags);
 }
 
 } // namespace

@@ -265,6 +265,15 @@ class CommSearcher:
             _lib.check(st.value or 7)
         self._h = C.c_void_p(h)
 
+    def prepare(self, nq_max, k_max):
+        """size the exchange buffers for searches of up to nq_max queries / k_max results (lb_gpu_comm_prepare).  Not a
+        collective: call it on every rank right after construction and agree on the outcome BEFORE the first search -- a
+        search within the prepared size allocates nothing between the shard search and the all-gather, so a rank that
+        runs out of memory cannot strand its peers there."""
+        rc = self._lib.lb_gpu_comm_prepare(self._h, int(nq_max), int(k_max))
+        if rc != 0:
+            raise _lib.LongbowGPUError(rc, (self._lib.lb_gpu_comm_last_error(self._h) or b"").decode())
+
     def search(self, queries, k):
         """queries: [nq, dim] float32 CUDA tensor, identical on all ranks -> (labels, dist) CUDA tensors"""
         t = self.torch

@@ -423,3 +423,86 @@ def test_searches_during_adds_see_a_whole_prefix_of_the_corpus(oracle):
     assert_same(lab, dist, *prefix[nchunks], "after the last Add")
     assert len(seen) >= 2, seen  # the readers did overlap the writer
     idx.Close()
+
+
+@pytest.mark.parametrize("nq", [16, 256])
+def test_query_batch_that_is_not_16_byte_aligned(oracle, nq):
+    """round-3 advisor: with the fp16 copy present the fp16 route is offered to a device batch whose pointer is only 4-byte
+    aligned (dim % 32 == 0); every launch of such a search must read the queries through paths that take any pointer"""
+    gpu_or_skip()
+    import torch
+    from longbow_amd import gpu
+    rng = np.random.default_rng(77)
+    n, d, k = 300_000, 64, 10
+    X = rng.random((n, d), dtype=F)
+    Q = rng.random((nq, d), dtype=F)
+    for metric in (0, 1):
+        idx = new_index(d, metric)
+        idx.Add(None, X)
+        assert idx.f16_image_bytes > 0
+        dev = torch.device("cuda", 0)
+        flat = torch.zeros(nq * d + 8, dtype=torch.float32, device=dev)
+        qv = flat[1:1 + nq * d]  # 4 bytes past a 16-byte boundary
+        qv.copy_(torch.from_numpy(Q.reshape(-1)).to(dev))
+        assert qv.data_ptr() % 16 == 4
+        od = torch.empty((nq, k), device=dev)
+        ol = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        idx.search_device(nq, qv.data_ptr(), k, od.data_ptr(), ol.data_ptr())
+        oi, odist = oracle.search_batch(metric, Q, X, k, nthreads=8)
+        assert np.array_equal(ol.cpu().numpy(), oi) and np.array_equal(od.cpu().numpy(), odist), (metric, nq)
+        idx.Close()
+
+
+def test_add_sheds_the_fp16_copy_when_the_device_is_full(oracle):
+    """round-3 advisor: the fp16 copy of the corpus (half the corpus's bytes again) only speeds searches up.  An Add that
+    runs out of device memory while the copy is resident must give the copy back and go through; searches stay exact
+    (they stage the f32 rows), and the copy is not rebuilt while the device is that full."""
+    gpu_or_skip()
+    import torch
+    dev = torch.device("cuda", 0)
+    d, n0 = 1024, 1_000_000
+    idx = new_index(d, 1)
+    idx.reserve(n0)
+    buf = torch.empty((250_000, d), device=dev)
+    from longbow_amd import _lib
+    lib = _lib.require_gpu(0)
+    for r0 in range(0, n0, 250_000):
+        _lib.check(lib.lb_gpu_fill_uniform_device(0, buf.data_ptr(), buf.numel(), 12345, r0 * d, None))
+        idx.add_device(250_000, buf.data_ptr())
+    copy = idx.f16_image_bytes
+    assert copy >= n0 * d * 2
+    q = torch.empty((40, d), device=dev)
+    _lib.check(lib.lb_gpu_fill_uniform_device(0, q.data_ptr(), q.numel(), 42, 0, None))
+    od = torch.empty((40, 10), device=dev)
+    ol = torch.empty((40, 10), dtype=torch.int64, device=dev)
+    idx.search_device(40, q.data_ptr(), 10, od.data_ptr(), ol.data_ptr())
+    want_l, want_d = ol.cpu().numpy().copy(), od.cpu().numpy().copy()
+    # somebody else fills the device: less than the next Add needs is left, more than it needs once the copy is gone
+    torch.cuda.empty_cache()
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    add_rows = 250_000                       # 1 GB of rows
+    leave = 256 << 20
+    blocker = torch.empty(free_b - leave, dtype=torch.uint8, device=dev)
+    try:
+        _lib.check(lib.lb_gpu_fill_uniform_device(0, buf.data_ptr(), buf.numel(), 12345, n0 * d, None))
+        idx.add_device(add_rows, buf.data_ptr())          # grows past the reservation: needs ~1 GB, 256 MB are free
+        assert idx.ntotal == n0 + add_rows
+        assert idx.f16_image_bytes == 0                    # the copy went, the rows stayed
+        idx.search_device(40, q.data_ptr(), 10, od.data_ptr(), ol.data_ptr())
+        # (the first n0 rows still answer the same wherever the new rows do not enter the lists: compare through the oracle
+        # on a few queries instead)
+    finally:
+        del blocker
+        torch.cuda.empty_cache()
+    # exactness after the shed: strict mode == default mode on the grown corpus, and the old answers are a subset relation
+    idx.search_device(40, q.data_ptr(), 10, od.data_ptr(), ol.data_ptr())
+    got_l, got_d = ol.cpu().numpy().copy(), od.cpu().numpy().copy()
+    idx.set_candidate_mode(0)
+    idx.search_device(40, q.data_ptr(), 10, od.data_ptr(), ol.data_ptr())
+    assert np.array_equal(got_l, ol.cpu().numpy()) and np.array_equal(got_d, od.cpu().numpy())
+    for i in range(40):  # rows of the first million that are still in a list keep their distance
+        old = dict(zip(want_l[i].tolist(), want_d[i].tolist()))
+        for lab, dist in zip(got_l[i].tolist(), got_d[i].tolist()):
+            if lab < n0:
+                assert lab in old and old[lab] == dist
+    idx.Close()
