@@ -455,11 +455,9 @@ std::atomic<int> g_last_route{0}; // diagnostic build: kind * 10 + split of the 
 std::atomic<int> g_search_fail_next{0}; // test hook (diagnostic build): the next search on this process fails with LB_ERR_INTERNAL
 // Add batches of at least this many bytes pin the caller's buffer instead of staging it (0 = never)
 std::atomic<long long> g_add_register_min{(long long)lb_tunable("LB_ADD_REGISTER_MIN_MB", 64) << 20};
-static SamplePlan sample_plan(int64_t n, int keep, uint32_t cap, uint32_t count_max = 8192u)
+static SamplePlan sample_plan_for(int64_t n, int keep, uint32_t cap, uint32_t count)
 {
     SamplePlan p;
-    if (!g_sample_tau.load() || n < 65536) return p;
-    const uint32_t count = std::min<uint32_t>(cap, count_max);
     int m = 8;
     int64_t span = 0;
     for (int it = 0; it < 8; it++) {
@@ -470,7 +468,7 @@ static SamplePlan sample_plan(int64_t n, int keep, uint32_t cap, uint32_t count_
         const int need = (int)std::ceil(lambda + 5.0 * std::sqrt(lambda) + 4.0);
         if (need <= m) break;
         m = need;
-        if (m > 64) return p; // (sample_tau_kernel: m rounds of a workgroup-wide minimum, m <= 64)
+        if (m > 64) return p; // (sample_tau_kernel: m pops of a minimum, m <= 64)
     }
     if (span < 8 * (int64_t)count || !sample_tau_supported(count, m)) return p;
     p.on = true;
@@ -478,6 +476,21 @@ static SamplePlan sample_plan(int64_t n, int keep, uint32_t cap, uint32_t count_
     p.count = count;
     p.m = m;
     return p;
+}
+static SamplePlan sample_plan(int64_t n, int keep, uint32_t cap, uint32_t count_max = 8192u)
+{
+    if (!g_sample_tau.load() || n < 65536 || (uint32_t)keep >= cap) return SamplePlan{};
+    // the largest sample whose threshold rank stays within the kernel's reach and whose span covers the view: a small view
+    // (a selective filter) or a long candidate list (large k) takes a smaller sample -- a sample that is a large share of
+    // the rows would need its several-hundredth smallest entry
+    SamplePlan best;
+    for (uint32_t count = std::min<uint32_t>(cap, count_max); count >= 1024u; count >>= 1) {
+        const SamplePlan p = sample_plan_for(n, keep, cap, count);
+        if (!p.on) continue;
+        if (!best.on || p.span > best.span) best = p;
+        if (p.span >= n) break;
+    }
+    return best;
 }
 
 // Exact scan of all rows for the query slots sel[0..nsel) (indices into d_q rows).
@@ -692,7 +705,8 @@ static Route choose_route(int nq, int64_t n, int D, int cmode, bool narrow_ok, b
     static const int f16_on = lb_tunable("LB_F16", 1);
     // (over the fp16 copy the route needs neither dim % 32 == 0 nor aligned queries: both images are zero-padded planes)
     if ((narrow_ok || have_f16_image) && f16_ok && f16_on && !image && (nq > 32 || have_f16_image) &&
-        (cmode == LB_CAND_F16 || (cmode == LB_CAND_AUTO && n >= 262144))) { // (below: launch overheads decide, and the narrow tiles win)
+        (cmode == LB_CAND_F16 || (cmode == LB_CAND_AUTO && (n >= 262144 || (have_f16_image && n * (int64_t)D >= ((int64_t)128 << 20))))))
+    { // (below: launch overheads decide, and the narrow tiles win; a filtered view of a large corpus counts by its elements)
         if (have_f16_image && nq <= 128) { // (one query tile: the 64- / 128-query form of the persistent kernel)
             // + what the route pays per query beside the stream: twice (beyond 1024 dimensions four times) the candidates to
             // select and re-rank
@@ -747,8 +761,9 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     // rows with inf / NaN components: the MFMA pipeline's keys and error bounds assume finite data;
     // the scan path orders non-finite distances canonically (NaN last)
     const int cmode = h->cand_mode.load();
-    // (the fp16 image serves unfiltered searches: under a filter the kernel gathers f32 rows)
-    const bool have_xh = h->d_Xh != nullptr && h->xh_rows == h->n && !rv.rowmap && !mask;
+    // (the fp16 image serves unfiltered searches and searches over a row list -- the persistent kernels gather out of it,
+    // dimensions from 256; under a per-row mask test the kernel stages f32 rows)
+    const bool have_xh = h->d_Xh != nullptr && h->xh_rows == h->n && !mask && (!rv.rowmap || h->dim >= 256);
     // 1 .. 4 queries: the exact scan streams the f32 corpus (0.52 ms per 1M x 768); with the fp16 copy the candidate pass
     // streams half the bytes and the exact re-rank of 512 candidates costs 0.03 ms -- taken when the model says it is cheaper
     bool small_on_copy = false;
@@ -792,7 +807,11 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         kc_in = std::max(kc_in, std::min(h->kc_hint.load(std::memory_order_relaxed), (int)(w->cap / 4)));
     }
     int kc = kc_in;
-    if (route.split == 3) kc = std::min(kc_in * (f16_kc_mult > 0 ? f16_kc_mult : (h->dim > 1024 ? 4 : 2)), (int)(w->cap / 4));
+    // (since the finish launch prunes in key space, kc only sizes the admission threshold: the list must hold the rows within
+    // the error bound of the k-th key -- 2-4 k of them with fp16 keys -- not a fixed number of rows to re-rank; capped so that
+    // a sampled threshold of that depth still exists)
+    if (route.split == 3)
+        kc = std::min(std::min(kc_in * (f16_kc_mult > 0 ? f16_kc_mult : (h->dim > 1024 ? 4 : 2)), std::max(1024, 2 * kc_in)), (int)(w->cap / 4));
     const SamplePlan sp = sample_plan(n, kc, w->cap);
     // up to 8 queries the sample is scored by the wave-per-row kernel (candidate keys; 22-28 us against
     // 44 us for 8192 rows through the 32-workgroup MFMA launch); larger batches sample through the MFMA
@@ -856,12 +875,17 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     // in kernels_gemm_narrow.hip: 19-34 us of sample + 13 us of threshold kernel off the critical path).
     static const int fused_max = lb_tunable("LB_FUSED_SAMPLE_MAXQ", 32); // (33-64 queries, the 64-query tile: measured level)
     const bool fused = sp.on && use_narrow && nsplit && nq <= fused_max && nq <= 64;
+    // a search over a row list on the persistent fp16 kernels: its candidate entries carry positions of the list
+    const bool entries_pos = use_tall16 && rv.rowmap != nullptr &&
+                             tall16_entries_are_positions(h->dim, nq, have_xh, true, mask != nullptr);
     // over the fp16 copy the sample goes through the persistent kernel itself: 512 granules of 16 consecutive rows, evenly
     // spaced over the span (whole KiB of the K-blocked image; every workgroup takes a share of them)
     static const bool granule_on = lb_tunable("LB_GRANULE_SAMPLE", 1) != 0;
     // (up to 8 queries the wave-per-row kernel over the f32 rows is 5 us quicker: every load of a row in flight at once)
-    static const int light_max = lb_tunable("LB_LIGHT_SAMPLE_MAXQ", 8);
-    const bool granule_sample = sp.on && use_tall16 && have_xh && granule_on && sp.count % 16 == 0 && nq > light_max;
+    static const int light_max = lb_tunable("LB_LIGHT_SAMPLE_MAXQ", 8); // (also over a row list: at 32 queries the wave-per-row
+                                                                        // kernel took 105 us against the granule sample's 40)
+    const bool granule_sample = sp.on && use_tall16 && have_xh && granule_on && sp.count % 16 == 0 && nq > light_max &&
+                                (rv.rowmap == nullptr || entries_pos);
     const bool light_sample = sp.on && !fused && !granule_sample && nq <= light_max;
     const bool norm_riders = prep_riders && metric == LB_METRIC_COSINE;
     // the last launch: key-space pruning + exact re-rank + proof in one (kernels_finish.hip); beta: how far beyond one error
@@ -881,10 +905,10 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         if (use_narrow)
             launch_gemm_filter_narrow(metric, gx, h->d_norm2, h->d_rnorm, b, e, h->dim, gq, nq, mask, rowmap,
                                       w->cs, boot, s, tile64, nsplit);
-        else if (use_tall16 && h->dim % 32 != 0 && (rowmap || mask))
+        else if (use_tall16 && h->dim % 32 != 0 && (rowmap || mask) && !entries_pos)
             // the sample of a search over the fp16 copy when the dimension is not a multiple of 32: the f32 tile takes any
             launch_gemm_filter(metric, h->d_X, h->d_norm2, h->d_rnorm, b, e, h->dim, d_q, nq, mask, rowmap, w->cs, boot, 0, s);
-        else if (use_tall && boot && (wsplit == 2 || wsplit == 3) && sample_narrow && narrow_ok &&
+        else if (use_tall && boot && (wsplit == 2 || wsplit == 3) && sample_narrow && narrow_ok && !entries_pos &&
                  !(use_tall16 && nq > sample_narrow_maxq))
             // the 8192-row sample of a tall-tile search: the 64-query tile of the narrow kernel (same contraction, f32
             // operands) gets through its 24 K-steps of 32 in 31-35 us, the tall tile through its 48 of 16 in 57
@@ -921,7 +945,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
                 ctx_check(w->ctx);
                 ProfScope p(w, s, prof, 1); // (timing class "select": threshold work, so that class "gemm" is the corpus pass alone)
                 launch_gemm_filter_tall16(metric, h->d_X, h->d_norm2, h->d_rnorm, 0, sp.count, h->dim, w->d_qh, d_qinv, nq, nullptr,
-                                          nullptr, w->cs, /*boot=*/true, s, h->d_Xh, h->xh_cap, (uint32_t)(sp.span / (int64_t)(sp.count / 16)));
+                                          rv.rowmap, w->cs, /*boot=*/true, s, h->d_Xh, h->xh_cap, (uint32_t)(sp.span / (int64_t)(sp.count / 16)));
             }
             ProfScope p(w, s, prof, 1);
             launch_sample_tau(w->cs, nullptr, nq, sp.count, sp.m, false, s, d_q, h->dim, norm_riders ? w->d_qna : nullptr, order);
@@ -999,7 +1023,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
             // members a query may have: twice the results wanted, at least 1024 (the lists hold up to cap entries below tau)
             const uint32_t smax = std::min<uint32_t>(kFinishSmaxMax, std::max<uint32_t>(1024u, 2u * next_pow2_host((uint32_t)k)));
             launch_finish(metric, order, h->d_X, h->dim, d_q, nq, w->d_qna, w->cs, k, h->d_maxnorm2, gamma, finish_beta,
-                          h->has_ids ? h->d_ids : nullptr, nullptr, d_dist, d_lab, s, w->h_flags, w->d_done, w->d_xcnt,
+                          h->has_ids ? h->d_ids : nullptr, entries_pos ? rv.rowmap : nullptr, d_dist, d_lab, s, w->h_flags, w->d_done, w->d_xcnt,
                           w->d_xscratch, kFinishSplitMaxQ, smax);
         } else {
             launch_rerank(metric, order, h->d_X, h->dim, d_q, nq, w->d_qna, w->cs, kc, k, h->d_maxnorm2, gamma,
@@ -1392,7 +1416,8 @@ void sync_f16_image(lb_gpu_index *h)
             if (!want) return;
         }
         if (h->d_Xh == nullptr) {
-            const size_t need = (size_t)h->capacity * (size_t)((h->dim + 31) & ~31) * 2; // (planes of 32 dimensions, the last zero-padded)
+            const int pd = corpus_f16_plane_dims();
+            const size_t need = (size_t)h->capacity * (size_t)((h->dim + pd - 1) / pd * pd) * 2; // (whole planes, the last zero-padded)
             size_t fr = 0, tot = 0;
             LB_HIP(hipMemGetInfo(&fr, &tot));
             const size_t keep = std::max<size_t>((size_t)2 << 30, tot / 16) * (h->xh_shed ? 2 : 1);
@@ -1643,7 +1668,8 @@ int64_t lb_gpu_index_f16_image_bytes(const lb_gpu_index *h)
 {
     if (!h) return 0;
     std::shared_lock<std::shared_mutex> g(const_cast<lb_gpu_index *>(h)->mu); // (the copy is built and dropped under the writer lock)
-    return h->d_Xh ? (int64_t)h->xh_cap * ((h->dim + 31) & ~31) * 2 : 0;
+    const int pd = corpus_f16_plane_dims();
+    return h->d_Xh ? (int64_t)h->xh_cap * ((h->dim + pd - 1) / pd * pd) * 2 : 0;
 }
 
 int64_t lb_gpu_index_ntotal(const lb_gpu_index *h)

@@ -59,6 +59,7 @@ struct FinishArgs {
     uint32_t *xcnt;   // [nq] members written to the scratch block (zero between launches)
     uint64_t *xent;   // [nq][smax] exact entries
     float *xcmp;      // [nq][smax] compare values
+    int abl;          // diagnostic build: timing-only ablations (1 = no gather / exact sums, 2 = no radix select, 3 = return at once)
 };
 
 // exactly `need` (>= 1) of the real entries held in registers are <= the returned pivot (entries are unique).
@@ -235,6 +236,9 @@ __global__ __launch_bounds__(FN_THREADS) void finish_kernel(FinishArgs a)
     float *scmp = reinterpret_cast<float *>(skey + smax);      // [smax] compare values
     float *work = scmp + smax;                                 // the scoring scheme's tile
 
+#ifdef LB_DIAG
+    if (a.abl == 3) return;
+#endif
     const uint32_t raw = a.cs.cnt[qi];
     const uint32_t n = raw < a.cs.cap ? raw : a.cs.cap;
     const uint64_t tau = a.cs.tau[qi];
@@ -288,7 +292,11 @@ __global__ __launch_bounds__(FN_THREADS) void finish_kernel(FinishArgs a)
     const float nqn = sqrtf(nq2) * (1.000002f + go);         // >= the real |q| (nq2 is an f32 sum in some order)
 
     const uint32_t kk = n < (uint32_t)k ? n : (uint32_t)k;
+#ifdef LB_DIAG
+    const uint64_t pivot = a.abl == 2 ? (e[0] | 0xffffffffull) : radix_kth_regs<PER>(e, kk, hist, wsum, scal, red, tid);
+#else
     const uint64_t pivot = radix_kth_regs<PER>(e, kk, hist, wsum, scal, red, tid);
+#endif
 
     // ---- the cut ------------------------------------------------------------------------------------------------------
     const float ga = a.gamma;
@@ -335,6 +343,14 @@ __global__ __launch_bounds__(FN_THREADS) void finish_kernel(FinishArgs a)
     if (a.posmap) __syncthreads();
 
     // ---- exact values of the members: skey[c], scmp[c], c < nm --------------------------------------------------------
+#ifdef LB_DIAG
+    if (a.abl == 1) {
+        for (uint32_t c = tid; c < nm; c += FN_THREADS) {
+            skey[c] = pack_entry(0.f, s_rows[c]);
+            scmp[c] = 0.f;
+        }
+    } else
+#endif
     if (!a.aligned) {
         for (uint32_t c = tid; c < nm; c += FN_THREADS) {
             float dist, cmp;
@@ -642,6 +658,7 @@ void launch_finish(int metric, int order, const float *X, int D, const float *Q,
     a.X = X; a.D = D; a.Q = Q; a.qna = qna; a.cs = cs; a.k = k; a.maxnorm2 = d_maxnorm2; a.gamma = gamma; a.beta = beta;
     a.ids = ids; a.posmap = posmap; a.out_dist = out_dist; a.out_labels = out_labels; a.flags_host = flags_host;
     a.smax = smax; a.done = done; a.xcnt = xcnt;
+    a.abl = lb_tunable("LB_FINISH_ABL", 0);
     a.xent = reinterpret_cast<uint64_t *>(xscratch);
     a.xcmp = reinterpret_cast<float *>(a.xent + (size_t)nq_split_max * smax);
     a.aligned = (D % 4 == 0) && D >= 4 && ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && ((reinterpret_cast<uintptr_t>(Q) & 15) == 0);

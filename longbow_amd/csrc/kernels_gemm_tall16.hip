@@ -45,6 +45,20 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 namespace {
 
 constexpr int H_BM = 256, H_BN = 256, H_BK = 32;
+// The corpus image is blocked in planes of H_XP dimensions: [Dp / H_XP][cap][H_XP] fp16.  H_XP = 32 (the K-step): the 64 B a
+// K-step needs of 16 consecutive rows are one KiB of whole lines.  H_XP = 64 (a row's piece = one whole 128-B line, the two
+// K-steps of a plane taking half each) was built for row lists -- HBM is fetched in whole lines, so a filtered view pays for
+// the neighbouring row's half -- and measured (round 4, 1.25M x 1536, 10 % visible): the gather pass 119 -> 94 us at 32
+// queries, 234 -> 216 at 256, but the UNFILTERED stream 234 -> 339 us per 1M x 768 (half-line requests under the
+// non-temporal policy fetch every line twice).  Not worth it: 32 stays; -DLB_XH_PLANE=64 rebuilds the other.
+#ifndef LB_XH_PLANE
+#define LB_XH_PLANE 32
+#endif
+constexpr int H_XP = LB_XH_PLANE, H_XROW = H_XP * 2, H_KPP = H_XP / H_BK; // plane dims, bytes of a row's piece, K-steps per plane
+__device__ __forceinline__ int64_t h_xoff(int ke, int64_t plane_bytes) // byte offset of K-step ke within a row's pieces
+{
+    return H_KPP == 1 ? ke * plane_bytes : (int64_t)(ke / H_KPP) * plane_bytes + (ke % H_KPP) * (H_BK * 2);
+}
 constexpr int H_THREADS = 512;
 constexpr int H_A_BYTES = H_BM * H_BK * 4;            // 32 KB: corpus rows as f32
 constexpr int H_B_BYTES = H_BN * H_BK * 2;            // 16 KB: query rows as fp16
@@ -75,7 +89,7 @@ struct Tall16Args {
     int boot;
     int abl; // diagnostic build: timing-only ablations of the persistent form (6 = no epilogue, 7 = no flush)
     int rot; // persistent form: the query tiles of a corpus tile walk K rotated by rot K-steps against each other
-    const _Float16 *Xh; // or null: fp16 image of the corpus, K-blocked [D / 32][xh_cap][32] (index.hip: sync_f16_image)
+    const _Float16 *Xh; // or null: fp16 image of the corpus, [Dp / H_XP][xh_cap][H_XP] (index.hip: sync_f16_image)
     int64_t xh_cap;     // rows per K-block plane of Xh
     uint32_t gstride;   // persistent forms, sample pass: 0 = position p is row row_begin + p; else the positions are granules of 16
                         // consecutive rows, granule j starting at row row_begin + j * gstride (an evenly spaced sample whose
@@ -483,7 +497,8 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16_kernel(Tall16
 // a third more time for a line that four CUs ask for at once to arrive.  The image is K-blocked like the
 // query image: the 64 B a K-step needs of 16 consecutive rows are one KiB of whole lines.
 // BOOT: the launch stores every position's entry (bootstrap chunk of the classic schedule, or -- gstride != 0 -- the sample pass)
-template <int METRIC, bool NT, bool AIMG, bool BOOT>
+// MAPPED: a filtered view -- the positions index a.rowmap; see the one-tile form below for how the kernel gathers
+template <int METRIC, bool NT, bool AIMG, bool BOOT, bool MAPPED = false>
 __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall16Args a, int spx)
 {
     constexpr int NST = AIMG ? 4 : 3;                       // ring stages
@@ -519,24 +534,43 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
     const uint32_t gstride = BOOT ? a.gstride : 0u;
     const unsigned char *Xb = reinterpret_cast<const unsigned char *>(a.X + a.row_begin * (int64_t)a.D);
     const int64_t row_bytes = (int64_t)a.D * 4;
-    const float *auxg = METRIC == METRIC_L2 ? a.norm2 + a.row_begin : (METRIC == METRIC_COS ? a.rnorm + a.row_begin : nullptr);
+    const float *auxg = METRIC == METRIC_L2 ? a.norm2 + (MAPPED ? 0 : a.row_begin) : (METRIC == METRIC_COS ? a.rnorm + (MAPPED ? 0 : a.row_begin) : nullptr);
     auto rt_of = [&](int i) { return (uint32_t)((group + gpx * i) * 8 + xcd) * H_BM; }; // first position of tile i
+    // MAPPED: row ids of three tiles, [3][512] (every wave asks for 64: entries 256 .. 511 repeat 0 .. 255, as the side inputs do)
+    const uint32_t *s_rowid = reinterpret_cast<const uint32_t *>(s_auxp + 2 * 512);
+    const uint32_t rowid_base = aux_base + 4096u;
+    auto rowid_request = [&](int t) {
+        uint32_t pos = rt_of(t) + (uint32_t)((wave & 3) * 64 + lane);
+        if (pos > last_pos) pos = last_pos;
+        uint32_t save;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(save) : "v"(a.rowmap + a.row_begin + h_rowof(pos, gstride)),
+                       "s"(__builtin_amdgcn_readfirstlane((int)(rowid_base + (uint32_t)(t % 3) * 2048u + (uint32_t)wave * 256u))));
+    };
 
     // request sources.  Corpus: request i < 4 of this wave fills local rows 32 wave + 8 i .. + 7 (lane l: row l / 8, chunk
     // position l % 8) -- from the image: request i < 2 fills rows 32 wave + 16 i .. + 15 (lane l: row l / 4, chunk position
     // l % 4, the query tile's layout); recomputed when the request cursor enters a tile.  Queries: fixed for the workgroup.
     const unsigned char *srcA[4], *srcB[2];
-    const unsigned char *Xhb = reinterpret_cast<const unsigned char *>(a.Xh) + a.row_begin * (int64_t)(H_BK * 2);
-    const int64_t plane_bytes = a.xh_cap * (int64_t)(H_BK * 2);
-    auto set_srcA = [&](uint32_t rt) {
+    const unsigned char *Xhb = reinterpret_cast<const unsigned char *>(a.Xh) + a.row_begin * (int64_t)H_XROW;
+    const int64_t plane_bytes = a.xh_cap * (int64_t)H_XROW;
+    auto set_srcA = [&](int t) { // request sources of tile t
+        const uint32_t rt = rt_of(t);
+        if (MAPPED) asm volatile("" ::: "memory"); // (the ids below were written by LDS-DMA: no read of them may be hoisted)
 #pragma unroll
         for (int i = 0; i < NPA; i++) {
             const int row = AIMG ? wave * 32 + i * 16 + (lane >> 2) : wave * 32 + i * 8 + (lane >> 3);
             const int c = AIMG ? (lane & 3) ^ ((row >> 2) & 3) : (lane & 7) ^ ((row >> 1) & 7);
-            uint32_t pos = rt + (uint32_t)row;
-            if (pos > last_pos) pos = last_pos;
-            pos = h_rowof(pos, gstride);
-            srcA[i] = AIMG ? Xhb + (int64_t)pos * (H_BK * 2) + 16 * c : Xb + (int64_t)pos * row_bytes + 16 * c;
+            if (MAPPED) {
+                const int64_t rid = (int64_t)s_rowid[(t % 3) * 512 + row];
+                srcA[i] = AIMG ? reinterpret_cast<const unsigned char *>(a.Xh) + rid * H_XROW + 16 * c
+                               : reinterpret_cast<const unsigned char *>(a.X) + rid * row_bytes + 16 * c;
+            } else {
+                uint32_t pos = rt + (uint32_t)row;
+                if (pos > last_pos) pos = last_pos;
+                pos = h_rowof(pos, gstride);
+                srcA[i] = AIMG ? Xhb + (int64_t)pos * H_XROW + 16 * c : Xb + (int64_t)pos * row_bytes + 16 * c;
+            }
         }
     };
 #pragma unroll
@@ -559,7 +593,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
         const uint32_t B = ring_base + (uint32_t)islot * STAGE + A_BYTES + (uint32_t)(wave * 32 * 64);
         int ke = ik + krot; // (the sum over k does not care where it starts)
         if (ke >= nk) ke -= nk;
-        if (p < NPA) h_dma16<NT>(srcA[p] + (AIMG ? ke * plane_bytes : (int64_t)ke * (H_BK * 4)), A + 1024u * p);
+        if (p < NPA) h_dma16<NT>(srcA[p] + (AIMG ? h_xoff(ke, plane_bytes) : (int64_t)ke * (H_BK * 4)), A + 1024u * p);
         else h_dma16<false>(srcB[p - NPA] + ke * kb_stride, B + 1024u * (p - NPA));
     };
     auto advance = [&]() { // (beyond the last stage the cursor stays on it)
@@ -571,16 +605,34 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
         if (METRIC == METRIC_DOT) return;
         uint32_t pos = rt_of(i) + (uint32_t)((wave & 3) * 64 + lane);
         if (pos > last_pos) pos = last_pos;
+        uint32_t src_row = h_rowof(pos, gstride);
+        if (MAPPED) {
+            asm volatile("" ::: "memory");
+            src_row = s_rowid[(i % 3) * 512 + (wave & 3) * 64 + lane];
+        }
         uint32_t save;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(save) : "v"(auxg + h_rowof(pos, gstride)), "s"(__builtin_amdgcn_readfirstlane((int)(aux_base + (uint32_t)(i & 1) * 2048u + (uint32_t)wave * 256u))));
+                     : "=&s"(save) : "v"(auxg + src_row), "s"(__builtin_amdgcn_readfirstlane((int)(aux_base + (uint32_t)(i & 1) * 2048u + (uint32_t)wave * 256u))));
+    };
+    // the cursor has entered tile `it`: its request sources, and (MAPPED) the ids of the tile after it
+    auto enter_tile = [&]() {
+        set_srcA(it);
+        if (MAPPED && it + 1 < n_my) rowid_request(it + 1);
+        cursor_new_tile = false;
     };
 
-    set_srcA(rt_of(0));
+    if (MAPPED) { // the ids of the first two tiles, once, before anything depends on them
+        rowid_request(0);
+        if (n_my > 1) rowid_request(1);
+        h_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    set_srcA(0);
     aux_request(0);
 #pragma unroll
     for (int st = 0; st < DIST; st++) { // the first DIST stages
-        if (cursor_new_tile) { set_srcA(rt_of(it)); cursor_new_tile = false; }
+        if (cursor_new_tile) enter_tile();
 #pragma unroll
         for (int p = 0; p < NPS; p++) piece(p);
         advance();
@@ -604,8 +656,9 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
         tkc[tn] = METRIC == METRIC_L2 ? tk : tk * scale;
     }
     // admission segments: what is left of the LDS beside the ring (3.2 KB per wave with the fp16 copy, 1.2 KB without)
-    constexpr uint32_t WCAP = AIMG ? 272 : 104, WFLUSH = AIMG ? 176 : 60, SEG_BYTES = WCAP * 12;
-    uint32_t *s_flag = reinterpret_cast<uint32_t *>(s_auxp + 2 * 512);              // [3] "somebody wants a flush", by tile % 3
+    // (MAPPED: the row-id ring takes 6 KB of it -- only built over the image)
+    constexpr uint32_t WCAP = AIMG ? (MAPPED ? 208 : 272) : 104, WFLUSH = AIMG ? (MAPPED ? 136 : 176) : 60, SEG_BYTES = WCAP * 12;
+    uint32_t *s_flag = reinterpret_cast<uint32_t *>(s_auxp + 2 * 512 + (MAPPED ? 3 * 512 : 0)); // [3] "somebody wants a flush", by tile % 3
     uint32_t *s_qn = s_flag + 4;                                                    // [H_BN] entries per query in the flush ...
     uint32_t *s_qb = s_qn + H_BN;                                                   // [H_BN] ... and where they start in its list
     unsigned char *seg = reinterpret_cast<unsigned char *>(s_qb + H_BN) + wave * SEG_BYTES;
@@ -681,7 +734,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
             }
             f16x8 a1[2], b1[4];
             if (PIPE) load_frag(cslot, 1, a1, b1); // (visible since the barrier in the middle of the step before)
-            if (cursor_new_tile) { set_srcA(rt_of(it)); cursor_new_tile = false; }
+            if (cursor_new_tile) enter_tile();
             // side input of the next tile: its buffer was last read in the epilogue a tile ago, and a barrier of THIS tile lies
             // between that and the request (one K-step per tile: only the barrier in the middle of the step does)
             const bool aux_now = i + 1 < n_my && kt == (nk > 1 ? 1 : 0);
@@ -839,7 +892,13 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
 // at BN = 64 -- lanes 0 .. 31 --, one at 128, two at 256); a stage is 16 KB + 4 / 8 / 16 KB, the ring SIX / FIVE / FOUR stages
 // deep (48-80 KB of corpus in flight per CU), loads non-temporal (every line is read once).  1M x 768: the image is 1.5 GB,
 // the pass 0.24-0.3 ms where the f32 rows take 0.49.
-template <int METRIC, int BN, bool BOOT>
+// MAPPED: the positions index a.rowmap (the visible rows of a filtered view, ascending) -- the kernel gathers: the row ids of a
+// tile come in by their own LDS-DMA request one tile ahead of the request cursor (a ring of three tiles: a plain load inside
+// the loop would make the compiler wait for vmcnt(0) and drain the stage ring), the corpus pieces and the side inputs are then
+// requested at rowmap[position]; candidate entries carry POSITIONS (the finish launch maps them to rows: posmap).  Needs at
+// least DIST + 3 K-steps per tile (the launcher checks), so that a tile's ids are older than everything the counted waits
+// leave in flight by the time they are read.
+template <int METRIC, int BN, bool BOOT, bool MAPPED>
 __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tall16Args a, int spx)
 {
     constexpr int TN = BN / 32;
@@ -866,20 +925,37 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
     const int last_q = a.nq - 1;
     const uint32_t last_pos = hi - 1;
     const uint32_t gstride = BOOT ? a.gstride : 0u;
-    const float *auxg = METRIC == METRIC_L2 ? a.norm2 + a.row_begin : (METRIC == METRIC_COS ? a.rnorm + a.row_begin : nullptr);
+    const float *auxg = METRIC == METRIC_L2 ? a.norm2 + (MAPPED ? 0 : a.row_begin) : (METRIC == METRIC_COS ? a.rnorm + (MAPPED ? 0 : a.row_begin) : nullptr);
     auto rt_of = [&](int i) { return lo + (uint32_t)i * H_BM; }; // first position of tile i
+    // MAPPED: row ids of three tiles, [3][512] (every wave asks for 64: entries 256 .. 511 repeat 0 .. 255, as the side inputs do)
+    const uint32_t *s_rowid = reinterpret_cast<const uint32_t *>(s_auxp + 2 * 512);
+    const uint32_t rowid_base = aux_base + 4096u;
+    auto rowid_request = [&](int t) {
+        uint32_t pos = rt_of(t) + (uint32_t)((wave & 3) * 64 + lane);
+        if (pos > last_pos) pos = last_pos;
+        uint32_t save;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(save) : "v"(a.rowmap + a.row_begin + h_rowof(pos, gstride)),
+                       "s"(__builtin_amdgcn_readfirstlane((int)(rowid_base + (uint32_t)(t % 3) * 2048u + (uint32_t)wave * 256u))));
+    };
 
     const unsigned char *srcA[2], *srcB[NPB];
-    const unsigned char *Xhb = reinterpret_cast<const unsigned char *>(a.Xh) + a.row_begin * (int64_t)(H_BK * 2);
-    const int64_t plane_bytes = a.xh_cap * (int64_t)(H_BK * 2);
-    auto set_srcA = [&](uint32_t rt) {
+    const unsigned char *Xhb = reinterpret_cast<const unsigned char *>(a.Xh) + a.row_begin * (int64_t)H_XROW;
+    const int64_t plane_bytes = a.xh_cap * (int64_t)H_XROW;
+    auto set_srcA = [&](int t) { // request sources of tile t
+        const uint32_t rt = rt_of(t);
+        if (MAPPED) asm volatile("" ::: "memory"); // (the ids below were written by LDS-DMA: no read of them may be hoisted)
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             const int row = wave * 32 + i * 16 + (lane >> 2);
             const int c = (lane & 3) ^ ((row >> 2) & 3);
-            uint32_t pos = rt + (uint32_t)row;
-            if (pos > last_pos) pos = last_pos;
-            srcA[i] = Xhb + (int64_t)h_rowof(pos, gstride) * (H_BK * 2) + 16 * c;
+            if (MAPPED) {
+                srcA[i] = reinterpret_cast<const unsigned char *>(a.Xh) + (int64_t)s_rowid[(t % 3) * 512 + row] * H_XROW + 16 * c;
+            } else {
+                uint32_t pos = rt + (uint32_t)row;
+                if (pos > last_pos) pos = last_pos;
+                srcA[i] = Xhb + (int64_t)h_rowof(pos, gstride) * H_XROW + 16 * c;
+            }
         }
     };
 #pragma unroll
@@ -898,7 +974,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
     auto piece = [&](int p) {
         const uint32_t A = ring_base + (uint32_t)islot * STAGE + (uint32_t)(wave * 32 * 64);
         const uint32_t B = ring_base + (uint32_t)islot * STAGE + A_BYTES + (uint32_t)(wave * (BN * 8));
-        if (p < 2) h_dma16<true>(srcA[p] + ik * plane_bytes, A + 1024u * p);
+        if (p < 2) h_dma16<true>(srcA[p] + h_xoff(ik, plane_bytes), A + 1024u * p);
         else if (BN != 64 || lane < 32) h_dma16<false>(srcB[p - 2] + ik * kb_stride, B + 1024u * (p - 2));
     };
     auto advance = [&]() {
@@ -910,16 +986,34 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
         if (METRIC == METRIC_DOT) return;
         uint32_t pos = rt_of(i) + (uint32_t)((wave & 3) * 64 + lane);
         if (pos > last_pos) pos = last_pos;
+        uint32_t src_row = h_rowof(pos, gstride);
+        if (MAPPED) {
+            asm volatile("" ::: "memory");
+            src_row = s_rowid[(i % 3) * 512 + (wave & 3) * 64 + lane];
+        }
         uint32_t save;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(save) : "v"(auxg + h_rowof(pos, gstride)), "s"(__builtin_amdgcn_readfirstlane((int)(aux_base + (uint32_t)(i & 1) * 2048u + (uint32_t)wave * 256u))));
+                     : "=&s"(save) : "v"(auxg + src_row), "s"(__builtin_amdgcn_readfirstlane((int)(aux_base + (uint32_t)(i & 1) * 2048u + (uint32_t)wave * 256u))));
+    };
+    // the cursor has entered tile `it`: its request sources, and (MAPPED) the ids of the tile after it
+    auto enter_tile = [&]() {
+        set_srcA(it);
+        if (MAPPED && it + 1 < n_my) rowid_request(it + 1);
+        cursor_new_tile = false;
     };
 
-    set_srcA(rt_of(0));
+    if (MAPPED) { // the ids of the first two tiles, once, before anything depends on them
+        rowid_request(0);
+        if (n_my > 1) rowid_request(1);
+        h_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    set_srcA(0);
     aux_request(0);
 #pragma unroll
     for (int st = 0; st < DIST; st++) {
-        if (cursor_new_tile) { set_srcA(rt_of(it)); cursor_new_tile = false; }
+        if (cursor_new_tile) enter_tile();
 #pragma unroll
         for (int p = 0; p < NPS; p++) piece(p);
         advance();
@@ -941,8 +1035,9 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
         if (a.abl == 8) tkc[tn] = -__builtin_huge_valf(); // timing only: nothing is admitted
 #endif
     }
-    constexpr uint32_t WCAP = BN == 256 ? 272 : 360, WFLUSH = BN == 256 ? 176 : 240, SEG_BYTES = WCAP * 12; // (what the ring leaves)
-    uint32_t *s_flag = reinterpret_cast<uint32_t *>(s_auxp + 2 * 512); // [3] "somebody wants a flush", by tile % 3 (see the 256-query form)
+    // (what the ring leaves; MAPPED: 6 KB less, the row-id ring)
+    constexpr uint32_t WCAP = BN == 256 ? 272 : (MAPPED ? 296 : 360), WFLUSH = BN == 256 ? 176 : (MAPPED ? 200 : 240), SEG_BYTES = WCAP * 12;
+    uint32_t *s_flag = reinterpret_cast<uint32_t *>(s_auxp + 2 * 512 + (MAPPED ? 3 * 512 : 0)); // [3] "somebody wants a flush", by tile % 3 (see the 256-query form)
     uint32_t *s_qn = s_flag + 4, *s_qb = s_qn + 256;
     unsigned char *seg = reinterpret_cast<unsigned char *>(s_qb + 256) + wave * SEG_BYTES;
     float *s_key = reinterpret_cast<float *>(seg);
@@ -987,7 +1082,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
             }
             f16x8 a1, b1[TN];
             if (PIPE) load_frag(cslot, 1, a1, b1);
-            if (cursor_new_tile) { set_srcA(rt_of(it)); cursor_new_tile = false; }
+            if (cursor_new_tile) enter_tile();
             const bool aux_now = i + 1 < n_my && kt == (nk > 1 ? 1 : 0); // (see the 256-query form)
             if (aux_now && !(PIPE && nk == 1)) aux_request(i + 1);
 #pragma unroll
@@ -1131,25 +1226,25 @@ __global__ __launch_bounds__(256) void queries_to_f16_kernel(const float *Q, int
     if (lane == 0) qinv[q] = inv;
 }
 
-// f32 corpus rows [row_begin, row_end) -> the K-blocked fp16 image Xh[D / 32][cap][32] (round to nearest even, the conversion the
-// kernels above apply in registers: both forms of the route see the same fp16 values).  One workgroup = 64 rows x one K-block:
-// whole 128-B lines in, 4 KB contiguous out.
+// f32 corpus rows [row_begin, row_end) -> the blocked fp16 image Xh[Dp / H_XP][cap][H_XP] (round to nearest even, the conversion
+// the kernels above apply in registers: both forms of the route see the same fp16 values; dimensions beyond D are zero).
+// One workgroup = 64 rows x 32 dimensions: whole 128-B lines in, 64-B pieces out.
 __global__ __launch_bounds__(256) void corpus_to_f16_kernel(const float *X, int64_t row_begin, int64_t row_end, int D, _Float16 *Xh, int64_t cap)
 {
     const int64_t row = row_begin + (int64_t)blockIdx.x * 64 + (threadIdx.x >> 2);
-    const int kb = blockIdx.y, q = threadIdx.x & 3;
+    const int kb = blockIdx.y, q = threadIdx.x & 3; // kb: block of 32 dimensions
     if (row >= row_end) return;
     const int k0 = kb * 32 + q * 8;
     f16x8 v;
     if (k0 + 8 <= D && (D & 3) == 0) { // (rows are 16-B aligned when D % 4 == 0)
         const f32x4 *src = reinterpret_cast<const f32x4 *>(X + row * (int64_t)D + k0);
         v = h_cvt8(src[0], src[1]);
-    } else { // the last K-block of a dimension that is not a multiple of 32 (zero beyond D), or unaligned rows
+    } else { // the last block of a dimension that is not a multiple of 32 (zero beyond D), or unaligned rows
         const float *src = X + row * (int64_t)D;
 #pragma unroll
         for (int e = 0; e < 8; e++) v[e] = k0 + e < D ? (_Float16)src[k0 + e] : (_Float16)0.f;
     }
-    *reinterpret_cast<f16x8 *>(Xh + ((int64_t)kb * cap + row) * 32 + q * 8) = v;
+    *reinterpret_cast<f16x8 *>(Xh + ((int64_t)(k0 / H_XP) * cap + row) * H_XP + (k0 % H_XP)) = v;
 }
 
 } // namespace
@@ -1165,10 +1260,12 @@ void read_tall16_probe(unsigned long long out[8], bool reset)
 }
 #endif
 
+int corpus_f16_plane_dims() { return H_XP; }
+
 void launch_corpus_to_f16(const float *X, int64_t row_begin, int64_t row_end, int D, void *Xh, int64_t cap, hipStream_t s)
 {
     if (row_end <= row_begin) return;
-    dim3 grid((unsigned)((row_end - row_begin + 63) / 64), (unsigned)((D + 31) / 32));
+    dim3 grid((unsigned)((row_end - row_begin + 63) / 64), (unsigned)(((D + H_XP - 1) / H_XP) * (H_XP / 32))); // (whole planes: zero padding)
     hipLaunchKernelGGL(corpus_to_f16_kernel, grid, dim3(256), 0, s, X, row_begin, row_end, D, reinterpret_cast<_Float16 *>(Xh), cap);
 }
 
@@ -1177,6 +1274,36 @@ void launch_queries_to_f16(const float *Q, int nq, int D, void *Qh, float *qinv,
     if (nq <= 0) return;
     hipLaunchKernelGGL(queries_to_f16_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, Q, nq, D,
                        reinterpret_cast<_Float16 *>(Qh), qinv);
+}
+
+// do the persistent kernels serve this launch (and, under a row list, leave POSITIONS in the candidate entries)?
+static bool tall16_persistent_ok(int D, int nq, bool img, bool mapped, bool masked)
+{
+    static const int persist = lb_tunable("LB_F16_PERSIST", 1);
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n;
+    }();
+    // (the persistent kernels take nearly all of a CU's 160 KB of LDS: on a device that offers a workgroup less, the
+    // one-workgroup-per-tile kernel serves everything)
+    static const int lds_max = [] {
+        int dev = 0, n = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMaxSharedMemoryPerBlock, dev);
+        return n;
+    }();
+    static const int mapped_on = lb_tunable("LB_F16_MAPPED", 1);
+    const int spx = cus / 8;
+    if (!persist || masked || spx < 1 || (nq + H_BN - 1) / H_BN > spx || lds_max < 163840) return false;
+    // a row list: gathered out of the image only, and with enough K-steps per tile for the row-id ring's hand-off (D >= 256)
+    if (mapped && !(img && mapped_on && (D + H_BK - 1) / H_BK >= 8)) return false;
+    return true;
+}
+bool tall16_entries_are_positions(int D, int nq, bool img, bool mapped, bool masked)
+{
+    return mapped && tall16_persistent_ok(D, nq, img, true, masked);
 }
 
 // Requires D % 32 == 0, 16-B aligned X / Qh; Qh / qinv from launch_queries_to_f16; X is the plain f32 corpus.
@@ -1202,8 +1329,8 @@ static void tall16_window(int metric, const float *X, const float *norm2, const 
     const int groups = (a.n_row_tiles + 7) / 8;
     dim3 grid((unsigned)(groups * 8 * a.n_q_tiles));
     const size_t shmem = (size_t)H_NST * H_STAGE_BYTES + H_BM * 4 + H_BM * 4 + H_BM;
-    // persistent form for unfiltered searches: one workgroup per CU (the ring leaves room for one), slots per XCD = CUs / 8
-    static const int persist = lb_tunable("LB_F16_PERSIST", 1);
+    // persistent form: one workgroup per CU (the ring leaves room for one), slots per XCD = CUs / 8; unfiltered searches, and
+    // (over the image) searches over a row list
     static const int cus = [] {
         int dev = 0, n = 0;
         (void)hipGetDevice(&dev);
@@ -1211,15 +1338,8 @@ static void tall16_window(int metric, const float *X, const float *norm2, const 
         return n;
     }();
     const int spx = cus / 8;
-    // (the persistent kernels take nearly all of a CU's 160 KB of LDS: on a device that offers a workgroup less, the
-    // one-workgroup-per-tile kernel below serves everything)
-    static const int lds_max = [] {
-        int dev = 0, n = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMaxSharedMemoryPerBlock, dev);
-        return n;
-    }();
-    if (persist && !rowmap && !mask && spx >= 1 && a.n_q_tiles <= spx && lds_max >= 163840) {
+    const bool mapped = rowmap != nullptr;
+    if (tall16_persistent_ok(D, nq, Xh != nullptr, mapped, mask != nullptr)) {
         const bool img = Xh != nullptr; // (sync_f16_image: in step with the corpus, K-blocked, xh_cap rows per plane)
         // A batch that ends 1 .. 64 queries into a 256-query tile: the whole tiles on the 256-wide kernel, the rest on the
         // one-tile kernel (a second pass over the image at its HBM rate, 0.24 ms per 1M x 768, instead of one more 256-wide
@@ -1251,26 +1371,32 @@ static void tall16_window(int metric, const float *X, const float *norm2, const 
             // ring, side inputs, flush flags + counters, admission segments
             const size_t nshmem = ring_b + 2 * 512 * sizeof(float) + 16 + 2 * 256 * 4 + 8 * (bn == 256 ? 272 : 360) * 12;
             dim3 ngrid((unsigned)(spx * 8));
-#define LB_NARROW16(M, N, B)                                                                                        \
-    do {                                                                                                            \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_filter_narrow16p_kernel<M, N, B>),           \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)nshmem);                         \
-        hipLaunchKernelGGL((gemm_filter_narrow16p_kernel<M, N, B>), ngrid, dim3(H_THREADS), nshmem, s, a, spx);     \
+#define LB_NARROW16(M, N, B, P)                                                                                        \
+    do {                                                                                                               \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_filter_narrow16p_kernel<M, N, B, P>),           \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)nshmem);                            \
+        hipLaunchKernelGGL((gemm_filter_narrow16p_kernel<M, N, B, P>), ngrid, dim3(H_THREADS), nshmem, s, a, spx);     \
     } while (0)
-#define LB_NARROW16_M(M)                                 \
-    do {                                                 \
-        if (boot) {                                      \
-            if (bn == 64) LB_NARROW16(M, 64, true);      \
-            else LB_NARROW16(M, 128, true);              \
-        } else {                                         \
-            if (bn == 64) LB_NARROW16(M, 64, false);     \
-            else LB_NARROW16(M, 128, false);             \
-        }                                                \
+#define LB_NARROW16_B(M, B, P)                       \
+    do {                                             \
+        if (bn == 64) LB_NARROW16(M, 64, B, P);      \
+        else LB_NARROW16(M, 128, B, P);              \
+    } while (0)
+#define LB_NARROW16_M(M)                                     \
+    do {                                                     \
+        if (mapped) {                                        \
+            if (boot) LB_NARROW16_B(M, true, true);          \
+            else LB_NARROW16_B(M, false, true);              \
+        } else {                                             \
+            if (boot) LB_NARROW16_B(M, true, false);         \
+            else LB_NARROW16_B(M, false, false);             \
+        }                                                    \
     } while (0)
             if (metric == METRIC_L2) LB_NARROW16_M(METRIC_L2);
             else if (metric == METRIC_COS) LB_NARROW16_M(METRIC_COS);
             else LB_NARROW16_M(METRIC_DOT);
 #undef LB_NARROW16_M
+#undef LB_NARROW16_B
 #undef LB_NARROW16
             return;
         }
@@ -1278,23 +1404,26 @@ static void tall16_window(int metric, const float *X, const float *norm2, const 
                               16 + 2 * H_BN * 4 + 8 * (img ? 272 : 104) * 12; // ring, side inputs, flush flags + counters, admission segments
         const bool pnt = a.n_q_tiles <= 1;
         dim3 pgrid((unsigned)(spx * 8));
-#define LB_TALL16P(M, N, I, B)                                                                                       \
-    do {                                                                                                             \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_filter_tall16p_kernel<M, N, I, B>),           \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)pshmem);                          \
-        hipLaunchKernelGGL((gemm_filter_tall16p_kernel<M, N, I, B>), pgrid, dim3(H_THREADS), pshmem, s, a, spx);     \
+#define LB_TALL16P(M, N, I, B, P)                                                                                       \
+    do {                                                                                                                \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_filter_tall16p_kernel<M, N, I, B, P>),           \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)pshmem);                             \
+        hipLaunchKernelGGL((gemm_filter_tall16p_kernel<M, N, I, B, P>), pgrid, dim3(H_THREADS), pshmem, s, a, spx);     \
     } while (0)
 #define LB_TALL16P_M(M)                                        \
     do {                                                       \
-        if (boot) { /* (a short launch: the cache policy does not matter) */ \
-            if (img) LB_TALL16P(M, false, true, true);         \
-            else LB_TALL16P(M, false, false, true);            \
+        if (mapped) { /* (only over the image; the corpus lines of a row list are not streamed: default cache policy) */ \
+            if (boot) LB_TALL16P(M, false, true, true, true);  \
+            else LB_TALL16P(M, false, true, false, true);      \
+        } else if (boot) { /* (a short launch: the cache policy does not matter) */ \
+            if (img) LB_TALL16P(M, false, true, true, false);  \
+            else LB_TALL16P(M, false, false, true, false);     \
         } else if (img) {                                      \
-            if (pnt) LB_TALL16P(M, true, true, false);         \
-            else LB_TALL16P(M, false, true, false);            \
+            if (pnt) LB_TALL16P(M, true, true, false, false);  \
+            else LB_TALL16P(M, false, true, false, false);     \
         } else {                                               \
-            if (pnt) LB_TALL16P(M, true, false, false);        \
-            else LB_TALL16P(M, false, false, false);           \
+            if (pnt) LB_TALL16P(M, true, false, false, false); \
+            else LB_TALL16P(M, false, false, false, false);    \
         }                                                      \
     } while (0)
         if (metric == METRIC_L2) LB_TALL16P_M(METRIC_L2);
@@ -1360,8 +1489,8 @@ void launch_gemm_filter_tall16(int metric, const float *X, const float *norm2, c
                                const uint32_t *rowmap, CandState cs, bool boot, hipStream_t s, const void *Xh, int64_t xh_cap,
                                uint32_t gstride)
 {
-    // (the granule-strided sample view exists in the persistent forms only: unfiltered, over the fp16 image or the f32 rows)
-    if (gstride != 0 && (rowmap || mask || !boot)) return;
+    // (the granule-strided sample view exists in the persistent forms only)
+    if (gstride != 0 && (!boot || !tall16_persistent_ok(D, nq, Xh != nullptr, rowmap != nullptr, mask != nullptr))) return;
     tall16_window(metric, X, norm2, rnorm, row_begin, row_end, D, Qh, qinv, nq, nq, mask, rowmap, cs, boot, s, Xh, xh_cap, true, gstride);
 }
 

@@ -203,7 +203,7 @@ void launch_queries_to_f16(const float *Q, int nq, int D, void *Qh, float *qinv,
 // the same image and scales, plus the exact ||q||^2 in `order` (qna, or null) and the reset of the queries' candidate state:
 // one launch for what a search over this route needs from its batch (kernels_scan.hip)
 void launch_query_prep(const float *Q, int nq, int D, void *Qh, float *qinv, float *qna, int order, CandState cs, hipStream_t s);
-// Xh (or null): the corpus's K-blocked fp16 image [D / 32][xh_cap][32] from launch_corpus_to_f16, in step with X; used by
+// Xh (or null): the corpus's K-blocked fp16 image [Dp / 32][xh_cap][32] from launch_corpus_to_f16, in step with X; used by
 // unfiltered searches (half the bytes to stage, a four-stage ring)
 void launch_gemm_filter_tall16(int metric, const float *X, const float *norm2, const float *rnorm, int64_t row_begin,
                                int64_t row_end, int D, const void *Qh, const float *qinv, int nq, const uint8_t *mask,
@@ -212,6 +212,10 @@ void launch_gemm_filter_tall16(int metric, const float *X, const float *norm2, c
                                uint32_t gstride = 0); // boot launches of the persistent forms: positions = granules of 16 rows,
                                                      // gstride rows apart (an evenly spaced sample read in whole KiB)
 void launch_corpus_to_f16(const float *X, int64_t row_begin, int64_t row_end, int D, void *Xh, int64_t cap, hipStream_t s);
+int corpus_f16_plane_dims(); // dimensions per plane of that image (its rows are zero-padded to a multiple of it)
+// under a row list (mapped) the persistent kernels gather out of the image and leave POSITIONS of the list in the candidate
+// entries (the finish launch maps them back: posmap); true when a launch with these parameters does so
+bool tall16_entries_are_positions(int D, int nq, bool img, bool mapped, bool masked);
 
 // per query: sort the list, keep the best kc, tau = kc-th entry (or max), flag overflow.
 // qsel (nullable): only these query slots.  boot_rows > 0: the list was filled by a bootstrap

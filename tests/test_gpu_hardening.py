@@ -483,17 +483,24 @@ def test_add_sheds_the_fp16_copy_when_the_device_is_full(oracle):
     add_rows = 250_000                       # 1 GB of rows
     leave = 256 << 20
     blocker = torch.empty(free_b - leave, dtype=torch.uint8, device=dev)
+    went_through = True
     try:
         _lib.check(lib.lb_gpu_fill_uniform_device(0, buf.data_ptr(), buf.numel(), 12345, n0 * d, None))
-        idx.add_device(add_rows, buf.data_ptr())          # grows past the reservation: needs ~1 GB, 256 MB are free
-        assert idx.ntotal == n0 + add_rows
-        assert idx.f16_image_bytes == 0                    # the copy went, the rows stayed
-        idx.search_device(40, q.data_ptr(), 10, od.data_ptr(), ol.data_ptr())
-        # (the first n0 rows still answer the same wherever the new rows do not enter the lists: compare through the oracle
-        # on a few queries instead)
+        try:
+            idx.add_device(add_rows, buf.data_ptr())      # grows past the reservation: needs ~1 GB, 256 MB are free
+        except _lib.LongbowGPUError as e:
+            # (the driver sometimes refuses to extend a mapped range -- hipMemSetAccess: invalid argument --, and the index then
+            # has to move its rows into a fresh allocation, old + new resident at once: that cannot fit here either way)
+            assert e.code == 5, e
+            went_through = False
+        assert idx.f16_image_bytes == 0                    # the copy went, whatever became of the Add
+        assert idx.ntotal == (n0 + add_rows if went_through else n0)
     finally:
         del blocker
         torch.cuda.empty_cache()
+    if not went_through:                                   # room again: the same Add succeeds, nothing was half-done
+        idx.add_device(add_rows, buf.data_ptr())
+        assert idx.ntotal == n0 + add_rows
     # exactness after the shed: strict mode == default mode on the grown corpus, and the old answers are a subset relation
     idx.search_device(40, q.data_ptr(), 10, od.data_ptr(), ol.data_ptr())
     got_l, got_d = ol.cpu().numpy().copy(), od.cpu().numpy().copy()

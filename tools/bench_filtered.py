@@ -11,7 +11,7 @@ import torch
 from longbow_amd import _lib, gpu
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 1_250_000
 D = int(sys.argv[2]) if len(sys.argv) > 2 else 1536
-K = 100
+K = int(os.environ.get('K', '100'))
 lib = _lib.require_gpu(0)
 X = torch.empty((rows, D), device="cuda"); Q = torch.empty((1024, D), device="cuda")
 lib.lb_gpu_fill_uniform_device(0, X.data_ptr(), X.numel(), 12345, 0, None)
@@ -35,5 +35,11 @@ for sel in [int(x) for x in os.environ.get("SELS", "100,50,10,1").split(",")]:
             idx.search_device(B, q.data_ptr(), K, od.data_ptr(), ol.data_ptr())
             ts.append(time.perf_counter() - t0)
         t = sorted(ts[2:])[len(ts[2:]) // 2]
-        print(f"sel {sel:3d} %  B={B:5d}  {t*1e3:8.3f} ms/batch  {B/t:10.0f} q/s  fallbacks {idx.last_fallbacks}"
-              f"  (filter set in {tf*1e3:.1f} ms incl. column upload)", flush=True)
+        idx.set_profiling(True)
+        idx.search_device(B, q.data_ptr(), K, od.data_ptr(), ol.data_ptr())
+        tm = idx.last_timing()
+        idx.set_profiling(False)
+        cls = " ".join(f"{c}={tm[c][0]*1e3:.0f}us/{tm[c][1]}" for c in ("gemm", "scan", "select", "rerank"))
+        vis = rows * sel / 100.0
+        print(f"sel {sel:3d} %  B={B:5d}  {t*1e3:8.3f} ms/batch  {B/t:10.0f} q/s  visible-f32-bytes/8TBs {4.0*vis*D/t/8e12:5.3f}  "
+              f"route {idx.last_route[2]}  fallbacks {idx.last_fallbacks}  [{cls}]  (filter set in {tf*1e3:.1f} ms incl. column upload)", flush=True)
