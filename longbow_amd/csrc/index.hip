@@ -261,6 +261,15 @@ struct lb_gpu_index {
     std::atomic<int> xh_mode{1}; // lb_gpu_index_set_f16_image: 0 never, 1 when it pays and fits
     bool xh_failed = false;      // an allocation was refused: not tried again for this handle
     bool xh_shed = false;        // the copy was given back to let an Add through: retaken only with twice the margin free
+    // L2 indexes keep the image CENTRED: fp16(x - c), c = the column means when the image was built.  L2 distances do not move
+    // when both sides are shifted, the key |x - c|^2 - 2 (q - c).(x - c) = d^2 - |q - c|^2 orders rows as the plain key does, and
+    // its errors scale with the centred norms: data with a large common offset (|c| >> spread), whose plain keys cancel, keeps
+    // the matrix-core route.  d_norm2c: [xh_cap] centred norms (the keys' side input); d_cstats: their max / smallest non-zero
+    // (float bits, as d_maxnorm2); xh_c_ok: those are within the fp16 contraction's range
+    float *d_center = nullptr, *d_norm2c = nullptr;
+    uint32_t *d_cstats = nullptr;
+    bool xh_centred = false, xh_c_ok = false;
+    int64_t xh_declined_n = 0;   // a centred image was out of fp16's range at this many rows: not tried again below twice that
     // data whose neighbours the candidate keys cannot separate (tight clusters): batched searches start with the widened
     // candidate list that proved the last such batch, for the next kc_hint_left searches (search_batch_device)
     std::atomic<int> kc_hint{0}, kc_hint_left{0};
@@ -763,18 +772,23 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     const int cmode = h->cand_mode.load();
     // (the fp16 image serves unfiltered searches and searches over a row list -- the persistent kernels gather out of it,
     // dimensions from 256; under a per-row mask test the kernel stages f32 rows)
-    const bool have_xh = h->d_Xh != nullptr && h->xh_rows == h->n && !mask && (!rv.rowmap || h->dim >= 256);
+    const bool have_xh = h->d_Xh != nullptr && h->xh_rows == h->n && !mask && (!rv.rowmap || h->dim >= 256) &&
+                         // (a centred image -- L2 -- is only ever read by the persistent kernels: nothing else knows the centre)
+                         (!h->xh_centred || tall16_runs_persistent(h->dim, nq, true, rv.rowmap != nullptr, false));
+    const bool centred = have_xh && h->xh_centred; // L2 keys about the image's centre (sync_f16_image)
+    // within the fp16 contraction's range: the centred norms when the image is centred, the rows' own norms otherwise
+    const bool f16_range_ok = centred ? h->xh_c_ok : h->f16_ok;
     // 1 .. 4 queries: the exact scan streams the f32 corpus (0.52 ms per 1M x 768); with the fp16 copy the candidate pass
     // streams half the bytes and the exact re-rank of 512 candidates costs 0.03 ms -- taken when the model says it is cheaper
     bool small_on_copy = false;
-    if (!h->nonfinite && nq < narrow_min && have_xh && h->f16_ok && allow_f16 &&
+    if (!h->nonfinite && nq < narrow_min && have_xh && f16_range_ok && allow_f16 &&
         (cmode == LB_CAND_F16 || (cmode == LB_CAND_AUTO && h->f16_skip.load(std::memory_order_relaxed) == 0))) {
         const double scan_ms = 1e-6 * (double)n * ((double)h->dim * 0.00066 + 0.04);
         const double copy_ms = route_ms(kCostNarrow16, n, h->dim, 1) + (h->dim > 1024 ? 0.0016 : 0.0007) * nq;
         small_on_copy = cmode == LB_CAND_F16 || copy_ms < scan_ms;
     }
     // (dimensions that are not multiples of 32: the MFMA tiles over f32 rows do not apply; the fp16 copy does)
-    const bool copy_route_ok = have_xh && h->f16_ok && allow_f16 &&
+    const bool copy_route_ok = have_xh && f16_range_ok && allow_f16 &&
                                (cmode == LB_CAND_F16 || (cmode == LB_CAND_AUTO && h->f16_skip.load(std::memory_order_relaxed) == 0));
     if (h->nonfinite || (nq < ((narrow_ok || copy_route_ok) ? narrow_min : kGemmMinQ) && !small_on_copy)) {
         h->last_route.store(0, std::memory_order_relaxed);
@@ -786,7 +800,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
 
     // ---- batched path: MFMA candidate generation + exact re-rank --------------------
     const bool have_image = h->d_Xs != nullptr && h->xs_rows == h->n && h->dim % 32 == 0;
-    bool f16_offer = h->f16_ok && allow_f16;
+    bool f16_offer = f16_range_ok && allow_f16;
     if (f16_offer && cmode == LB_CAND_AUTO && h->f16_skip.load(std::memory_order_relaxed) > 0) {
         h->f16_skip.fetch_sub(1, std::memory_order_relaxed);
         f16_offer = false;
@@ -865,7 +879,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         // (the exact norm is a serial chain of D additions, 3.5 us at 768: up to 384 queries it rides in the threshold launch
         // instead, where nothing waits for it)
         launch_query_prep(d_q, nq, h->dim, w->d_qh, d_qinv, (metric == LB_METRIC_COSINE && !prep_riders) ? w->d_qna : nullptr, order,
-                          w->cs, s);
+                          w->cs, s, centred ? h->d_center : nullptr);
     }
     if (!use_narrow && route.split == 1) {
         gx = h->d_Xs;
@@ -884,8 +898,9 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     // (up to 8 queries the wave-per-row kernel over the f32 rows is 5 us quicker: every load of a row in flight at once)
     static const int light_max = lb_tunable("LB_LIGHT_SAMPLE_MAXQ", 8); // (also over a row list: at 32 queries the wave-per-row
                                                                         // kernel took 105 us against the granule sample's 40)
-    const bool granule_sample = sp.on && use_tall16 && have_xh && granule_on && sp.count % 16 == 0 && nq > light_max &&
-                                (rv.rowmap == nullptr || entries_pos);
+    // (centred keys: the sample must come out of the same kernel -- the wave-per-row kernel's keys are the plain ones)
+    const bool granule_sample = sp.on && use_tall16 && have_xh && sp.count % 16 == 0 && (rv.rowmap == nullptr || entries_pos) &&
+                                ((granule_on && nq > light_max) || centred);
     const bool light_sample = sp.on && !fused && !granule_sample && nq <= light_max;
     const bool norm_riders = prep_riders && metric == LB_METRIC_COSINE;
     // the last launch: key-space pruning + exact re-rank + proof in one (kernels_finish.hip); beta: how far beyond one error
@@ -908,7 +923,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         else if (use_tall16 && h->dim % 32 != 0 && (rowmap || mask) && !entries_pos)
             // the sample of a search over the fp16 copy when the dimension is not a multiple of 32: the f32 tile takes any
             launch_gemm_filter(metric, h->d_X, h->d_norm2, h->d_rnorm, b, e, h->dim, d_q, nq, mask, rowmap, w->cs, boot, 0, s);
-        else if (use_tall && boot && (wsplit == 2 || wsplit == 3) && sample_narrow && narrow_ok && !entries_pos &&
+        else if (use_tall && boot && (wsplit == 2 || wsplit == 3) && sample_narrow && narrow_ok && !entries_pos && !centred &&
                  !(use_tall16 && nq > sample_narrow_maxq))
             // the 8192-row sample of a tall-tile search: the 64-query tile of the narrow kernel (same contraction, f32
             // operands) gets through its 24 K-steps of 32 in 31-35 us, the tall tile through its 48 of 16 in 57
@@ -917,8 +932,8 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
             launch_gemm_filter_narrow(metric, h->d_X, h->d_norm2, h->d_rnorm, b, e, h->dim, d_q, nq, mask, rowmap, w->cs,
                                       true, s, /*tile64=*/true, /*split=*/true);
         else if (use_tall16)
-            launch_gemm_filter_tall16(metric, h->d_X, h->d_norm2, h->d_rnorm, b, e, h->dim, w->d_qh, d_qinv, nq, mask, rowmap,
-                                      w->cs, boot, s, have_xh ? h->d_Xh : nullptr, h->xh_cap);
+            launch_gemm_filter_tall16(metric, h->d_X, centred ? h->d_norm2c : h->d_norm2, h->d_rnorm, b, e, h->dim, w->d_qh, d_qinv, nq,
+                                      mask, rowmap, w->cs, boot, s, have_xh ? h->d_Xh : nullptr, h->xh_cap);
         else if (use_tall2)
             launch_gemm_filter_tall2(metric, gx, h->d_norm2, h->d_rnorm, b, e, h->dim, w->d_qs, nq, mask, rowmap, w->cs,
                                      boot, wsplit, s);
@@ -944,8 +959,9 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
             {
                 ctx_check(w->ctx);
                 ProfScope p(w, s, prof, 1); // (timing class "select": threshold work, so that class "gemm" is the corpus pass alone)
-                launch_gemm_filter_tall16(metric, h->d_X, h->d_norm2, h->d_rnorm, 0, sp.count, h->dim, w->d_qh, d_qinv, nq, nullptr,
-                                          rv.rowmap, w->cs, /*boot=*/true, s, h->d_Xh, h->xh_cap, (uint32_t)(sp.span / (int64_t)(sp.count / 16)));
+                launch_gemm_filter_tall16(metric, h->d_X, centred ? h->d_norm2c : h->d_norm2, h->d_rnorm, 0, sp.count, h->dim, w->d_qh, d_qinv,
+                                          nq, nullptr, rv.rowmap, w->cs, /*boot=*/true, s, h->d_Xh, h->xh_cap,
+                                          (uint32_t)(sp.span / (int64_t)(sp.count / 16)));
             }
             ProfScope p(w, s, prof, 1);
             launch_sample_tau(w->cs, nullptr, nq, sp.count, sp.m, false, s, d_q, h->dim, norm_riders ? w->d_qna : nullptr, order);
@@ -1022,9 +1038,10 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         if (use_finish) {
             // members a query may have: twice the results wanted, at least 1024 (the lists hold up to cap entries below tau)
             const uint32_t smax = std::min<uint32_t>(kFinishSmaxMax, std::max<uint32_t>(1024u, 2u * next_pow2_host((uint32_t)k)));
-            launch_finish(metric, order, h->d_X, h->dim, d_q, nq, w->d_qna, w->cs, k, h->d_maxnorm2, gamma, finish_beta,
+            const bool ckeys = centred && use_tall16; // (the keys of this search were taken about the image's centre)
+            launch_finish(metric, order, h->d_X, h->dim, d_q, nq, w->d_qna, w->cs, k, ckeys ? h->d_cstats : h->d_maxnorm2, gamma, finish_beta,
                           h->has_ids ? h->d_ids : nullptr, entries_pos ? rv.rowmap : nullptr, d_dist, d_lab, s, w->h_flags, w->d_done, w->d_xcnt,
-                          w->d_xscratch, kFinishSplitMaxQ, smax);
+                          w->d_xscratch, kFinishSplitMaxQ, smax, ckeys ? h->d_center : nullptr);
         } else {
             launch_rerank(metric, order, h->d_X, h->dim, d_q, nq, w->d_qna, w->cs, kc, k, h->d_maxnorm2, gamma,
                           h->has_ids ? h->d_ids : nullptr, d_dist, d_lab, s, w->h_flags, w->d_done);
@@ -1169,6 +1186,8 @@ void finish_profile(lb_gpu_index *h, Workspace *w)
 // Make room for `need` rows.  The corpus itself grows in place (VmmBuf); only the small per-row side
 // arrays (norms, ids, mask: 17 B per row) are reallocated geometrically and copied.  Without VMM the
 // corpus follows the same malloc + copy scheme (needs old + new resident at once).
+void drop_f16_image(lb_gpu_index *h);
+
 int grow(lb_gpu_index *h, int64_t need)
 {
     const size_t row_bytes = (size_t)h->dim * sizeof(float);
@@ -1252,11 +1271,7 @@ int grow(lb_gpu_index *h, int64_t need)
         h->d_Xs = nullptr;
         h->xs_rows = 0;
     }
-    if (h->d_Xh) { // its planes are `capacity` rows apart: rebuilt by the next sync_f16_image
-        (void)hipFree(h->d_Xh);
-        h->d_Xh = nullptr;
-        h->xh_rows = h->xh_cap = 0;
-    }
+    if (h->d_Xh) drop_f16_image(h); // its planes are `capacity` rows apart: rebuilt by the next sync_f16_image
     return LB_OK;
 }
 
@@ -1275,9 +1290,7 @@ int grow_or_shed(lb_gpu_index *h, int64_t need)
         if (e.e != hipErrorOutOfMemory || (!h->d_Xh && !h->d_Xs)) throw;
         (void)hipGetLastError();
         if (h->d_Xh) {
-            (void)hipFree(h->d_Xh);
-            h->d_Xh = nullptr;
-            h->xh_rows = h->xh_cap = 0;
+            drop_f16_image(h);
             h->xh_shed = true;
         }
         if (h->d_Xs) { // (the explicit split-image mode cannot be kept: back to the default routes)
@@ -1289,6 +1302,16 @@ int grow_or_shed(lb_gpu_index *h, int64_t need)
         buf_pool().trim(h->device);
         return grow(h, need);
     }
+}
+
+void drop_f16_image(lb_gpu_index *h)
+{
+    if (h->d_Xh) (void)hipFree(h->d_Xh);
+    if (h->d_norm2c) (void)hipFree(h->d_norm2c);
+    h->d_Xh = nullptr;
+    h->d_norm2c = nullptr;
+    h->xh_rows = h->xh_cap = 0;
+    h->xh_centred = h->xh_c_ok = false;
 }
 
 // Recompute the visible-row list from d_mask (caller holds the exclusive lock).  The list is used
@@ -1406,23 +1429,26 @@ void sync_split_image(lb_gpu_index *h)
 void sync_f16_image(lb_gpu_index *h)
 {
     const int cm = h->cand_mode.load();
-    const bool want = h->xh_mode.load() != 0 && !h->xh_failed && h->f16_ok && h->n > 0 &&
+    const bool l2 = h->metric == LB_METRIC_EUCLIDEAN;
+    // (L2: the image is centred, so what must fit fp16 are the centred norms -- known once the centre is)
+    const bool range_ok = l2 ? (!h->nonfinite && (h->xh_declined_n == 0 || h->n >= 2 * h->xh_declined_n)) : h->f16_ok;
+    const bool want = h->xh_mode.load() != 0 && !h->xh_failed && range_ok && h->n > 0 &&
                       (cm == LB_CAND_F16 || (cm == LB_CAND_AUTO && h->n >= 262144));
     try {
         if (!want || (h->d_Xh && (h->xh_cap < h->n || h->xh_rows > h->n))) {
-            if (h->d_Xh) (void)hipFree(h->d_Xh);
-            h->d_Xh = nullptr;
-            h->xh_rows = h->xh_cap = 0;
+            drop_f16_image(h);
             if (!want) return;
         }
+        hipStream_t s = h->add_stream;
         if (h->d_Xh == nullptr) {
             const int pd = corpus_f16_plane_dims();
-            const size_t need = (size_t)h->capacity * (size_t)((h->dim + pd - 1) / pd * pd) * 2; // (whole planes, the last zero-padded)
+            const size_t need = (size_t)h->capacity * (size_t)((h->dim + pd - 1) / pd * pd) * 2 // (whole planes, the last zero-padded)
+                                + (l2 ? (size_t)h->capacity * sizeof(float) : 0);
             size_t fr = 0, tot = 0;
             LB_HIP(hipMemGetInfo(&fr, &tot));
             const size_t keep = std::max<size_t>((size_t)2 << 30, tot / 16) * (h->xh_shed ? 2 : 1);
             if (fr < need + keep) return; // (not remembered: memory may be free again at the next Add)
-            if (hipMalloc(&h->d_Xh, need) != hipSuccess) {
+            if (hipMalloc(&h->d_Xh, need - (l2 ? (size_t)h->capacity * sizeof(float) : 0)) != hipSuccess) {
                 (void)hipGetLastError();
                 h->d_Xh = nullptr;
                 h->xh_failed = true;
@@ -1430,17 +1456,41 @@ void sync_f16_image(lb_gpu_index *h)
             }
             h->xh_cap = h->capacity;
             h->xh_rows = 0;
+            if (l2) { // the centre: column means of the rows there are (fixed from here on: appended rows are shifted by the same)
+                const int dpad = ((h->dim + 31) & ~31) + 8;
+                if (!h->d_center) LB_HIP(hipMalloc(&h->d_center, (size_t)dpad * sizeof(float)));
+                if (!h->d_cstats) LB_HIP(hipMalloc(&h->d_cstats, 2 * sizeof(uint32_t)));
+                LB_HIP(hipMalloc(&h->d_norm2c, (size_t)h->capacity * sizeof(float)));
+                const uint32_t init[2] = {0u, 0x7f800000u};
+                LB_HIP(hipMemcpyAsync(h->d_cstats, init, sizeof init, hipMemcpyHostToDevice, s));
+                Lease part(h->device, (size_t)256 * h->dim * sizeof(float));
+                launch_column_means(h->d_X, h->n, h->dim, part.as<float>(), h->d_center, dpad, s);
+                LB_HIP(hipStreamSynchronize(s)); // (the lease goes back to the pool)
+                h->xh_centred = true;
+            }
         }
         if (h->xh_rows < h->n) {
-            launch_corpus_to_f16(h->d_X, h->xh_rows, h->n, h->dim, h->d_Xh, h->xh_cap, h->add_stream);
-            LB_HIP(hipStreamSynchronize(h->add_stream));
+            launch_corpus_to_f16(h->d_X, h->xh_rows, h->n, h->dim, h->d_Xh, h->xh_cap, s, h->xh_centred ? h->d_center : nullptr);
+            if (h->xh_centred) {
+                launch_row_norms(h->d_X + (size_t)h->xh_rows * h->dim, h->n - h->xh_rows, h->dim, h->d_norm2c + h->xh_rows, nullptr,
+                                 h->d_cstats, s, h->d_center);
+                uint32_t cb[2] = {0, 0};
+                LB_HIP(hipMemcpyAsync(cb, h->d_cstats, sizeof cb, hipMemcpyDeviceToHost, s));
+                LB_HIP(hipStreamSynchronize(s));
+                const float mx = __builtin_bit_cast(float, cb[0]), mn = __builtin_bit_cast(float, cb[1]);
+                h->xh_c_ok = cb[0] < 0x7f800000u && mx <= 67108864.0f /* 2^26 */ && (cb[1] == 0x7f800000u || mn >= 0.000244140625f /* 2^-12 */);
+                if (!h->xh_c_ok) { // the spread itself is beyond fp16: no image for this index until it has doubled
+                    h->xh_declined_n = h->n;
+                    drop_f16_image(h);
+                    return;
+                }
+            }
+            LB_HIP(hipStreamSynchronize(s));
             h->xh_rows = h->n;
         }
     } catch (const HipErr &) {
         (void)hipGetLastError();
-        if (h->d_Xh) (void)hipFree(h->d_Xh);
-        h->d_Xh = nullptr;
-        h->xh_rows = h->xh_cap = 0;
+        drop_f16_image(h);
         h->xh_failed = true;
     }
 }
@@ -1603,6 +1653,9 @@ void lb_gpu_index_free(lb_gpu_index *h)
         if (h->d_maxnorm2) (void)hipFree(h->d_maxnorm2);
         if (h->d_Xs) (void)hipFree(h->d_Xs);
         if (h->d_Xh) (void)hipFree(h->d_Xh);
+        if (h->d_norm2c) (void)hipFree(h->d_norm2c);
+        if (h->d_center) (void)hipFree(h->d_center);
+        if (h->d_cstats) (void)hipFree(h->d_cstats);
         for (int i = 0; i < 2; i++) {
             if (h->h_stage[i]) (void)hipHostFree(h->h_stage[i]);
             if (h->stage_ev[i]) (void)hipEventDestroy(h->stage_ev[i]);
@@ -1656,7 +1709,7 @@ int lb_gpu_index_set_f16_image(lb_gpu_index *h, int mode)
         if (h->closed) return LB_ERR_CLOSED;
         if (hipSetDevice(h->device) != hipSuccess) { (void)hipGetLastError(); return LB_ERR_HIP; }
         h->xh_mode.store(mode);
-        if (mode) h->xh_failed = h->xh_shed = false;
+        if (mode) { h->xh_failed = h->xh_shed = false; h->xh_declined_n = 0; }
         sync_f16_image(h);
     } catch (...) {
         return LB_ERR_INTERNAL;

@@ -49,6 +49,8 @@ struct FinishArgs {
     float gamma, beta;
     const int64_t *ids;
     const uint32_t *posmap; // or null: the lists carry positions of this row list (a filtered view), not corpus rows
+    const float *center;    // or null (L2 only): the keys were taken about this centre -- key + |q - c|^2 ~ d^2, the proof's norms
+                            // are the centred ones (maxnorm2 then points at the centred maximum); the exact sums are untouched
     float *out_dist;
     int64_t *out_labels;
     uint32_t *flags_host;
@@ -278,7 +280,10 @@ __global__ __launch_bounds__(FN_THREADS) void finish_kernel(FinishArgs a)
     const float *q = a.Q + (int64_t)qi * D;
     float nq2 = 0.f;
     if (METRIC != METRIC_COS) { // (any order: only ever used as a bound, with slack)
-        for (int i = tid; i < D; i += FN_THREADS) nq2 += q[i] * q[i];
+        for (int i = tid; i < D; i += FN_THREADS) {
+            const float v = (METRIC == METRIC_L2 && a.center) ? q[i] - a.center[i] : q[i];
+            nq2 += v * v;
+        }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) nq2 += __shfl_xor(nq2, off);
         if (lane == 0) fred[wave] = nq2;
@@ -651,10 +656,11 @@ size_t finish_scratch_bytes(int nq_split_max, uint32_t smax) { return (size_t)nq
 void launch_finish(int metric, int order, const float *X, int D, const float *Q, int nq, const float *qna, CandState cs, int k,
                    const uint32_t *d_maxnorm2, float gamma, float beta, const int64_t *ids, const uint32_t *posmap, float *out_dist,
                    int64_t *out_labels, hipStream_t s, uint32_t *flags_host, uint32_t *done, uint32_t *xcnt, void *xscratch,
-                   int nq_split_max, uint32_t smax)
+                   int nq_split_max, uint32_t smax, const float *center)
 {
     if (nq <= 0) return;
     FinishArgs a;
+    a.center = metric == METRIC_L2 ? center : nullptr;
     a.X = X; a.D = D; a.Q = Q; a.qna = qna; a.cs = cs; a.k = k; a.maxnorm2 = d_maxnorm2; a.gamma = gamma; a.beta = beta;
     a.ids = ids; a.posmap = posmap; a.out_dist = out_dist; a.out_labels = out_labels; a.flags_host = flags_host;
     a.smax = smax; a.done = done; a.xcnt = xcnt;

@@ -1229,14 +1229,19 @@ __global__ __launch_bounds__(256) void queries_to_f16_kernel(const float *Q, int
 // f32 corpus rows [row_begin, row_end) -> the blocked fp16 image Xh[Dp / H_XP][cap][H_XP] (round to nearest even, the conversion
 // the kernels above apply in registers: both forms of the route see the same fp16 values; dimensions beyond D are zero).
 // One workgroup = 64 rows x 32 dimensions: whole 128-B lines in, 64-B pieces out.
-__global__ __launch_bounds__(256) void corpus_to_f16_kernel(const float *X, int64_t row_begin, int64_t row_end, int D, _Float16 *Xh, int64_t cap)
+__global__ __launch_bounds__(256) void corpus_to_f16_kernel(const float *X, int64_t row_begin, int64_t row_end, int D, _Float16 *Xh, int64_t cap,
+                                                            const float *center)
 {
     const int64_t row = row_begin + (int64_t)blockIdx.x * 64 + (threadIdx.x >> 2);
     const int kb = blockIdx.y, q = threadIdx.x & 3; // kb: block of 32 dimensions
     if (row >= row_end) return;
     const int k0 = kb * 32 + q * 8;
     f16x8 v;
-    if (k0 + 8 <= D && (D & 3) == 0) { // (rows are 16-B aligned when D % 4 == 0)
+    if (center) { // the centred image (L2): fp16(x - center), the subtraction in f32
+        const float *src = X + row * (int64_t)D;
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = k0 + e < D ? (_Float16)(src[k0 + e] - center[k0 + e]) : (_Float16)0.f;
+    } else if (k0 + 8 <= D && (D & 3) == 0) { // (rows are 16-B aligned when D % 4 == 0)
         const f32x4 *src = reinterpret_cast<const f32x4 *>(X + row * (int64_t)D + k0);
         v = h_cvt8(src[0], src[1]);
     } else { // the last block of a dimension that is not a multiple of 32 (zero beyond D), or unaligned rows
@@ -1262,11 +1267,12 @@ void read_tall16_probe(unsigned long long out[8], bool reset)
 
 int corpus_f16_plane_dims() { return H_XP; }
 
-void launch_corpus_to_f16(const float *X, int64_t row_begin, int64_t row_end, int D, void *Xh, int64_t cap, hipStream_t s)
+void launch_corpus_to_f16(const float *X, int64_t row_begin, int64_t row_end, int D, void *Xh, int64_t cap, hipStream_t s,
+                          const float *center)
 {
     if (row_end <= row_begin) return;
     dim3 grid((unsigned)((row_end - row_begin + 63) / 64), (unsigned)(((D + H_XP - 1) / H_XP) * (H_XP / 32))); // (whole planes: zero padding)
-    hipLaunchKernelGGL(corpus_to_f16_kernel, grid, dim3(256), 0, s, X, row_begin, row_end, D, reinterpret_cast<_Float16 *>(Xh), cap);
+    hipLaunchKernelGGL(corpus_to_f16_kernel, grid, dim3(256), 0, s, X, row_begin, row_end, D, reinterpret_cast<_Float16 *>(Xh), cap, center);
 }
 
 void launch_queries_to_f16(const float *Q, int nq, int D, void *Qh, float *qinv, hipStream_t s)
@@ -1301,6 +1307,7 @@ static bool tall16_persistent_ok(int D, int nq, bool img, bool mapped, bool mask
     if (mapped && !(img && mapped_on && (D + H_BK - 1) / H_BK >= 8)) return false;
     return true;
 }
+bool tall16_runs_persistent(int D, int nq, bool img, bool mapped, bool masked) { return tall16_persistent_ok(D, nq, img, mapped, masked); }
 bool tall16_entries_are_positions(int D, int nq, bool img, bool mapped, bool masked)
 {
     return mapped && tall16_persistent_ok(D, nq, img, true, masked);

@@ -485,8 +485,9 @@ __device__ __forceinline__ float exact_sq_norm_lds(const float *sq, int D)
 // image [D / 32][nq][32] (each query scaled by the power of two that brings its norm into [1, 2); qinv[q] = 1 / scale, exact),
 // the exact ||q||^2 in the reference's order (cosine: the re-rank divides by it, internal/simd/simd.go:138-152), and the
 // reset of the query's candidate state.  (A zero or non-finite query keeps scale 1: the exact scan answers it anyway.)
+// center (or null; L2 over the centred image): the image holds q - center (the exact norm, cosine only, is never asked for then)
 __global__ __launch_bounds__(64) void query_prep_kernel(const float *Q, int nq, int D, _Float16 *Qh, float *qinv, float *qna, int order,
-                                                        CandState cs)
+                                                        CandState cs, const float *center)
 {
     extern __shared__ __attribute__((aligned(16))) float sq[];
     const int q = blockIdx.x, lane = threadIdx.x;
@@ -494,7 +495,7 @@ __global__ __launch_bounds__(64) void query_prep_kernel(const float *Q, int nq, 
     const int Dpad = (D + 3) & ~3;
     float s = 0.f;
     for (int i = lane; i < Dpad; i += 64) {
-        const float v = i < D ? src[i] : 0.f;
+        const float v = i < D ? (center ? src[i] - center[i] : src[i]) : 0.f;
         sq[i] = v;
         s += v * v;
     }
@@ -522,11 +523,12 @@ __global__ __launch_bounds__(64) void query_prep_kernel(const float *Q, int nq, 
     }
 }
 
-void launch_query_prep(const float *Q, int nq, int D, void *Qh, float *qinv, float *qna, int order, CandState cs, hipStream_t s)
+void launch_query_prep(const float *Q, int nq, int D, void *Qh, float *qinv, float *qna, int order, CandState cs, hipStream_t s,
+                       const float *center)
 {
     if (nq <= 0) return;
     hipLaunchKernelGGL(query_prep_kernel, dim3((unsigned)nq), dim3(64), (size_t)((D + 3) & ~3) * sizeof(float), s, Q, nq, D,
-                       reinterpret_cast<_Float16 *>(Qh), qinv, qna, order, cs);
+                       reinterpret_cast<_Float16 *>(Qh), qinv, center ? nullptr : qna, order, cs, center);
 }
 
 // R = sampled rows per wave: every query chunk fetched from L2 is used for R rows (with 32 query
@@ -904,16 +906,22 @@ void launch_scan(int metric, int order, bool raw_dot, const float *X, int64_t ro
 // Row norms at Add time: one wave per row, coalesced float4 reads, wave reduction.
 // Used only for candidate keys and error bounds (never for reported distances).
 // ---------------------------------------------------------------------------
+// center (or null): the norms of x - center (the L2 keys over the centred fp16 image, index.hip: sync_f16_image); rnorm may be null
 __global__ __launch_bounds__(256) void row_norms_kernel(const float *X, int64_t n, int D,
                                                         float *norm2, float *rnorm,
-                                                        uint32_t *maxnorm2, int aligned)
+                                                        uint32_t *maxnorm2, int aligned, const float *center)
 {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
     const float *x = X + row * (int64_t)D;
     float s = 0.f;
-    if (aligned) {
+    if (center) {
+        for (int i = lane; i < D; i += 64) {
+            const float v = x[i] - center[i];
+            s += v * v;
+        }
+    } else if (aligned) {
         for (int i = lane * 4; i < D; i += 256) {
             const f32x4 v = *reinterpret_cast<const f32x4 *>(x + i);
             s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
@@ -925,7 +933,7 @@ __global__ __launch_bounds__(256) void row_norms_kernel(const float *X, int64_t 
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
     if (lane == 0) {
         norm2[row] = s;
-        rnorm[row] = s > 0.f ? (float)(1.0 / sqrt((double)s)) : 0.f;
+        if (rnorm) rnorm[row] = s > 0.f ? (float)(1.0 / sqrt((double)s)) : 0.f;
         // s >= 0: uint order == float order.  Read first: one contended atomic per row would
         // serialise the whole kernel on a single address.
         const uint32_t bits = __builtin_bit_cast(uint32_t, s);
@@ -936,13 +944,43 @@ __global__ __launch_bounds__(256) void row_norms_kernel(const float *X, int64_t 
 }
 
 void launch_row_norms(const float *X, int64_t n, int D, float *norm2, float *rnorm,
-                      uint32_t *d_maxnorm2, hipStream_t s)
+                      uint32_t *d_maxnorm2, hipStream_t s, const float *center)
 {
     if (n <= 0) return;
     const int aligned = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
     dim3 grid((unsigned)((n + 3) / 4));
     hipLaunchKernelGGL(row_norms_kernel, grid, dim3(256), 0, s, X, n, D, norm2, rnorm, d_maxnorm2,
-                       aligned);
+                       aligned, center);
+}
+
+// Column means of X[0 .. n) in a fixed summation order (two stages: 256 partial sums per column, then their sum): the centre
+// the L2 keys of the fp16 image are taken about.  Any fixed vector would do -- L2 distances do not move when both sides are
+// shifted -- the mean makes the shifted norms, and with them the key errors, as small as a shift can.
+__global__ __launch_bounds__(256) void column_sums_kernel(const float *X, int64_t n, int D, float *partial)
+{
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < n ? r0 + per : n;
+    for (int c = threadIdx.x; c < D; c += 256) {
+        float acc = 0.f;
+        for (int64_t r = r0; r < r1; r++) acc += X[r * (int64_t)D + c];
+        partial[(int64_t)blockIdx.x * D + c] = acc;
+    }
+}
+__global__ __launch_bounds__(256) void column_mean_kernel(const float *partial, int nparts, int D, int64_t n, float *center, int Dpad)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= Dpad) return;
+    float acc = 0.f;
+    if (c < D)
+        for (int p = 0; p < nparts; p++) acc += partial[(int64_t)p * D + c];
+    center[c] = c < D ? acc / (float)n : 0.f;
+}
+void launch_column_means(const float *X, int64_t n, int D, float *partial /* [256][D] */, float *center /* [Dpad] */, int Dpad,
+                         hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(column_sums_kernel, dim3(256), dim3(256), 0, s, X, n, D, partial);
+    hipLaunchKernelGGL(column_mean_kernel, dim3((unsigned)((Dpad + 255) / 256)), dim3(256), 0, s, partial, 256, D, n, center, Dpad);
 }
 
 // ---------------------------------------------------------------------------

@@ -145,8 +145,11 @@ __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
 
 // per-row ||x||^2 and 1/||x|| (0 if the norm is 0); max ||x||^2 folded into d_maxnorm2[0], the smallest NON-ZERO ||x||^2
 // into d_maxnorm2[1] (float bits; initialise to {0, 0x7f800000})
+// center (or null): norms of x - center instead (rnorm may then be null)
 void launch_row_norms(const float *X, int64_t n, int D, float *norm2, float *rnorm,
-                      uint32_t *d_maxnorm2, hipStream_t s);
+                      uint32_t *d_maxnorm2, hipStream_t s, const float *center = nullptr);
+// column means of X[0 .. n) in a fixed order -> center[0 .. Dpad) (zero beyond D); partial: [256][D] scratch
+void launch_column_means(const float *X, int64_t n, int D, float *partial, float *center, int Dpad, hipStream_t s);
 
 // candidate generation: f32 MFMA inner products of queries [nq][D] x rows [row_begin,row_end)
 // -> metric key -> admit (key,row) < tau[q] into the query's list.
@@ -202,7 +205,8 @@ void launch_gemm_filter_tall2(int metric, const float *X, const float *norm2, co
 void launch_queries_to_f16(const float *Q, int nq, int D, void *Qh, float *qinv, hipStream_t s);
 // the same image and scales, plus the exact ||q||^2 in `order` (qna, or null) and the reset of the queries' candidate state:
 // one launch for what a search over this route needs from its batch (kernels_scan.hip)
-void launch_query_prep(const float *Q, int nq, int D, void *Qh, float *qinv, float *qna, int order, CandState cs, hipStream_t s);
+void launch_query_prep(const float *Q, int nq, int D, void *Qh, float *qinv, float *qna, int order, CandState cs, hipStream_t s,
+                       const float *center = nullptr); // center: the image of q - center (L2 over the centred corpus image)
 // Xh (or null): the corpus's K-blocked fp16 image [Dp / 32][xh_cap][32] from launch_corpus_to_f16, in step with X; used by
 // unfiltered searches (half the bytes to stage, a four-stage ring)
 void launch_gemm_filter_tall16(int metric, const float *X, const float *norm2, const float *rnorm, int64_t row_begin,
@@ -211,11 +215,13 @@ void launch_gemm_filter_tall16(int metric, const float *X, const float *norm2, c
                                int64_t xh_cap = 0,
                                uint32_t gstride = 0); // boot launches of the persistent forms: positions = granules of 16 rows,
                                                      // gstride rows apart (an evenly spaced sample read in whole KiB)
-void launch_corpus_to_f16(const float *X, int64_t row_begin, int64_t row_end, int D, void *Xh, int64_t cap, hipStream_t s);
+void launch_corpus_to_f16(const float *X, int64_t row_begin, int64_t row_end, int D, void *Xh, int64_t cap, hipStream_t s,
+                          const float *center = nullptr); // center (or null; [>= D + 8]): the image holds fp16(x - center)
 int corpus_f16_plane_dims(); // dimensions per plane of that image (its rows are zero-padded to a multiple of it)
 // under a row list (mapped) the persistent kernels gather out of the image and leave POSITIONS of the list in the candidate
 // entries (the finish launch maps them back: posmap); true when a launch with these parameters does so
 bool tall16_entries_are_positions(int D, int nq, bool img, bool mapped, bool masked);
+bool tall16_runs_persistent(int D, int nq, bool img, bool mapped, bool masked); // the persistent kernels serve such a launch
 
 // per query: sort the list, keep the best kc, tau = kc-th entry (or max), flag overflow.
 // qsel (nullable): only these query slots.  boot_rows > 0: the list was filled by a bootstrap
@@ -266,7 +272,8 @@ size_t finish_scratch_bytes(int nq_split_max, uint32_t smax);
 void launch_finish(int metric, int order, const float *X, int D, const float *Q, int nq, const float *qna, CandState cs, int k,
                    const uint32_t *d_maxnorm2, float gamma, float beta, const int64_t *ids, const uint32_t *posmap, float *out_dist,
                    int64_t *out_labels, hipStream_t s, uint32_t *flags_host, uint32_t *done, uint32_t *xcnt, void *xscratch,
-                   int nq_split_max, uint32_t smax);
+                   int nq_split_max, uint32_t smax,
+                   const float *center = nullptr); // L2 keys taken about this centre: d_maxnorm2 = the centred maximum norm
 
 // ||q||^2 per selected query slot in the requested accumulation order (cosine).
 void launch_query_norms(int order, const float *Q, const int *qsel, int nsel, int D, float *qna,

@@ -68,3 +68,35 @@ def test_l2_fast_routes_survive_row_norms_over_twenty_binades(oracle):
     assert_same(lab[:6], dist[:6], oi, od, "row binades")
     assert idx.last_fallbacks <= 2, idx.last_fallbacks
     idx.Close()
+
+
+@pytest.mark.parametrize("offset", [100.0, 1000.0])
+def test_l2_with_a_large_common_offset_stays_on_the_matrix_cores(oracle, offset):
+    """round-3 verdict, item 4: L2 on data whose rows share a large offset (|mean| >> spread).  The plain candidate key
+    |x|^2 - 2 q.x cancels -- the strict mode leaves every such query to the exact scan -- but L2 does not move when both sides
+    are shifted: the index's fp16 image holds x - c (c = the column means), the queries' image q - c, and the proof runs on the
+    centred norms.  The default mode must answer with the oracle's lists and leave (almost) nothing to the scan."""
+    gpu_or_skip()
+    rng = np.random.default_rng(int(offset))
+    n, d, k = 300_000, 64, 10
+    X = np.ascontiguousarray(rng.standard_normal((n, d)).astype(F) * F(0.01) + F(offset))
+    rows = rng.integers(0, n, 300)
+    Q = np.ascontiguousarray(X[rows] + rng.standard_normal((300, d)).astype(F) * F(0.002))
+    idx = new_index(d, 0)
+    idx.Add(None, X)
+    assert idx.f16_image_bytes > 0
+    oi, od = oracle.search_batch(0, Q[:8], X, k, nthreads=8)
+    for nq in (1, 8, 40, 300):
+        lab, dist = idx.SearchBatch(Q[:nq], k)
+        m = min(nq, 8)
+        assert_same(lab[:m], dist[:m], oi[:m], od[:m], f"offset {offset} nq {nq} route {idx.last_route}")
+        assert idx.last_fallbacks <= max(1, nq // 100), (offset, nq, idx.last_fallbacks)
+    # appended rows are shifted by the same centre
+    extra = np.ascontiguousarray(rng.standard_normal((5000, d)).astype(F) * F(0.01) + F(offset))
+    idx.Add(None, extra)
+    X2 = np.concatenate([X, extra])
+    lab, dist = idx.SearchBatch(Q[:40], k)
+    oi2, od2 = oracle.search_batch(0, Q[:8], X2, k, nthreads=8)
+    assert_same(lab[:8], dist[:8], oi2, od2, f"offset {offset} after an append")
+    assert idx.last_fallbacks == 0
+    idx.Close()
