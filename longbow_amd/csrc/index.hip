@@ -269,6 +269,8 @@ struct lb_gpu_index {
     float *d_center = nullptr, *d_norm2c = nullptr;
     uint32_t *d_cstats = nullptr;
     bool xh_centred = false, xh_c_ok = false;
+    bool xh_offset_dom = false;  // |c|^2 is several times the largest centred |x - c|^2: plain L2 keys cancel on this data, so
+                                 // AUTO keeps batched searches on the centred image whatever the cost model says of other routes
     int64_t xh_declined_n = 0;   // a centred image was out of fp16's range at this many rows: not tried again below twice that
     // data whose neighbours the candidate keys cannot separate (tight clusters): batched searches start with the widened
     // candidate list that proved the last such batch, for the next kc_hint_left searches (search_batch_device)
@@ -805,7 +807,9 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         h->f16_skip.fetch_sub(1, std::memory_order_relaxed);
         f16_offer = false;
     }
-    const Route route = choose_route(nq, n, h->dim, cmode, narrow_ok, have_image, f16_offer, have_xh);
+    // (offset-dominated L2 data: only the centred image's keys resolve anything)
+    const int cmode_route = (cmode == LB_CAND_AUTO && centred && h->xh_offset_dom && f16_offer) ? LB_CAND_F16 : cmode;
+    const Route route = choose_route(nq, n, h->dim, cmode_route, narrow_ok, have_image, f16_offer, have_xh);
     h->last_route.store(route.kind * 10 + route.split, std::memory_order_relaxed);
 #ifdef LB_DIAG
     g_last_route.store(route.kind * 10 + route.split);
@@ -862,11 +866,17 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         launch_split_bf16(d_q, w->d_qs, nq, h->dim, s);
     };
     if (!use_narrow && (route.split == 1 || route.split == 2)) split_queries(); // the tall / wide split kernels take the batch as an image
-    float *d_qinv = nullptr;
+    float *d_qinv = nullptr, *d_qnrm = nullptr;
+    // dot product on the persistent fp16 kernels: LOWER-BOUND keys -(q.x)~ / G - |x|, G = (gamma_a + gamma_o) |q| (a few very long
+    // rows then sort to the front of the lists and are scored exactly instead of widening every row's error bound)
+    const float gsum = gamma + 1.05f * (float)(h->dim + 8) * u24;
+    const bool dot_lb = metric == LB_METRIC_DOT && use_tall16 &&
+                        tall16_runs_persistent(h->dim, nq, have_xh, rv.rowmap != nullptr, mask != nullptr);
+    const bool own_keys = centred || dot_lb; // keys only the persistent kernels produce: sample and boot chunks must come from them
     static const int riders_max = lb_tunable("LB_NORM_RIDERS_MAXQ", 384);
     const bool prep_riders = sp.on && nq <= riders_max; // (cosine: the exact query norms come out of the threshold launch)
     if (use_tall16) { // fp16 image of the batch (scaled per query) + the inverse scales
-        const size_t img = (((size_t)nq * (size_t)((h->dim + 31) & ~31) * 2) + 255) & ~(size_t)255, need = img + (size_t)nq * sizeof(float);
+        const size_t img = (((size_t)nq * (size_t)((h->dim + 31) & ~31) * 2) + 255) & ~(size_t)255, need = img + 2 * (size_t)nq * sizeof(float);
         if (w->d_qh_bytes < need) {
             if (w->d_qh) (void)hipFree(w->d_qh);
             w->d_qh = nullptr;
@@ -875,11 +885,12 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
             w->d_qh_bytes = need;
         }
         d_qinv = reinterpret_cast<float *>(static_cast<char *>(w->d_qh) + img);
+        d_qnrm = d_qinv + nq;
         // one launch: the image, the scales, the exact query norms (cosine) and the reset of the candidate state
         // (the exact norm is a serial chain of D additions, 3.5 us at 768: up to 384 queries it rides in the threshold launch
         // instead, where nothing waits for it)
         launch_query_prep(d_q, nq, h->dim, w->d_qh, d_qinv, (metric == LB_METRIC_COSINE && !prep_riders) ? w->d_qna : nullptr, order,
-                          w->cs, s, centred ? h->d_center : nullptr);
+                          w->cs, s, centred ? h->d_center : nullptr, dot_lb ? d_qnrm : nullptr);
     }
     if (!use_narrow && route.split == 1) {
         gx = h->d_Xs;
@@ -899,8 +910,8 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     static const int light_max = lb_tunable("LB_LIGHT_SAMPLE_MAXQ", 8); // (also over a row list: at 32 queries the wave-per-row
                                                                         // kernel took 105 us against the granule sample's 40)
     // (centred keys: the sample must come out of the same kernel -- the wave-per-row kernel's keys are the plain ones)
-    const bool granule_sample = sp.on && use_tall16 && have_xh && sp.count % 16 == 0 && (rv.rowmap == nullptr || entries_pos) &&
-                                ((granule_on && nq > light_max) || centred);
+    const bool granule_sample = sp.on && use_tall16 && sp.count % 16 == 0 && (rv.rowmap == nullptr || entries_pos) &&
+                                ((have_xh && granule_on && nq > light_max) || own_keys);
     const bool light_sample = sp.on && !fused && !granule_sample && nq <= light_max;
     const bool norm_riders = prep_riders && metric == LB_METRIC_COSINE;
     // the last launch: key-space pruning + exact re-rank + proof in one (kernels_finish.hip); beta: how far beyond one error
@@ -923,7 +934,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         else if (use_tall16 && h->dim % 32 != 0 && (rowmap || mask) && !entries_pos)
             // the sample of a search over the fp16 copy when the dimension is not a multiple of 32: the f32 tile takes any
             launch_gemm_filter(metric, h->d_X, h->d_norm2, h->d_rnorm, b, e, h->dim, d_q, nq, mask, rowmap, w->cs, boot, 0, s);
-        else if (use_tall && boot && (wsplit == 2 || wsplit == 3) && sample_narrow && narrow_ok && !entries_pos && !centred &&
+        else if (use_tall && boot && (wsplit == 2 || wsplit == 3) && sample_narrow && narrow_ok && !entries_pos && !own_keys &&
                  !(use_tall16 && nq > sample_narrow_maxq))
             // the 8192-row sample of a tall-tile search: the 64-query tile of the narrow kernel (same contraction, f32
             // operands) gets through its 24 K-steps of 32 in 31-35 us, the tall tile through its 48 of 16 in 57
@@ -933,7 +944,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
                                       true, s, /*tile64=*/true, /*split=*/true);
         else if (use_tall16)
             launch_gemm_filter_tall16(metric, h->d_X, centred ? h->d_norm2c : h->d_norm2, h->d_rnorm, b, e, h->dim, w->d_qh, d_qinv, nq,
-                                      mask, rowmap, w->cs, boot, s, have_xh ? h->d_Xh : nullptr, h->xh_cap);
+                                      mask, rowmap, w->cs, boot, s, have_xh ? h->d_Xh : nullptr, h->xh_cap, 0u, d_qnrm, gsum);
         else if (use_tall2)
             launch_gemm_filter_tall2(metric, gx, h->d_norm2, h->d_rnorm, b, e, h->dim, w->d_qs, nq, mask, rowmap, w->cs,
                                      boot, wsplit, s);
@@ -960,8 +971,8 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
                 ctx_check(w->ctx);
                 ProfScope p(w, s, prof, 1); // (timing class "select": threshold work, so that class "gemm" is the corpus pass alone)
                 launch_gemm_filter_tall16(metric, h->d_X, centred ? h->d_norm2c : h->d_norm2, h->d_rnorm, 0, sp.count, h->dim, w->d_qh, d_qinv,
-                                          nq, nullptr, rv.rowmap, w->cs, /*boot=*/true, s, h->d_Xh, h->xh_cap,
-                                          (uint32_t)(sp.span / (int64_t)(sp.count / 16)));
+                                          nq, nullptr, rv.rowmap, w->cs, /*boot=*/true, s, have_xh ? h->d_Xh : nullptr, h->xh_cap,
+                                          (uint32_t)(sp.span / (int64_t)(sp.count / 16)), d_qnrm, gsum);
             }
             ProfScope p(w, s, prof, 1);
             launch_sample_tau(w->cs, nullptr, nq, sp.count, sp.m, false, s, d_q, h->dim, norm_riders ? w->d_qna : nullptr, order);
@@ -1041,7 +1052,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
             const bool ckeys = centred && use_tall16; // (the keys of this search were taken about the image's centre)
             launch_finish(metric, order, h->d_X, h->dim, d_q, nq, w->d_qna, w->cs, k, ckeys ? h->d_cstats : h->d_maxnorm2, gamma, finish_beta,
                           h->has_ids ? h->d_ids : nullptr, entries_pos ? rv.rowmap : nullptr, d_dist, d_lab, s, w->h_flags, w->d_done, w->d_xcnt,
-                          w->d_xscratch, kFinishSplitMaxQ, smax, ckeys ? h->d_center : nullptr);
+                          w->d_xscratch, kFinishSplitMaxQ, smax, ckeys ? h->d_center : nullptr, dot_lb ? h->d_norm2 : nullptr, d_qnrm, gsum);
         } else {
             launch_rerank(metric, order, h->d_X, h->dim, d_q, nq, w->d_qna, w->cs, kc, k, h->d_maxnorm2, gamma,
                           h->has_ids ? h->d_ids : nullptr, d_dist, d_lab, s, w->h_flags, w->d_done);
@@ -1311,7 +1322,7 @@ void drop_f16_image(lb_gpu_index *h)
     h->d_Xh = nullptr;
     h->d_norm2c = nullptr;
     h->xh_rows = h->xh_cap = 0;
-    h->xh_centred = h->xh_c_ok = false;
+    h->xh_centred = h->xh_c_ok = h->xh_offset_dom = false;
 }
 
 // Recompute the visible-row list from d_mask (caller holds the exclusive lock).  The list is used
@@ -1484,6 +1495,11 @@ void sync_f16_image(lb_gpu_index *h)
                     drop_f16_image(h);
                     return;
                 }
+                std::vector<float> hc((size_t)h->dim);
+                LB_HIP(hipMemcpy(hc.data(), h->d_center, hc.size() * sizeof(float), hipMemcpyDeviceToHost));
+                double c2 = 0.0;
+                for (float v : hc) c2 += (double)v * (double)v;
+                h->xh_offset_dom = c2 > 4.0 * (double)mx;
             }
             LB_HIP(hipStreamSynchronize(s));
             h->xh_rows = h->n;

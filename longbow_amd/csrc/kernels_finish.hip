@@ -51,6 +51,10 @@ struct FinishArgs {
     const uint32_t *posmap; // or null: the lists carry positions of this row list (a filtered view), not corpus rows
     const float *center;    // or null (L2 only): the keys were taken about this centre -- key + |q - c|^2 ~ d^2, the proof's norms
                             // are the centred ones (maxnorm2 then points at the centred maximum); the exact sums are untouched
+    // dot product with LOWER-BOUND keys (the persistent fp16 kernels, kernels_gemm_tall16.hip): key' = -(q.x)~ / G - |x|,
+    // G = lb_gsum * lb_qnrm[q], so that -q.x >= key' G for every row, however long.  lb_norm2 (or null: plain keys): the rows' |x|^2
+    const float *lb_norm2, *lb_qnrm;
+    float lb_gsum;
     float *out_dist;
     int64_t *out_labels;
     uint32_t *flags_host;
@@ -313,6 +317,32 @@ __global__ __launch_bounds__(FN_THREADS) void finish_kernel(FinishArgs a)
                     (METRIC == METRIC_COS ? nqn : 1.0f); // (cosine: the slack is in distance units, keys are |q| times that)
     float cutk = ak + (1.0f + a.beta) * E;
     if (!(cutk >= ak)) cutk = ak; // (NaN / overflow: the proof below decides)
+    const bool dot_lb = METRIC == METRIC_DOT && a.lb_norm2 != nullptr;
+    float lbG = 0.f;
+    if (dot_lb) {
+        // Lower-bound keys: -q.x >= key' G for every row, and -q.x <= (key' + 2 |x|) G.  So the k-th smallest of the UPPER
+        // bounds U = key' + 2 |x| over the list bounds the k-th best exact value from above, and every row that can still be
+        // among the k best has key' <= that: the cut.  A very long row has a very low key' (it might be anything) and a very
+        // high U: it becomes a member, is scored exactly, and widens nobody else's bound.
+        lbG = a.lb_gsum * a.lb_qnrm[qi];
+        const float pad = 1.0f + (a.lb_gsum > 0.f ? 6.0e-7f / a.lb_gsum : 0.f) + 1.0e-5f + 1.05f * (float)(D + 8) * 5.9604645e-8f;
+        uint64_t u[PER];
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            u[j] = kEntryMax;
+            if (e[j] != kEntryMax) {
+                uint32_t row = entry_row(e[j]);
+                if (a.posmap) row = a.posmap[row];
+                const float up = entry_key(e[j]) + 2.0f * sqrtf(a.lb_norm2[row]) * pad * pad;
+                u[j] = pack_entry(up, (uint32_t)tid + (uint32_t)FN_THREADS * j);
+            }
+        }
+        const float uk = entry_key(radix_kth_regs<PER>(u, kk, hist, wsum, scal, red, tid));
+        cutk = uk + fabsf(uk) * 1.0e-5f + 1.0e-30f;
+        if (!(cutk >= uk)) cutk = FLT_MAX;
+        if (tid == 0) { scal[2] = 0; scal[3] = 0; }
+        __syncthreads();
+    }
     if (kk < (uint32_t)k) cutk = FLT_MAX; // fewer entries than results wanted: all of them
     uint32_t cut_s = f32_sortable(cutk + 0.0f);
     const uint32_t tau_s = (uint32_t)(tau >> 32);
@@ -635,6 +665,7 @@ __global__ __launch_bounds__(FN_THREADS) void finish_kernel(FinishArgs a)
         const float slack = out_slack<METRIC>(cutf, dk, nq2, nqn, xmax, ga, go);
         if (METRIC == METRIC_L2) T = (cutf + nq2) - slack;
         else if (METRIC == METRIC_COS) T = 1.0f + (na > 0.f ? __fdiv_rn(cutf, sqrtf(na)) : 0.f) - slack;
+        else if (dot_lb) T = cutf * lbG; // (-q.y >= key'(y) G > cut G; the roundings of the key are inside its padded |x|)
         else T = cutf - slack;
         T = T - fabsf(T) * 1e-6f;
         unsigned int local = 0;
@@ -656,11 +687,14 @@ size_t finish_scratch_bytes(int nq_split_max, uint32_t smax) { return (size_t)nq
 void launch_finish(int metric, int order, const float *X, int D, const float *Q, int nq, const float *qna, CandState cs, int k,
                    const uint32_t *d_maxnorm2, float gamma, float beta, const int64_t *ids, const uint32_t *posmap, float *out_dist,
                    int64_t *out_labels, hipStream_t s, uint32_t *flags_host, uint32_t *done, uint32_t *xcnt, void *xscratch,
-                   int nq_split_max, uint32_t smax, const float *center)
+                   int nq_split_max, uint32_t smax, const float *center, const float *lb_norm2, const float *lb_qnrm, float lb_gsum)
 {
     if (nq <= 0) return;
     FinishArgs a;
     a.center = metric == METRIC_L2 ? center : nullptr;
+    a.lb_norm2 = metric == METRIC_DOT ? lb_norm2 : nullptr;
+    a.lb_qnrm = lb_qnrm;
+    a.lb_gsum = lb_gsum;
     a.X = X; a.D = D; a.Q = Q; a.qna = qna; a.cs = cs; a.k = k; a.maxnorm2 = d_maxnorm2; a.gamma = gamma; a.beta = beta;
     a.ids = ids; a.posmap = posmap; a.out_dist = out_dist; a.out_labels = out_labels; a.flags_host = flags_host;
     a.smax = smax; a.done = done; a.xcnt = xcnt;

@@ -80,6 +80,11 @@ struct Tall16Args {
                          // by side, so a request of 16 query rows is ONE KiB of whole lines instead of 16 half lines: -10 %
                          // on the kernel), each query scaled by a power of two to 1 <= |q| < 2
     const float *qinv;   // [nq] 1 / that scale (exact)
+    const float *qnrm;   // [nq] an upper bound of |q| (dot product, persistent forms: the lower-bound key, see gsum)
+    float gsum;          // dot product, persistent forms: gamma_a + gamma_o.  The candidate key is -(q.x)~ / G - |x| with
+                         // G = gsum |q| -- a lower bound of -q.x (in units of G) whatever the row's norm, so that a few very long
+                         // rows, whose products are uncertain by gamma_a |q||x|, sort to the FRONT of the list and are scored
+                         // exactly instead of widening every other row's error bound (kernels_finish.hip: dot_lb)
     int nq;              // queries of this launch (Qh, qinv and the candidate state start at its first one)
     int q_stride;        // query rows per K-block plane of Qh (the whole batch; a launch may cover a part of it)
     const uint8_t *mask;
@@ -532,9 +537,12 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
     const int last_q = a.nq - 1;
     const uint32_t last_pos = (uint32_t)(a.row_end - a.row_begin - 1); // positions of this launch: corpus row = row_begin + position (sample pass: h_rowof)
     const uint32_t gstride = BOOT ? a.gstride : 0u;
+    // dot product: |x| of the lower-bound key, padded for the f32 roundings of the key's own fma (they are relative to the first
+    // term, up to 1 / (gamma_a + gamma_o) times |x|) and of the stored norm
+    const float dot_pad = 1.0f + (a.gsum > 0.f ? 6.0e-7f / a.gsum : 0.f) + 1.0e-5f + 1.05f * (float)(a.D + 8) * 5.9604645e-8f;
     const unsigned char *Xb = reinterpret_cast<const unsigned char *>(a.X + a.row_begin * (int64_t)a.D);
     const int64_t row_bytes = (int64_t)a.D * 4;
-    const float *auxg = METRIC == METRIC_L2 ? a.norm2 + (MAPPED ? 0 : a.row_begin) : (METRIC == METRIC_COS ? a.rnorm + (MAPPED ? 0 : a.row_begin) : nullptr);
+    const float *auxg = METRIC == METRIC_COS ? a.rnorm + (MAPPED ? 0 : a.row_begin) : a.norm2 + (MAPPED ? 0 : a.row_begin); // (dot: |x| for the lower-bound key)
     auto rt_of = [&](int i) { return (uint32_t)((group + gpx * i) * 8 + xcd) * H_BM; }; // first position of tile i
     // MAPPED: row ids of three tiles, [3][512] (every wave asks for 64: entries 256 .. 511 repeat 0 .. 255, as the side inputs do)
     const uint32_t *s_rowid = reinterpret_cast<const uint32_t *>(s_auxp + 2 * 512);
@@ -602,7 +610,6 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
         else if (it + 1 < n_my) { it++; ik = 0; cursor_new_tile = true; }
     };
     auto aux_request = [&](int i) { // side input of tile i -> buffer i & 1 (every wave asks for 64 rows: entries 256 .. 511 repeat 0 .. 255)
-        if (METRIC == METRIC_DOT) return;
         uint32_t pos = rt_of(i) + (uint32_t)((wave & 3) * 64 + lane);
         if (pos > last_pos) pos = last_pos;
         uint32_t src_row = h_rowof(pos, gstride);
@@ -652,8 +659,12 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
         const float tk = tau_key_of(tau);
         qs[tn] = a.qinv[qc];
         m2qs[tn] = -2.0f * qs[tn];
+        if (METRIC == METRIC_DOT) { // key' = -(q.x)~ / G - |x|, G = (gamma_a + gamma_o) |q|: a LOWER bound of -q.x in units of G
+            const float G = a.gsum * a.qnrm[qc];
+            m2qs[tn] = G > 0.f ? -qs[tn] / G : 0.f;
+        }
         const float scale = __builtin_bit_cast(float, (254u << 23) - __builtin_bit_cast(uint32_t, qs[tn]));
-        tkc[tn] = METRIC == METRIC_L2 ? tk : tk * scale;
+        tkc[tn] = METRIC != METRIC_COS ? tk : tk * scale;
     }
     // admission segments: what is left of the LDS beside the ring (3.2 KB per wave with the fp16 copy, 1.2 KB without)
     // (MAPPED: the row-id ring takes 6 KB of it -- only built over the image)
@@ -775,7 +786,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
         // One K-step per tile (D <= 32): this tile's side input was asked for in the middle of the step before, which the
         // K-steps' waits do not cover (they cover a stage asked for DIST steps earlier, and with it everything older).  By now
         // 2 NPS - H1 (+ 1) requests are newer than it; vmcnt retires in order, the barrier publishes the other waves' parts.
-        if (PIPE && nk == 1 && METRIC != METRIC_DOT) {
+        if (PIPE && nk == 1) {
             h_wait_vmcnt<2 * NPS - H1>();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -801,10 +812,10 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
             for (int g = 0; g < 4; g++) {
                 const int lr = wr * 64 + tm * 32 + 8 * g + 4 * h;
                 f32x4 av = {1.f, 1.f, 1.f, 1.f};
-                if (METRIC != METRIC_DOT) av = *reinterpret_cast<const f32x4 *>(&s_aux[lr]);
+                av = *reinterpret_cast<const f32x4 *>(&s_aux[lr]);
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    const float v = METRIC == METRIC_L2 ? av[e] : -av[e];
+                    const float v = METRIC == METRIC_L2 ? av[e] : (METRIC == METRIC_COS ? -av[e] : -sqrtf(av[e]) * dot_pad);
                     aux[g][e] = pos0 + (uint32_t)(8 * g + e) <= last_pos ? v : __builtin_nanf("");
                 }
             }
@@ -818,25 +829,25 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
                     if (qok) {
 #pragma unroll
                         for (int x = 0; x < 16; x++) {
-                            const float kp = METRIC == METRIC_L2 ? fmaf(acc[tm][tn][x], m2qs[tn], aux[x >> 2][x & 3])
+                            const float kp = METRIC != METRIC_COS ? fmaf(acc[tm][tn][x], m2qs[tn], aux[x >> 2][x & 3])
                                                                  : acc[tm][tn][x] * aux[x >> 2][x & 3];
                             const uint32_t px = pos0 + (uint32_t)(8 * (x >> 2) + (x & 3));
                             if (px <= last_pos)
-                                list[px] = pack_entry(METRIC == METRIC_L2 ? kp : kp * qs[tn], (uint32_t)a.row_begin + h_rowof(px, gstride));
+                                list[px] = pack_entry(METRIC != METRIC_COS ? kp : kp * qs[tn], (uint32_t)a.row_begin + h_rowof(px, gstride));
                         }
                     }
                     continue;
                 }
 #pragma unroll
                 for (int x = 0; x < 16; x++) {
-                    const float kp = METRIC == METRIC_L2 ? fmaf(acc[tm][tn][x], m2qs[tn], aux[x >> 2][x & 3])
+                    const float kp = METRIC != METRIC_COS ? fmaf(acc[tm][tn][x], m2qs[tn], aux[x >> 2][x & 3])
                                                          : acc[tm][tn][x] * aux[x >> 2][x & 3];
                     const bool adm = kp <= tkc[tn]; // (a padded query's threshold is NaN)
                     const uint64_t am = __builtin_amdgcn_ballot_w64(adm);
                     if (am != 0) { // (wave-uniform; one element in six has an admitted lane)
                         if (adm) {
                             const uint32_t sl = wcnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
-                            const float key = METRIC == METRIC_L2 ? kp : kp * qs[tn];
+                            const float key = METRIC != METRIC_COS ? kp : kp * qs[tn];
                             const uint32_t rid = rid0 + 8 * (x >> 2) + (x & 3);
                             if (sl < WCAP) {
                                 s_key[sl] = key;
@@ -925,7 +936,10 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
     const int last_q = a.nq - 1;
     const uint32_t last_pos = hi - 1;
     const uint32_t gstride = BOOT ? a.gstride : 0u;
-    const float *auxg = METRIC == METRIC_L2 ? a.norm2 + (MAPPED ? 0 : a.row_begin) : (METRIC == METRIC_COS ? a.rnorm + (MAPPED ? 0 : a.row_begin) : nullptr);
+    // dot product: |x| of the lower-bound key, padded for the f32 roundings of the key's own fma (they are relative to the first
+    // term, up to 1 / (gamma_a + gamma_o) times |x|) and of the stored norm
+    const float dot_pad = 1.0f + (a.gsum > 0.f ? 6.0e-7f / a.gsum : 0.f) + 1.0e-5f + 1.05f * (float)(a.D + 8) * 5.9604645e-8f;
+    const float *auxg = METRIC == METRIC_COS ? a.rnorm + (MAPPED ? 0 : a.row_begin) : a.norm2 + (MAPPED ? 0 : a.row_begin); // (dot: |x| for the lower-bound key)
     auto rt_of = [&](int i) { return lo + (uint32_t)i * H_BM; }; // first position of tile i
     // MAPPED: row ids of three tiles, [3][512] (every wave asks for 64: entries 256 .. 511 repeat 0 .. 255, as the side inputs do)
     const uint32_t *s_rowid = reinterpret_cast<const uint32_t *>(s_auxp + 2 * 512);
@@ -983,7 +997,6 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
         else if (it + 1 < n_my) { it++; ik = 0; cursor_new_tile = true; }
     };
     auto aux_request = [&](int i) {
-        if (METRIC == METRIC_DOT) return;
         uint32_t pos = rt_of(i) + (uint32_t)((wave & 3) * 64 + lane);
         if (pos > last_pos) pos = last_pos;
         uint32_t src_row = h_rowof(pos, gstride);
@@ -1029,8 +1042,12 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
         const float tk = tau_key_of(tau);
         qs[tn] = a.qinv[qc];
         m2qs[tn] = -2.0f * qs[tn];
+        if (METRIC == METRIC_DOT) { // key' = -(q.x)~ / G - |x|, G = (gamma_a + gamma_o) |q|: a LOWER bound of -q.x in units of G
+            const float G = a.gsum * a.qnrm[qc];
+            m2qs[tn] = G > 0.f ? -qs[tn] / G : 0.f;
+        }
         const float scale = __builtin_bit_cast(float, (254u << 23) - __builtin_bit_cast(uint32_t, qs[tn]));
-        tkc[tn] = METRIC == METRIC_L2 ? tk : tk * scale;
+        tkc[tn] = METRIC != METRIC_COS ? tk : tk * scale;
 #ifdef LB_DIAG
         if (a.abl == 8) tkc[tn] = -__builtin_huge_valf(); // timing only: nothing is admitted
 #endif
@@ -1114,7 +1131,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
         // than that stage: from three K-steps per tile on).  Requests newer than it by now: 2 NPS - H1 (+ 1) at one K-step per
         // tile (asked for in the middle of the step before), 3 NPS (+ 1) at two (at the top of the tile before's second step);
         // vmcnt retires in order, and the barrier publishes the other waves' parts.
-        if (PIPE && nk <= 2 && METRIC != METRIC_DOT) {
+        if (PIPE && nk <= 2) {
             if (nk == 1) h_wait_vmcnt<2 * NPS - H1>();
             else h_wait_vmcnt<3 * NPS>();
             __builtin_amdgcn_s_barrier();
@@ -1128,10 +1145,10 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
         for (int g = 0; g < 4; g++) {
             const int lr = wave * 32 + 8 * g + 4 * h;
             f32x4 av = {1.f, 1.f, 1.f, 1.f};
-            if (METRIC != METRIC_DOT) av = *reinterpret_cast<const f32x4 *>(&s_aux[lr]);
+            av = *reinterpret_cast<const f32x4 *>(&s_aux[lr]);
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                const float v = METRIC == METRIC_L2 ? av[e] : -av[e];
+                const float v = METRIC == METRIC_L2 ? av[e] : (METRIC == METRIC_COS ? -av[e] : -sqrtf(av[e]) * dot_pad);
                 aux[g][e] = pos0 + (uint32_t)(8 * g + e) <= last_pos ? v : __builtin_nanf("");
             }
         }
@@ -1145,23 +1162,23 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
                 if (qok) {
 #pragma unroll
                     for (int x = 0; x < 16; x++) {
-                        const float kp = METRIC == METRIC_L2 ? fmaf(acc[tn][x], m2qs[tn], aux[x >> 2][x & 3]) : acc[tn][x] * aux[x >> 2][x & 3];
+                        const float kp = METRIC != METRIC_COS ? fmaf(acc[tn][x], m2qs[tn], aux[x >> 2][x & 3]) : acc[tn][x] * aux[x >> 2][x & 3];
                         const uint32_t px = pos0 + (uint32_t)(8 * (x >> 2) + (x & 3));
                         if (px <= last_pos)
-                            list[px] = pack_entry(METRIC == METRIC_L2 ? kp : kp * qs[tn], (uint32_t)a.row_begin + h_rowof(px, gstride));
+                            list[px] = pack_entry(METRIC != METRIC_COS ? kp : kp * qs[tn], (uint32_t)a.row_begin + h_rowof(px, gstride));
                     }
                 }
                 continue;
             }
 #pragma unroll
             for (int x = 0; x < 16; x++) {
-                const float kp = METRIC == METRIC_L2 ? fmaf(acc[tn][x], m2qs[tn], aux[x >> 2][x & 3]) : acc[tn][x] * aux[x >> 2][x & 3];
+                const float kp = METRIC != METRIC_COS ? fmaf(acc[tn][x], m2qs[tn], aux[x >> 2][x & 3]) : acc[tn][x] * aux[x >> 2][x & 3];
                 const bool adm = kp <= tkc[tn];
                 const uint64_t am = __builtin_amdgcn_ballot_w64(adm);
                 if (am != 0) {
                     if (adm) {
                         const uint32_t sl = wcnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
-                        const float key = METRIC == METRIC_L2 ? kp : kp * qs[tn];
+                        const float key = METRIC != METRIC_COS ? kp : kp * qs[tn];
                         const uint32_t rid = rid0 + 8 * (x >> 2) + (x & 3);
                         if (sl < WCAP) {
                             s_key[sl] = key;
@@ -1319,11 +1336,13 @@ bool tall16_entries_are_positions(int D, int nq, bool img, bool mapped, bool mas
 static void tall16_window(int metric, const float *X, const float *norm2, const float *rnorm, int64_t row_begin, int64_t row_end,
                           int D, const void *Qh, const float *qinv, int nq, int q_stride, const uint8_t *mask,
                           const uint32_t *rowmap, CandState cs, bool boot, hipStream_t s, const void *Xh, int64_t xh_cap,
-                          bool may_split, uint32_t gstride)
+                          bool may_split, uint32_t gstride, const float *qnrm, float gsum)
 {
     if (row_end <= row_begin || nq <= 0) return;
     Tall16Args a;
     a.gstride = gstride;
+    a.qnrm = qnrm;
+    a.gsum = gsum;
     a.rowmap = rowmap;
     a.X = X; a.norm2 = norm2; a.rnorm = rnorm; a.row_begin = row_begin; a.row_end = row_end; a.D = D;
     a.Qh = reinterpret_cast<const _Float16 *>(Qh); a.qinv = qinv; a.nq = nq; a.q_stride = q_stride; a.mask = mask; a.cs = cs; a.boot = boot ? 1 : 0;
@@ -1359,13 +1378,13 @@ static void tall16_window(int metric, const float *X, const float *norm2, const 
         if (img && may_split && split_tail && nq > H_BN && tail >= 1 && tail <= 64) {
             const int head = nq - tail;
             tall16_window(metric, X, norm2, rnorm, row_begin, row_end, D, Qh, qinv, head, q_stride, mask, rowmap, cs, boot, s, Xh,
-                          xh_cap, false, gstride);
+                          xh_cap, false, gstride, qnrm, gsum);
             CandState ct = cs;
             ct.lists += (size_t)head * cs.cap;
             ct.cnt += head;
             ct.tau += head;
             tall16_window(metric, X, norm2, rnorm, row_begin, row_end, D, reinterpret_cast<const _Float16 *>(Qh) + (size_t)head * H_BK,
-                          qinv + head, tail, q_stride, mask, rowmap, ct, boot, s, Xh, xh_cap, false, gstride);
+                          qinv + head, tail, q_stride, mask, rowmap, ct, boot, s, Xh, xh_cap, false, gstride, qnrm ? qnrm + head : nullptr, gsum);
             return;
         }
         static const int n16 = lb_tunable("LB_F16_NARROW", 1);
@@ -1494,11 +1513,11 @@ static void tall16_window(int metric, const float *X, const float *norm2, const 
 void launch_gemm_filter_tall16(int metric, const float *X, const float *norm2, const float *rnorm, int64_t row_begin,
                                int64_t row_end, int D, const void *Qh, const float *qinv, int nq, const uint8_t *mask,
                                const uint32_t *rowmap, CandState cs, bool boot, hipStream_t s, const void *Xh, int64_t xh_cap,
-                               uint32_t gstride)
+                               uint32_t gstride, const float *qnrm, float gsum)
 {
     // (the granule-strided sample view exists in the persistent forms only)
     if (gstride != 0 && (!boot || !tall16_persistent_ok(D, nq, Xh != nullptr, rowmap != nullptr, mask != nullptr))) return;
-    tall16_window(metric, X, norm2, rnorm, row_begin, row_end, D, Qh, qinv, nq, nq, mask, rowmap, cs, boot, s, Xh, xh_cap, true, gstride);
+    tall16_window(metric, X, norm2, rnorm, row_begin, row_end, D, Qh, qinv, nq, nq, mask, rowmap, cs, boot, s, Xh, xh_cap, true, gstride, qnrm, gsum);
 }
 
 } // namespace lb

@@ -487,7 +487,7 @@ __device__ __forceinline__ float exact_sq_norm_lds(const float *sq, int D)
 // reset of the query's candidate state.  (A zero or non-finite query keeps scale 1: the exact scan answers it anyway.)
 // center (or null; L2 over the centred image): the image holds q - center (the exact norm, cosine only, is never asked for then)
 __global__ __launch_bounds__(64) void query_prep_kernel(const float *Q, int nq, int D, _Float16 *Qh, float *qinv, float *qna, int order,
-                                                        CandState cs, const float *center)
+                                                        CandState cs, const float *center, float *qnrm)
 {
     extern __shared__ __attribute__((aligned(16))) float sq[];
     const int q = blockIdx.x, lane = threadIdx.x;
@@ -516,6 +516,8 @@ __global__ __launch_bounds__(64) void query_prep_kernel(const float *Q, int nq, 
     for (int i = lane; i < Dp; i += 64) Qh[((int64_t)(i >> 5) * nq + q) * 32 + (i & 31)] = i < D ? (_Float16)(sq[i] * scale) : (_Float16)0.f;
     if (lane == 0) {
         qinv[q] = inv;
+        // (s is an f32 sum in some order: relative error below (D + 8) 2^-24)
+        if (qnrm) qnrm[q] = (s < 3.0e38f) ? sqrtf(s) * (1.000002f + 1.05f * (float)(D + 8) * 5.9604645e-8f) : s;
         cs.cnt[q] = 0;
         cs.tau[q] = kEntryMax;
         cs.flags[q] = 0;
@@ -524,11 +526,11 @@ __global__ __launch_bounds__(64) void query_prep_kernel(const float *Q, int nq, 
 }
 
 void launch_query_prep(const float *Q, int nq, int D, void *Qh, float *qinv, float *qna, int order, CandState cs, hipStream_t s,
-                       const float *center)
+                       const float *center, float *qnrm)
 {
     if (nq <= 0) return;
     hipLaunchKernelGGL(query_prep_kernel, dim3((unsigned)nq), dim3(64), (size_t)((D + 3) & ~3) * sizeof(float), s, Q, nq, D,
-                       reinterpret_cast<_Float16 *>(Qh), qinv, center ? nullptr : qna, order, cs, center);
+                       reinterpret_cast<_Float16 *>(Qh), qinv, center ? nullptr : qna, order, cs, center, qnrm);
 }
 
 // R = sampled rows per wave: every query chunk fetched from L2 is used for R rows (with 32 query

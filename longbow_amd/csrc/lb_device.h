@@ -206,15 +206,18 @@ void launch_queries_to_f16(const float *Q, int nq, int D, void *Qh, float *qinv,
 // the same image and scales, plus the exact ||q||^2 in `order` (qna, or null) and the reset of the queries' candidate state:
 // one launch for what a search over this route needs from its batch (kernels_scan.hip)
 void launch_query_prep(const float *Q, int nq, int D, void *Qh, float *qinv, float *qna, int order, CandState cs, hipStream_t s,
-                       const float *center = nullptr); // center: the image of q - center (L2 over the centred corpus image)
+                       const float *center = nullptr, // center: the image of q - center (L2 over the centred corpus image)
+                       float *qnrm = nullptr);        // [nq] upper bounds of |q| (the dot product's lower-bound key)
 // Xh (or null): the corpus's K-blocked fp16 image [Dp / 32][xh_cap][32] from launch_corpus_to_f16, in step with X; used by
 // unfiltered searches (half the bytes to stage, a four-stage ring)
 void launch_gemm_filter_tall16(int metric, const float *X, const float *norm2, const float *rnorm, int64_t row_begin,
                                int64_t row_end, int D, const void *Qh, const float *qinv, int nq, const uint8_t *mask,
                                const uint32_t *rowmap, CandState cs, bool boot, hipStream_t s, const void *Xh = nullptr,
                                int64_t xh_cap = 0,
-                               uint32_t gstride = 0); // boot launches of the persistent forms: positions = granules of 16 rows,
-                                                     // gstride rows apart (an evenly spaced sample read in whole KiB)
+                               uint32_t gstride = 0,  // boot launches of the persistent forms: positions = granules of 16 rows,
+                                                      // gstride rows apart (an evenly spaced sample read in whole KiB)
+                               const float *qnrm = nullptr, float gsum = 0.f); // dot product on the persistent forms: upper bounds
+                                                      // of |q| (launch_query_prep) and gamma_a + gamma_o -- the lower-bound key
 void launch_corpus_to_f16(const float *X, int64_t row_begin, int64_t row_end, int D, void *Xh, int64_t cap, hipStream_t s,
                           const float *center = nullptr); // center (or null; [>= D + 8]): the image holds fp16(x - center)
 int corpus_f16_plane_dims(); // dimensions per plane of that image (its rows are zero-padded to a multiple of it)
@@ -273,7 +276,8 @@ void launch_finish(int metric, int order, const float *X, int D, const float *Q,
                    const uint32_t *d_maxnorm2, float gamma, float beta, const int64_t *ids, const uint32_t *posmap, float *out_dist,
                    int64_t *out_labels, hipStream_t s, uint32_t *flags_host, uint32_t *done, uint32_t *xcnt, void *xscratch,
                    int nq_split_max, uint32_t smax,
-                   const float *center = nullptr); // L2 keys taken about this centre: d_maxnorm2 = the centred maximum norm
+                   const float *center = nullptr, // L2 keys taken about this centre: d_maxnorm2 = the centred maximum norm
+                   const float *lb_norm2 = nullptr, const float *lb_qnrm = nullptr, float lb_gsum = 0.f); // dot: lower-bound keys
 
 // ||q||^2 per selected query slot in the requested accumulation order (cosine).
 void launch_query_norms(int order, const float *Q, const int *qsel, int nsel, int D, float *qna,
