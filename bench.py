@@ -185,8 +185,9 @@ def leg_pq_adc(torch, dev, lib, _lib, cores, check=True):
         "ms_per_query": round(ms1, 4), "queries_per_s": round(1e3 / ms1, 1),
         "ms_per_query_after_2s_idle": round(min(rested), 4),
         "ms_per_query_at_B2": round(ms2 / 2, 4), "ms_per_query_at_B4": round(ms4 / 4, 4),
-        "batch_note": "B >= 2: two queries share one pass over the codes (the pass is bound by LDS gathers + stream, not by the "
-                      "stream alone); each query's result equals its single-query search",
+        "batch_note": "batches: FOUR queries share one pass over the codes (their byte tables interleaved, one LDS gather per code byte "
+                      "for all four; a remainder of two or three runs as a pair + one) -- the pass is bound by the LDS gathers, not by "
+                      "the stream; each query's result equals its single-query search",
         "batch_equals_single_query_searches": pair_ok,
         "roofline": {"bound": "hbm", "kernel": "adc_prefilter_kernel", "achieved": round(n * M / (k_ms * 1e-3) / 1e9, 1),
                      "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(n * M / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "liblongbow_gpu.so")
 OUT_DIAG = os.path.join(HERE, "liblongbow_gpu_diag.so")
-SOURCES = ["index.hip", "pq.hip", "comm.hip", "flight.hip", "kernels_gemm.hip", "kernels_gemm_narrow.hip", "kernels_gemm_tall.hip", "kernels_gemm_tall2.hip", "kernels_gemm_tall16.hip", "kernels_scan.hip", "kernels_select.hip", "kernels_finish.hip",
+SOURCES = ["index.hip", "pq.hip", "comm.hip", "flight.hip", "kernels_gemm.hip", "kernels_gemm_narrow.hip", "kernels_gemm_tall2.hip", "kernels_gemm_tall16.hip", "kernels_scan.hip", "kernels_select.hip", "kernels_finish.hip",
            "kernels_pq.hip", "kernels_pq2.hip", "kernels_filter.hip"]
 HEADERS = ["lb_device.h", "lb_host.h", "lb_combine.h", "lb_select.h", os.path.join("..", "..", "include", "longbow_gpu.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -230,6 +230,8 @@ struct lb_gpu_index {
     uint32_t *d_maxnorm2 = nullptr;
     bool nonfinite = false; // some row holds an inf / NaN: every search takes the exact scan path
     bool f16_ok = false;    // row norms within the fp16 single-product contraction's range (kernels_gemm_tall16.hip)
+    bool norm_spread = false; // the longest row is more than 16 times the shortest non-zero one: dot-product searches then keep
+                              // to the kernels with lower-bound keys under AUTO (plain keys leave such corpora to the exact scan)
     // AUTO backs off from the fp16 route on data whose neighbours are too close for its error bound (many queries then
     // fail the containment proof and are redone by the exact scan): searches left to skip it, and the next back-off span
     std::atomic<int> f16_skip{0}, f16_span{16};
@@ -643,7 +645,7 @@ void scan_with_retry(lb_gpu_index *h, Workspace *w, hipStream_t s, const float *
 // Cost model: a pass over `n` positions of dimension D costs  n * (alpha * D + beta) [+ gamma]  per query tile, with
 // the constants measured per kernel on MI355X over D in {128 .. 1536} x n in {100k .. 10M} (tools/route_grid.py; the
 // GPU test test_route_choice_is_near_the_best_forced_route checks the choice against every forced route).
-enum RouteKind { ROUTE_NARROW32 = 1, ROUTE_NARROW64 = 2, ROUTE_TALL = 3, ROUTE_WIDE = 4, ROUTE_TALL2 = 5, ROUTE_TALL16 = 6,
+enum RouteKind { ROUTE_NARROW32 = 1, ROUTE_NARROW64 = 2, /* 3: the 256 x 128 split tile of rounds 2-3, removed */ ROUTE_WIDE = 4, ROUTE_TALL2 = 5, ROUTE_TALL16 = 6,
                  ROUTE_NARROW16 = 7 /* the fp16 route's 64- / 128-query tile over the fp16 copy: same pipeline as TALL16, reported apart */ };
 struct Route {
     int kind = ROUTE_WIDE;
@@ -655,7 +657,7 @@ struct Route {
 // alpha: the contraction (per position, dimension and query tile); beta: the per-position work that does not scale with
 // D (epilogue: key, admission test, side inputs); hbm: the corpus stream under that kernel (4 bytes per element at the
 // rate the kernel's staging reaches); first: what the first query tile of a multi-tile pass waits for the corpus.
-// Fitted to tools/route_grid.py on MI355X (D in {128, 384, 768, 1536} x n in {100k, 1M, 4M}), see DESIGN.md 3.2.
+// Fitted to tools/route_grid.py on MI355X (D in {128, 384, 768, 1536} x n in {100k, 1M, 4M}), see LABNOTES.md 3.2.
 struct RouteCost {
     double alpha, beta, hbm, first;
     double fixed = 0; // ms per search whatever the corpus: launches, thresholds, select, re-rank (fp16: + the query image, twice the
@@ -664,8 +666,6 @@ struct RouteCost {
 // (narrow tiles: one launch, the corpus tile is read from HBM once and re-used from L2 by the other query tiles)
 constexpr RouteCost kCostNarrow32{0.000323, 0.0247, 0.000640, 0.000300, 0.09};   // per 32-query tile: 1.09 ms at 4M x 768, 0.27 at 4M x 128
 constexpr RouteCost kCostNarrow64{0.000527, 0.0225, 0.000640, 0.000200, 0.09};   // per 64-query tile: 1.71 ms at 4M x 768, 0.36 at 4M x 128
-constexpr RouteCost kCostTallInreg{0.000687, 0.0445, 0.000640, 0.000250, 0.09};  // per 128-query tile: 2.29 ms at 4M x 768, 0.53 at 4M x 128
-constexpr RouteCost kCostTallImage{0.000630, 0.0445, 0.000640, 0.000220, 0.09};
 constexpr RouteCost kCostTall2Inreg{0.001260, 0.1300, 0.000640, 0.000250, 0.09}; // per 256-query tile: 3.9 ms at 4M x 768, 1.16 at 4M x 128
 constexpr RouteCost kCostTall2Image{0.001150, 0.1300, 0.000640, 0.000220, 0.09};
 constexpr RouteCost kCostWideF32{0.001940, 0.0600, 0.000640, 0.0, 0.09};
@@ -686,11 +686,9 @@ static Route choose_route(int nq, int64_t n, int D, int cmode, bool narrow_ok, b
 {
     static const int narrow_max = lb_tunable("LB_NARROW_MAXQ", 384);
     static const bool nsplit_on = lb_tunable("LB_NARROW_SPLIT", 1) != 0;
-    static const int tall_on = lb_tunable("LB_TALL", 1);
     const int tiles32 = (nq + 31) / 32, tiles64 = (nq + 63) / 64, tiles128 = (nq + 127) / 128, tiles256 = (nq + 255) / 256;
     // (tall tiles only with enough of them to fill the chip a few times over: 512 workgroups run at once, and at 125k
     // visible rows x 256 queries the 978 tall tiles came out 5 % behind the 3908 smaller ones)
-    const bool tall_fills = (n / 256) * tiles128 >= 2048;
     const bool tall2_fills = (n / 256) * tiles256 >= 1024; // (one workgroup per CU: 256 run at once)
     Route cand[8];
     int nc = 0;
@@ -701,13 +699,13 @@ static Route choose_route(int nq, int64_t n, int D, int cmode, bool narrow_ok, b
         if (nq <= 32 || tiles32 <= 10) add(ROUTE_NARROW32, nsp, route_ms(kCostNarrow32, n, D, tiles32));
         if (nq > 32) add(ROUTE_NARROW64, nsp, route_ms(kCostNarrow64, n, D, tiles64));
     }
-    if (narrow_ok && tall_on) {
+    // (round 4: the 256 x 128 tile -- ROUTE_TALL, kernels_gemm_tall.hip -- is gone: within 2-5 % of the 64-query narrow tile and of
+    // this one wherever it was picked, profiles/r03_route_grid.txt, and never picked once the fp16 route is on offer)
+    if (narrow_ok) {
         if (image) {
-            add(ROUTE_TALL, 1, route_ms(kCostTallImage, n, D, tiles128));
-            if (nq > 128) add(ROUTE_TALL2, 1, route_ms(kCostTall2Image, n, D, tiles256));
+            add(ROUTE_TALL2, 1, route_ms(kCostTall2Image, n, D, tiles256));
         } else if (nsplit_on && (cmode != LB_CAND_F32_MFMA || nq <= narrow_max)) {
             const bool forced = cmode == LB_CAND_SPLIT_BF16_INREG;
-            if (tall_fills || forced) add(ROUTE_TALL, 2, route_ms(kCostTallInreg, n, D, tiles128));
             if (nq > 128 && (tall2_fills || forced)) add(ROUTE_TALL2, 2, route_ms(kCostTall2Inreg, n, D, tiles256));
         }
     }
@@ -726,8 +724,7 @@ static Route choose_route(int nq, int64_t n, int D, int cmode, bool narrow_ok, b
         }
         else add(ROUTE_TALL16, 3, route_ms(have_f16_image ? kCostTall16Img : kCostTall16, n, D, tiles256));
     }
-    if (image && !tall_on) add(ROUTE_WIDE, 1, route_ms(kCostWideF32, n, D, tiles128) * 0.4);
-    else if (cmode == LB_CAND_F32_MFMA || cmode == LB_CAND_AUTO || nc == 0) add(ROUTE_WIDE, 0, route_ms(kCostWideF32, n, D, tiles128));
+    if (cmode == LB_CAND_F32_MFMA || cmode == LB_CAND_AUTO || nc == 0) add(ROUTE_WIDE, 0, route_ms(kCostWideF32, n, D, tiles128));
 #ifdef LB_DIAG
     { // A/B (tools/route_grid.py): force a route when it is available for this batch (read per call: the tool flips it)
         const char *e = getenv("LB_FORCE_ROUTE");
@@ -807,8 +804,10 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         h->f16_skip.fetch_sub(1, std::memory_order_relaxed);
         f16_offer = false;
     }
-    // (offset-dominated L2 data: only the centred image's keys resolve anything)
-    const int cmode_route = (cmode == LB_CAND_AUTO && centred && h->xh_offset_dom && f16_offer) ? LB_CAND_F16 : cmode;
+    // (offset-dominated L2 data: only the centred image's keys resolve anything; dot product over rows of very different
+    // lengths: only the lower-bound keys do)
+    const bool keys_matter = (centred && h->xh_offset_dom) || (metric == LB_METRIC_DOT && h->norm_spread);
+    const int cmode_route = (cmode == LB_CAND_AUTO && keys_matter && f16_offer) ? LB_CAND_F16 : cmode;
     const Route route = choose_route(nq, n, h->dim, cmode_route, narrow_ok, have_image, f16_offer, have_xh);
     h->last_route.store(route.kind * 10 + route.split, std::memory_order_relaxed);
 #ifdef LB_DIAG
@@ -839,7 +838,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     const bool use_narrow = route.kind == ROUTE_NARROW32 || route.kind == ROUTE_NARROW64;
     const bool tile64 = route.kind == ROUTE_NARROW64;
     const bool nsplit = use_narrow && route.split == 2;
-    const bool use_tall = route.kind == ROUTE_TALL || route.kind == ROUTE_TALL2 || route.kind == ROUTE_TALL16 || route.kind == ROUTE_NARROW16;
+    const bool use_tall = route.kind == ROUTE_TALL2 || route.kind == ROUTE_TALL16 || route.kind == ROUTE_NARROW16;
     const bool use_tall2 = route.kind == ROUTE_TALL2;
     const bool use_tall16 = route.kind == ROUTE_TALL16 || route.kind == ROUTE_NARROW16; // (the launcher takes the 64-query tile by itself)
     const int wsplit = use_narrow ? 0 : route.split;
@@ -916,7 +915,6 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     const bool norm_riders = prep_riders && metric == LB_METRIC_COSINE;
     // the last launch: key-space pruning + exact re-rank + proof in one (kernels_finish.hip); beta: how far beyond one error
     // bound the cut lies (the proof itself never depends on it)
-    static const bool use_finish = lb_tunable("LB_FINISH", 1) != 0;
     static const float finish_beta = 0.01f * (float)lb_tunable("LB_FINISH_BETA_PCT", 25);
     if (!light_sample && !fused && !use_tall16) launch_init_cand(w->cs, nullptr, nq, s);
     if (metric == LB_METRIC_COSINE && !norm_riders && !use_tall16) launch_query_norms(order, d_q, nullptr, nq, h->dim, w->d_qna, s); // (fp16 route: query_prep)
@@ -948,9 +946,6 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         else if (use_tall2)
             launch_gemm_filter_tall2(metric, gx, h->d_norm2, h->d_rnorm, b, e, h->dim, w->d_qs, nq, mask, rowmap, w->cs,
                                      boot, wsplit, s);
-        else if (use_tall)
-            launch_gemm_filter_tall(metric, gx, h->d_norm2, h->d_rnorm, b, e, h->dim, w->d_qs, nq, mask, rowmap, w->cs,
-                                    boot, wsplit, s);
         else
             launch_gemm_filter(metric, gx, h->d_norm2, h->d_rnorm, b, e, h->dim, gq, nq, mask, rowmap, w->cs,
                                boot, wsplit, s);
@@ -1026,7 +1021,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
             candidates(0, sp.span, rv.rowmap, /*boot=*/false);
         }
         // (one span covers the view: the finish launch prunes the raw list itself -- everything below tau is in it)
-        if (sp.span < n || !use_finish) {
+        if (sp.span < n) {
             ProfScope p(w, s, prof, 1);
             launch_select(w->cs, nullptr, nq, kc, 0u, s, false, (uint32_t)kc, nullptr, false, /*unsorted=*/true);
         }
@@ -1046,16 +1041,13 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     }
     {
         ProfScope p(w, s, prof, 2);
-        if (use_finish) {
+        {
             // members a query may have: twice the results wanted, at least 1024 (the lists hold up to cap entries below tau)
             const uint32_t smax = std::min<uint32_t>(kFinishSmaxMax, std::max<uint32_t>(1024u, 2u * next_pow2_host((uint32_t)k)));
             const bool ckeys = centred && use_tall16; // (the keys of this search were taken about the image's centre)
             launch_finish(metric, order, h->d_X, h->dim, d_q, nq, w->d_qna, w->cs, k, ckeys ? h->d_cstats : h->d_maxnorm2, gamma, finish_beta,
                           h->has_ids ? h->d_ids : nullptr, entries_pos ? rv.rowmap : nullptr, d_dist, d_lab, s, w->h_flags, w->d_done, w->d_xcnt,
                           w->d_xscratch, kFinishSplitMaxQ, smax, ckeys ? h->d_center : nullptr, dot_lb ? h->d_norm2 : nullptr, d_qnrm, gsum);
-        } else {
-            launch_rerank(metric, order, h->d_X, h->dim, d_q, nq, w->d_qna, w->cs, kc, k, h->d_maxnorm2, gamma,
-                          h->has_ids ? h->d_ids : nullptr, d_dist, d_lab, s, w->h_flags, w->d_done);
         }
     }
     std::vector<int> bad;
@@ -1396,6 +1388,7 @@ void finish_add(lb_gpu_index *h, int64_t n, const int64_t *ids_src, bool ids_on_
         // row norm bounds the subnormal rounding term of the contraction's error bound (>= 2^-6: kernels_gemm_tall16.hip)
         const float mx = __builtin_bit_cast(float, maxbits), mn = __builtin_bit_cast(float, nbits[1]);
         h->f16_ok = !h->nonfinite && mx <= 67108864.0f /* 2^26 */ && (nbits[1] == 0x7f800000u || mn >= 0.000244140625f /* 2^-12 */);
+        h->norm_spread = !h->nonfinite && nbits[1] != 0x7f800000u && mx > 256.0f * mn;
     }
     h->n += n; // the rows are committed from here on: nothing below may fail the call (a retry would duplicate them)
     try {

@@ -19,7 +19,7 @@
 // extra 32 queries; over SPLIT (the contraction on 3 x bf16 MFMA with both operands split in
 // registers: the default) and over FUSED (5..32 queries: the sampled threshold of the search rides
 // inside the launch -- sample tiles, per-query threshold workgroups, corpus workgroups of two row
-// tiles that pick the thresholds up; see FusedSample in lb_device.h and DESIGN.md 3.3).
+// tiles that pick the thresholds up; see FusedSample in lb_device.h and LABNOTES.md 3.3).
 #include "lb_device.h"
 
 namespace lb {

@@ -31,7 +31,7 @@
 //                                copy's HBM stream
 //   gemm_filter_tall16_kernel    one workgroup per tile, f32 rows through a row map / mask: filtered searches, and batches
 //                                with more query tiles than an XCD has workgroup slots
-// What each design decision bought is in DESIGN.md 4.2 (measured with tools/experiments/dma_patterns.hip).
+// What each design decision bought is in LABNOTES.md 4.2 (measured with tools/experiments/dma_patterns.hip).
 #include "lb_device.h"
 
 #include <type_traits>
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16_kernel(Tall16
 // then), so every K-step issues the same requests and every wait is the same s_waitcnt vmcnt(N).
 // AIMG: the corpus comes from its fp16 image (the index keeps one while memory allows): a stage is 16 KB of corpus + 16 KB of
 // queries, the ring FOUR stages deep and a stage is requested three K-steps ahead -- half the corpus bytes to stage, and
-// a third more time for a line that four CUs ask for at once to arrive.  The image is K-blocked like the
+// a third more time for a line that four CUs ask for at once to arrive (LABNOTES.md 4.2).  The image is K-blocked like the
 // query image: the 64 B a K-step needs of 16 consecutive rows are one KiB of whole lines.
 // BOOT: the launch stores every position's entry (bootstrap chunk of the classic schedule, or -- gstride != 0 -- the sample pass)
 // MAPPED: a filtered view -- the positions index a.rowmap; see the one-tile form below for how the kernel gathers

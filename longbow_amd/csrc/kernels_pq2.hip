@@ -404,6 +404,135 @@ __global__ __launch_bounds__(WAVES * 64) void adc_prefilter_kernel(AdcPreArgs a)
     }
 }
 
+// FOUR queries per pass over the codes (round 4).  The pass is bound by the LDS gather rate (2.3 ms per PAIR of queries at
+// 100M x 96 against a 1.5 ms code stream), so one gather should serve more queries: the four byte tables are interleaved as
+// tab4[j][code] = {b_q0, b_q1, b_q2, b_q3} -- one dword -- and ONE ds_read_b32 per code byte returns all four queries' entries;
+// v_dot4_u32_u8 with a one-hot selector adds each query's byte to its sum (4 VALU per gather, exact integer sums as before).
+// A subtable is 256 dwords = 4 per bank: random codes collide ~4-way, but that is one instruction where the two-query form
+// issues four.  LDS: M KiB of tables + WAVES x 64 M of staging (M = 96: 96 + 60 KB with ten waves).
+struct AdcPre4Args {
+    const uint8_t *qtab[4];
+    const int *params[4];
+    uint32_t *cand[4];
+    uint32_t *cand_cnt[4];
+    const uint8_t *codes;
+    int64_t n;
+    uint32_t cand_cap;
+};
+
+template <int MCH, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void adc_prefilter4_kernel(AdcPre4Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_u8[];
+    constexpr int M = MCH * 16;
+    uint32_t *tab4 = reinterpret_cast<uint32_t *>(smem_u8);            // [M][256] dwords
+    unsigned char *stage_all = smem_u8 + (size_t)M * 1024;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int s_tau[4];
+    bool any = false;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { // (a query whose prefilter is unusable admits nothing: its select flags it, the host redoes it)
+        const int ok = a.params[q][1];
+        s_tau[q] = ok ? a.params[q][0] : -1;
+        any = any || ok != 0;
+    }
+    if (!any) return;
+    for (int i = tid; i < M * 64; i += WAVES * 64) { // dword i of every table = the entries of codes 4 i .. 4 i + 3
+        uint32_t d[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) d[q] = reinterpret_cast<const uint32_t *>(a.qtab[q])[i];
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+            tab4[4 * i + c] = ((d[0] >> (8 * c)) & 0xffu) | (((d[1] >> (8 * c)) & 0xffu) << 8) | (((d[2] >> (8 * c)) & 0xffu) << 16) |
+                              (((d[3] >> (8 * c)) & 0xffu) << 24);
+    }
+    __syncthreads();
+    unsigned char *stage = stage_all + wave * (64 * M);
+    const int64_t ntiles = (a.n + 63) / 64;
+    const int64_t tstride = (int64_t)gridDim.x * WAVES;
+    const unsigned char *last16 = a.codes + a.n * (int64_t)M - 16;
+    auto issue = [&](int64_t tile) {
+        const unsigned char *src0 = a.codes + tile * 64 * (int64_t)M + lane * 16;
+#pragma unroll
+        for (int i = 0; i < MCH; i++) {
+            const unsigned char *src = src0 + i * 1024;
+            if (src > last16) src = last16; // tail tile: stay inside the buffer (rows past the end are discarded)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(stage + i * 1024), 16, 0, 2 /* nt */);
+        }
+    };
+    int64_t tile = (int64_t)blockIdx.x * WAVES + wave;
+    if (tile < ntiles) issue(tile);
+    for (; tile < ntiles; tile += tstride) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint4 c[MCH];
+#pragma unroll
+        for (int i = 0; i < MCH; i++) c[i] = *reinterpret_cast<const uint4 *>(stage + lane * M + i * 16);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // slot fully read before it is refilled
+        if (tile + tstride < ntiles) issue(tile + tstride);
+        uint32_t S[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int g = 0; g < MCH; g++) {
+            const uint32_t w[4] = {c[g].x, c[g].y, c[g].z, c[g].w};
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const int j = g * 16 + t * 4 + b;
+                    const uint32_t code = (w[t] >> (8 * b)) & 0xffu;
+                    const uint32_t v = tab4[j * 256 + code];
+                    S[0] = __builtin_amdgcn_udot4(v, 0x00000001u, S[0], false);
+                    S[1] = __builtin_amdgcn_udot4(v, 0x00000100u, S[1], false);
+                    S[2] = __builtin_amdgcn_udot4(v, 0x00010000u, S[2], false);
+                    S[3] = __builtin_amdgcn_udot4(v, 0x01000000u, S[3], false);
+                }
+        }
+        const int64_t row = tile * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (row < a.n && (int)S[q] <= s_tau[q]) {
+                const uint32_t pos = atomicAdd(a.cand_cnt[q], 1u);
+                if (pos < a.cand_cap) a.cand[q][pos] = (uint32_t)row;
+            }
+    }
+}
+
+template <int MCH, int WAVES>
+static bool try_prefilter4(const AdcPre4Args &a, hipStream_t s)
+{
+    const size_t shmem = (size_t)(MCH * 16) * 1024 + (size_t)WAVES * 64 * (MCH * 16);
+    if (shmem > 160 * 1024) return false;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(adc_prefilter4_kernel<MCH, WAVES>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    const int64_t ntiles = (a.n + 63) / 64;
+    int64_t blocks = (ntiles + WAVES - 1) / WAVES;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL((adc_prefilter4_kernel<MCH, WAVES>), dim3((unsigned)blocks), dim3(WAVES * 64), shmem, s, a);
+    return true;
+}
+
+// four queries in ONE pass over the codes; false = no such form for this M (the caller runs pairs)
+bool launch_adc_prefilter4(const uint8_t *const qtab[4], const int *const params[4], uint32_t *const cand[4], uint32_t *const cand_cnt[4],
+                           int M, const uint8_t *codes, int64_t n, uint32_t cand_cap, hipStream_t s)
+{
+    if (n < 4096 || M % 16 != 0 || (reinterpret_cast<uintptr_t>(codes) & 15) != 0) return false;
+    AdcPre4Args a;
+    for (int q = 0; q < 4; q++) {
+        if ((reinterpret_cast<uintptr_t>(qtab[q]) & 15) != 0) return false;
+        a.qtab[q] = qtab[q]; a.params[q] = params[q]; a.cand[q] = cand[q]; a.cand_cnt[q] = cand_cnt[q];
+    }
+    a.codes = codes; a.n = n; a.cand_cap = cand_cap;
+    switch (M / 16) {
+    case 1: return try_prefilter4<1, 16>(a, s);
+    case 2: return try_prefilter4<2, 16>(a, s);
+    case 3: return try_prefilter4<3, 16>(a, s);
+    case 4: return try_prefilter4<4, 16>(a, s);
+    case 6: return try_prefilter4<6, 10>(a, s);
+    default: return false; // (M = 128: 128 KB of tables leave room for four waves' staging only)
+    }
+}
+
 // The same pass with the codes staged in REGISTERS, not LDS.  A wave's tile is 64 rows = 64 * M contiguous bytes; request i
 // of the wave loads bytes [1024 i, 1024 i + 1024) of it with one coalesced global_load_dwordx4 (nt), so lane l holds the
 // 16-byte chunk c = 64 i + l: sub-quantisers 16 (c % MCH) .. + 15 of row c / MCH (a chunk never straddles a row: M = 16 MCH).

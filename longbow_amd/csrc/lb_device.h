@@ -189,13 +189,8 @@ void launch_gemm_filter_narrow_fused(int metric, const float *X, const float *no
 uint32_t fused_sample_blocks(uint32_t count, int nq, bool tile64); // sample workgroups such a launch starts with
 // f32 [rows][D] -> split-bf16 image (same byte shape; D % 32 == 0) consumed by the split GEMM
 void launch_split_bf16(const float *src, float *dst, int64_t rows, int D, hipStream_t s);
-// split-bf16 contraction on the 256-row x 128-query tile (kernels_gemm_tall.hip); Qs = split image of the batch;
-// asplit 1: X is the split image of the corpus, 2: X is the f32 corpus (split in registers)
-void launch_gemm_filter_tall(int metric, const float *X, const float *norm2, const float *rnorm, int64_t row_begin,
-                             int64_t row_end, int D, const float *Qs, int nq, const uint8_t *mask, const uint32_t *rowmap,
-                             CandState cs, bool boot, int asplit, hipStream_t s);
-
-// the same contraction on 256 x 256 tiles with whole 128-B lines per row and K-step (kernels_gemm_tall2.hip)
+// split-bf16 contraction on 256 x 256 tiles with whole 128-B lines per row and K-step (kernels_gemm_tall2.hip); Qs = split image
+// of the batch (launch_split_bf16); asplit 1: X is the split image of the corpus, 2: X is the f32 corpus (split in registers)
 void launch_gemm_filter_tall2(int metric, const float *X, const float *norm2, const float *rnorm, int64_t row_begin,
                               int64_t row_end, int D, const float *Qs, int nq, const uint8_t *mask, const uint32_t *rowmap,
                               CandState cs, bool boot, int asplit, hipStream_t s);
@@ -259,13 +254,6 @@ void launch_sample_tau(CandState cs, const int *qsel, int nsel, uint32_t count, 
                        const float *Q = nullptr, int D = 0, float *qna = nullptr, int order = 0);
 // smap[i] = row behind the i-th of `count` evenly spaced positions of [0, span) (through rowmap if given)
 void launch_sample_map(const uint32_t *rowmap, int64_t span, uint32_t count, uint32_t *smap, hipStream_t s);
-
-// exact-order distances of the kept candidates, final ordering, containment check, output.
-// gamma: relative rounding-error bound of the candidate inner products (depends on the contraction)
-void launch_rerank(int metric, int order, const float *X, int D, const float *Q, int nq,
-                   const float *qna, CandState cs, int kc, int k, const uint32_t *d_maxnorm2, float gamma,
-                   const int64_t *ids, float *out_dist, int64_t *out_labels, hipStream_t s, uint32_t *flags_host = nullptr,
-                   uint32_t *done = nullptr);
 
 // The last launch of a batched search (kernels_finish.hip): members of each query's candidate list within the key-space cut
 // a_k + (1 + beta) E are re-ranked in the exact order, proven (or flagged: bit 1) and written.  posmap (or null): the lists
@@ -341,6 +329,9 @@ bool launch_adc_prefilter(const uint8_t *qtab, const int *params, int M, const u
 bool launch_adc_prefilter2(const uint8_t *qtab, const int *params, uint32_t *cand, uint32_t *cand_cnt, const uint8_t *qtab2,
                            const int *params2, uint32_t *cand2, uint32_t *cand_cnt2, int M, const uint8_t *codes, int64_t n,
                            uint32_t cand_cap, hipStream_t s);
+// four queries in ONE pass (interleaved byte tables, one dword gather per code byte; false: no such form for this M)
+bool launch_adc_prefilter4(const uint8_t *const qtab[4], const int *const params[4], uint32_t *const cand[4], uint32_t *const cand_cnt[4],
+                           int M, const uint8_t *codes, int64_t n, uint32_t cand_cap, hipStream_t s);
 void launch_adc_exact_candidates(const float *table, int M, const uint8_t *codes, const uint32_t *cand,
                                  const uint32_t *cand_cnt, uint32_t cand_cap, const int *params, int slot, CandState cs,
                                  hipStream_t s);

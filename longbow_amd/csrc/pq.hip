@@ -107,7 +107,7 @@ struct PqScratch {
     uint8_t *d_qtabs = nullptr;  // [nq][M*256] u8
     float *d_minrng = nullptr;   // [nq][M][4]: subtable minimum, range, bad flag
     int *d_params = nullptr;     // [nq][4]
-    uint32_t *d_cand = nullptr;  // [2][kCandCap] survivors of the (up to two) queries in flight
+    uint32_t *d_cand = nullptr;  // [4][kCandCap] survivors of the (up to four) queries in flight
     uint32_t *d_cand_cnt = nullptr; // [nq]
     int *d_slots = nullptr;      // 0..nq-1
     uint64_t *d_samp = nullptr;  // ADC entries of the sampled rows
@@ -160,7 +160,7 @@ std::unique_ptr<PqScratch> acquire_scratch(lb_gpu_pq *p, int nq, uint32_t cap, s
         LBP_HIP(hipMalloc(&sc->d_qtabs, nqc * p->M * 256));
         LBP_HIP(hipMalloc(&sc->d_minrng, nqc * p->M * 4 * sizeof(float)));
         LBP_HIP(hipMalloc(&sc->d_params, nqc * 4 * sizeof(int)));
-        LBP_HIP(hipMalloc(&sc->d_cand, (size_t)2 * kCandCap * 4));
+        LBP_HIP(hipMalloc(&sc->d_cand, (size_t)4 * kCandCap * 4));
         LBP_HIP(hipMalloc(&sc->d_cand_cnt, nqc * 4));
         LBP_HIP(hipMalloc(&sc->d_slots, nqc * sizeof(int)));
         LBP_HIP(hipHostMalloc(&sc->h_flags, nqc * 4, hipHostMallocDefault));
@@ -640,6 +640,41 @@ int lb_gpu_pq_search_device_ctx(lb_gpu_pq *p, int64_t nq, const float *d_queries
             }
             return true;
         };
+        // four queries share ONE pass (interleaved byte tables: one LDS gather per code byte serves all four)
+        auto scan_quad = [&](int q) -> bool {
+            if (!prefilter || !samp_count) return false;
+            const int *prm[4];
+            const uint8_t *qtab[4];
+            uint32_t *cand[4], *ccnt[4];
+            for (int j = 0; j < 4; j++) {
+                const int qq = q + j;
+                const float *tab = sc.d_tables + (size_t)qq * p->M * 256;
+                if (!threshold(qq)) return false;
+                int *prm_w = sc.d_params + qq * 4;
+                uint8_t *qt = sc.d_qtabs + (size_t)qq * p->M * 256;
+                launch_adc_quantise(tab, sc.d_minrng + (size_t)qq * p->M * 4, p->M, sc.cs.tau + qq, qt, prm_w, s);
+                prm[j] = prm_w; qtab[j] = qt;
+                cand[j] = sc.d_cand + (size_t)j * kCandCap;
+                ccnt[j] = sc.d_cand_cnt + qq;
+            }
+            const bool last = q + 3 == nqi - 1;
+            if (prof && last) (void)hipEventRecord(p->ev[2], s);
+            if (!launch_adc_prefilter4(qtab, prm, cand, ccnt, p->M, p->d_codes, p->n, kCandCap, s)) {
+                for (int j = 0; j < 4; j += 2)
+                    if (!launch_adc_prefilter2(qtab[j], prm[j], cand[j], ccnt[j], qtab[j + 1], prm[j + 1], cand[j + 1], ccnt[j + 1], p->M,
+                                               p->d_codes, p->n, kCandCap, s))
+                        for (int u = j; u < j + 2; u++)
+                            launch_adc_prefilter(qtab[u], prm[u], p->M, p->d_codes, p->n, cand[u], kCandCap, ccnt[u], s);
+            }
+            if (prof && last) (void)hipEventRecord(p->ev[3], s);
+            for (int j = 0; j < 4; j++) {
+                const int qq = q + j;
+                const float *tab = sc.d_tables + (size_t)qq * p->M * 256;
+                launch_adc_exact_candidates(tab, p->M, p->d_codes, cand[j], ccnt[j], kCandCap, prm[j], qq, sc.cs, s);
+                launch_select(sc.cs, sc.d_slots + qq, 1, k, 0u, s, false, (uint32_t)std::min<int64_t>(k, p->n), &em);
+            }
+            return true;
+        };
         for (int q = 0; q < nqi; q++) {
             if (ctx && q > 0) { // a cancellable call waits for each pass before it enqueues the next (~10 us each)
                 LBP_HIP(hipStreamSynchronize(s));
@@ -648,6 +683,10 @@ int lb_gpu_pq_search_device_ctx(lb_gpu_pq *p, int64_t nq, const float *d_queries
                     p->set_error(st == LB_ERR_CANCELLED ? "context canceled" : "context deadline exceeded");
                     return st;
                 }
+            }
+            if (q + 3 < nqi && p->pair_pass.load() != 0 && scan_quad(q)) {
+                q += 3;
+                continue;
             }
             if (q + 1 < nqi && p->pair_pass.load() != 0 && scan_pair(q)) {
                 q++;

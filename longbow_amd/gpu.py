@@ -240,7 +240,7 @@ class Index:
         self._live()
         return int(self._lib.lb_gpu_index_ntotal(self._h))
 
-    ROUTE_NAMES = {0: "exact scan", 1: "narrow 256x32", 2: "narrow 128x64", 3: "tall 256x128 split-bf16", 4: "wide 128x128 f32 MFMA",
+    ROUTE_NAMES = {0: "exact scan", 1: "narrow 256x32", 2: "narrow 128x64", 4: "wide 128x128 f32 MFMA",
                    5: "tall 256x256 split-bf16", 6: "tall 256x256 fp16 single product",
                    7: "one query tile (64/128) fp16 single product over the fp16 copy"}
 

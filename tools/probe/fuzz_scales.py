@@ -18,7 +18,7 @@ while time.time() - t0 < budget:
     nq = int(rng.choice([1, 4, 17, 64, 130, 256, 300, 520]))
     k = int(rng.choice([1, 10, 100]))
     metric = int(rng.integers(0, 3))
-    kind = int(rng.integers(0, 7))
+    kind = int(rng.integers(0, 8))
     base = rng.standard_normal((n, d)).astype(F) if rng.integers(0, 2) else rng.random((n, d), dtype=F)
     lo, hi = (-14, 14) if rng.integers(0, 2) else (-6, 6)
     if kind == 0:    # every row its own binade
@@ -32,6 +32,10 @@ while time.time() - t0 < budget:
         X = base * (rng.random((n, d)) < 0.05).astype(F)
     elif kind == 4:  # a large common offset: L2 distances are differences of nearly equal numbers
         X = base * F(0.01) + F(rng.choice([10.0, 1000.0]))
+    elif kind == 7:  # the same offset, queries INSIDE the cloud (below): what the centred L2 image is for.  (Kind 4's queries sit
+        # 0.02 |mean| per dimension away from a cloud 0.01 wide: every row is then equally far within the rounding of the f32
+        # distance itself, (D + 8) 2^-24 d^2 -- no key can certify an order that only the exact sums define)
+        X = base * F(0.01) + F(rng.choice([10.0, 1000.0]))
     elif kind == 5:  # all rows uniformly huge or uniformly tiny
         X = base * F(2.0 ** rng.choice([lo, hi]))
     else:            # a few exact duplicates of the queries' rows at mixed scales
@@ -40,7 +44,8 @@ while time.time() - t0 < budget:
     X = np.ascontiguousarray(X, dtype=F)
     qrows = rng.integers(0, n, nq)
     Q = X[qrows] + (rng.standard_normal((nq, d)).astype(F) * F(0.02) * np.abs(X[qrows]).mean(1, keepdims=True).astype(F))
-    if rng.integers(0, 3) == 0: Q = Q * np.exp2(rng.integers(lo, hi + 1, (nq, 1))).astype(F)
+    if kind == 7: Q = X[qrows] + rng.standard_normal((nq, d)).astype(F) * F(0.002)
+    elif rng.integers(0, 3) == 0: Q = Q * np.exp2(rng.integers(lo, hi + 1, (nq, 1))).astype(F)
     Q = np.ascontiguousarray(Q, dtype=F)
     if not (np.isfinite(X).all() and np.isfinite(Q).all()): continue
     idx = new_index(d, metric); idx.Add(None, X)
