@@ -79,7 +79,10 @@ lb_gpu_index *lb_gpu_index_new(int device, int dim, int metric, int *out_status)
 void lb_gpu_index_free(lb_gpu_index *h);
 
 /* Text of the last failure on this handle ("" if none).  Valid until the next
- * failing call on the same handle. */
+ * failing call on the same handle.  Concurrent host-pointer searches of a few queries are combined into one
+ * device batch (lb_gpu_index_set_combining): this text, last_fallbacks and last_route describe the last device
+ * BATCH on the handle, which may have held other callers' queries.  Return codes are per caller: a combined
+ * batch that fails is searched again request by request before anybody is told. */
 const char *lb_gpu_last_error(const lb_gpu_index *h);
 
 int lb_gpu_index_set_order(lb_gpu_index *h, int order);
@@ -193,13 +196,13 @@ int lb_gpu_index_filter_float32(lb_gpu_index *h, const float *column, int64_t n,
 /* Per-search telemetry of the most recent search on this handle (for benches):
  * number of queries that needed the exact-scan fallback. */
 int64_t lb_gpu_index_last_fallbacks(const lb_gpu_index *h);
-/* Cumulative count of small-batch searches (5..32 queries) whose in-launch threshold hand-off gave up after its
+/* Cumulative count of small-batch searches (1..32 queries) whose in-launch threshold hand-off gave up after its
  * ~1 ms bound (the launch's workgroups were not co-resident, e.g. many such launches from many streams at once) and
  * were redone on the exact path: a latency event worth a metric, never a correctness one. */
 int64_t lb_gpu_index_fused_giveups(const lb_gpu_index *h);
 /* Which kernel generated the candidates of the most recent batched search on this handle: kind * 10 + operand form.
- * kind: 0 exact scan path (<= 4 queries, non-finite data), 1 / 2 narrow tile (32 / 64 queries per pass), 3 256 x 128
- * split-bf16 tile, 4 128 x 128 f32-MFMA tile, 5 256 x 256 split-bf16 tile, 6 256 x 256 fp16 single-product tile;
+ * kind: 0 exact scan path (<= 4 queries, non-finite data), 1 / 2 narrow tile (32 / 64 queries per pass), (3: retired
+ * in round 4), 4 128 x 128 f32-MFMA tile, 5 256 x 256 split-bf16 tile, 6 256 x 256 fp16 single-product tile;
  * form: 0 f32 operands, 1 pre-split corpus image, 2 split in registers, 3 fp16.  Telemetry only. */
 int lb_gpu_index_last_route(const lb_gpu_index *h);
 

@@ -14,7 +14,11 @@ namespace lb {
 // they come, T overlapping calls stream the corpus T times.  Instead: one or two callers search at once (two lanes while nothing
 // is queued, one under load); a caller that finds the lanes taken queues, and when a search ends the first in the queue answers
 // everybody who queued with its k by ONE batched search (at most kBatch queries), then hands the lane on.  A batch's lists are the
-// single searches' lists bit for bit, so nobody can tell except by the clock.  No allocation after the enqueue, nothing thrown.
+// single searches' lists bit for bit, so nobody can tell except by the clock.  No allocation after the enqueue, nothing thrown:
+// an exception out of run() is caught here and becomes kRunThrew (the lane is always handed on).  A combined batch that FAILS
+// is not reported to its callers as one: the leader searches every request of it again alone, so that each caller gets the
+// status of its own query (a device error in one caller's batch does not fail up to 255 others).  The handle's last_error /
+// last_fallbacks / last_route describe the last device BATCH, which under combining may hold other callers' queries.
 struct HostReq {
     const float *q;
     int64_t nq;
@@ -35,6 +39,7 @@ class SearchCombiner {
     // Two searches at a time while nothing is queued: one's host work (staging, copies, wake-up: ~80 us around a 0.3 ms search)
     // runs under the other's device work, and two callers alone are served as without combining.
     static constexpr int kLanes = 2;
+    static constexpr int kRunThrew = 7; // (== LB_ERR_INTERNAL: run() threw)
     std::atomic<int> on{1};
     std::atomic<int64_t> batches{0}, requests{0}; // combined batches run / requests served by them
 
@@ -48,6 +53,9 @@ class SearchCombiner {
             std::unique_lock<std::mutex> lk(mu_);
             // (two lanes while callers come one or two at a time; ONE under load: two batches side by side would halve each
             // other's share of the HBM stream, one batch of everybody does not)
+            // (the size of the last batch is evidence of load only for a moment: after kRecentUs without a search a lone
+            // caller neither loses the second lane nor pays the gather wait)
+            if (recent_ > 1 && std::chrono::steady_clock::now() - last_end_ > std::chrono::microseconds(kRecentUs)) recent_ = 1;
             const int lanes = (recent_ > 1 || !wait_.empty()) ? 1 : kLanes;
             if (!gatherer_ && active_ < lanes) {
                 active_++;
@@ -57,7 +65,7 @@ class SearchCombiner {
                 } catch (...) { // (out of memory: search alone, beside whoever holds the device)
                     lk.unlock();
                     HostReq *one = &me;
-                    return run(&one, 1, me.k);
+                    return guarded(run, &one, 1, me.k);
                 }
                 if (gatherer_) gatherer_->cv.notify_one(); // (the gathering caller counts the queue)
                 me.cv.wait(lk, [&] { return me.done || me.lead; });
@@ -84,16 +92,26 @@ class SearchCombiner {
             nb = take_same_k(me, batch);
         }
         batch[nb++] = &me;
-        const int rc = run(batch, nb, me.k);
+        int rc = guarded(run, batch, nb, me.k);
         if (nb > 1) {
             batches.fetch_add(1);
             requests.fetch_add((int64_t)nb);
+            if (rc != 0) { // every request again, alone: each caller gets its own query's status
+                retried.fetch_add(1);
+                for (int i = 0; i < nb; i++) {
+                    HostReq *one = batch[i];
+                    one->rc = guarded(run, &one, 1, one->k);
+                }
+                rc = me.rc;
+            } else {
+                for (int i = 0; i < nb; i++) batch[i]->rc = 0;
+            }
         }
         {
             std::lock_guard<std::mutex> g(mu_);
             recent_ = nb;
+            last_end_ = std::chrono::steady_clock::now();
             for (int i = 0; i + 1 < nb; i++) {
-                batch[i]->rc = rc;
                 batch[i]->done = true;
                 batch[i]->cv.notify_one(); // (the waiter re-checks under the lock we hold: it cannot be gone before we let go)
             }
@@ -112,8 +130,19 @@ class SearchCombiner {
         return rc;
     }
 
+    std::atomic<int64_t> retried{0}; // combined batches that failed and were searched again request by request
+
   private:
-    static constexpr int kGatherUs = 50;
+    static constexpr int kGatherUs = 50, kRecentUs = 2000;
+    template <typename Run>
+    static int guarded(Run &run, HostReq *const *reqs, int n, int k)
+    {
+        try {
+            return run(reqs, n, k);
+        } catch (...) {
+            return kRunThrew;
+        }
+    }
     // every queued request with me's k (at most kBatch queries with me's) leaves the queue for me's batch
     int take_same_k(HostReq &me, HostReq **batch)
     {
@@ -134,6 +163,7 @@ class SearchCombiner {
     std::mutex mu_;
     int active_ = 0;              // searches of this kind on the device right now (at most kLanes)
     int recent_ = 1;              // requests in the batch that ended last
+    std::chrono::steady_clock::time_point last_end_{}; // when it ended
     HostReq *gatherer_ = nullptr; // the caller that holds the lane and is gathering the others of the last batch
     std::deque<HostReq *> wait_;
 };
