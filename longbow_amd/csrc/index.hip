@@ -908,9 +908,10 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     // (up to 8 queries the wave-per-row kernel over the f32 rows is 5 us quicker: every load of a row in flight at once)
     static const int light_max = lb_tunable("LB_LIGHT_SAMPLE_MAXQ", 8); // (also over a row list: at 32 queries the wave-per-row
                                                                         // kernel took 105 us against the granule sample's 40)
-    // (centred keys: the sample must come out of the same kernel -- the wave-per-row kernel's keys are the plain ones)
+    // (dot product's lower-bound keys: the sample must come out of the same kernel; centred L2 keys the wave-per-row kernel
+    // computes too, from the f32 rows about the same centre)
     const bool granule_sample = sp.on && use_tall16 && sp.count % 16 == 0 && (rv.rowmap == nullptr || entries_pos) &&
-                                ((have_xh && granule_on && nq > light_max) || own_keys);
+                                ((have_xh && granule_on && nq > light_max) || dot_lb || (centred && nq > light_max));
     const bool light_sample = sp.on && !fused && !granule_sample && nq <= light_max;
     const bool norm_riders = prep_riders && metric == LB_METRIC_COSINE;
     // the last launch: key-space pruning + exact re-rank + proof in one (kernels_finish.hip); beta: how far beyond one error
@@ -957,8 +958,9 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         const uint32_t *smap = w->d_smap;
         if (light_sample) {
             ProfScope p(w, s, prof, 1);
+            // (centred keys: the same key about the image's centre, from the f32 rows)
             launch_sample_scores(metric, order, h->d_X, h->dim, sp.span, sp.count, rv.rowmap, mask, d_q, nullptr, nq,
-                                 w->cs, nullptr, s, h->d_norm2, h->d_rnorm);
+                                 w->cs, nullptr, s, centred ? h->d_norm2c : h->d_norm2, h->d_rnorm, centred ? h->d_center : nullptr);
             launch_sample_tau(w->cs, nullptr, nq, sp.count, sp.m, false, s, d_q, h->dim,
                               norm_riders ? w->d_qna : nullptr, order);
         } else if (granule_sample) {

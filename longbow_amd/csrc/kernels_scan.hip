@@ -454,6 +454,7 @@ struct SampleArgs {
     // keys mode (batched path): entries carry the MFMA pipeline's candidate key instead of the distance
     int keys;
     const float *norm2, *rnorm;
+    const float *center; // keys mode, L2 over the centred image: (q - c).(x - c) and norm2 = |x - c|^2 (or null)
 };
 
 __device__ __forceinline__ float wave_sum(float v)
@@ -486,21 +487,24 @@ __device__ __forceinline__ float exact_sq_norm_lds(const float *sq, int D)
 // the exact ||q||^2 in the reference's order (cosine: the re-rank divides by it, internal/simd/simd.go:138-152), and the
 // reset of the query's candidate state.  (A zero or non-finite query keeps scale 1: the exact scan answers it anyway.)
 // center (or null; L2 over the centred image): the image holds q - center (the exact norm, cosine only, is never asked for then)
-__global__ __launch_bounds__(64) void query_prep_kernel(const float *Q, int nq, int D, _Float16 *Qh, float *qinv, float *qna, int order,
-                                                        CandState cs, const float *center, float *qnrm)
+// reset: 1 = the query's candidate state (count, threshold, status bits), 2 = the status bits only (the caller's launch sets
+// the other two itself, from another workgroup), 0 = nothing.  active: this thread belongs to the ONE wave that does the work
+// (every thread of the workgroup makes the call: there is a barrier inside).
+__device__ __forceinline__ void query_prep_body(const float *Q, int nq, int D, _Float16 *Qh, float *qinv, float *qna, int order, CandState cs,
+                                                const float *center, float *qnrm, int reset, int q, int lane, bool active, float *sq)
 {
-    extern __shared__ __attribute__((aligned(16))) float sq[];
-    const int q = blockIdx.x, lane = threadIdx.x;
     const float *src = Q + (int64_t)q * D;
     const int Dpad = (D + 3) & ~3;
     float s = 0.f;
-    for (int i = lane; i < Dpad; i += 64) {
-        const float v = i < D ? (center ? src[i] - center[i] : src[i]) : 0.f;
-        sq[i] = v;
-        s += v * v;
-    }
+    if (active) {
+        for (int i = lane; i < Dpad; i += 64) {
+            const float v = i < D ? (center ? src[i] - center[i] : src[i]) : 0.f;
+            sq[i] = v;
+            s += v * v;
+        }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    }
     float scale = 1.f, inv = 1.f;
     if (s > 0.f && s < 3.0e38f) {
         const float nrm = sqrtf(s);
@@ -512,17 +516,27 @@ __global__ __launch_bounds__(64) void query_prep_kernel(const float *Q, int nq, 
         inv = ldexpf(1.f, -sh);
     }
     __syncthreads();
+    if (!active) return;
     const int Dp = (D + 31) & ~31; // (dimensions beyond D: zero -- they add nothing to a product)
     for (int i = lane; i < Dp; i += 64) Qh[((int64_t)(i >> 5) * nq + q) * 32 + (i & 31)] = i < D ? (_Float16)(sq[i] * scale) : (_Float16)0.f;
     if (lane == 0) {
         qinv[q] = inv;
         // (s is an f32 sum in some order: relative error below (D + 8) 2^-24)
         if (qnrm) qnrm[q] = (s < 3.0e38f) ? sqrtf(s) * (1.000002f + 1.05f * (float)(D + 8) * 5.9604645e-8f) : s;
-        cs.cnt[q] = 0;
-        cs.tau[q] = kEntryMax;
-        cs.flags[q] = 0;
+        if (reset == 1) {
+            cs.cnt[q] = 0;
+            cs.tau[q] = kEntryMax;
+        }
+        if (reset != 0) cs.flags[q] = 0;
         if (qna) qna[q] = order == ORDER_UNROLL4 ? exact_sq_norm_lds<ORDER_UNROLL4>(sq, D) : exact_sq_norm_lds<ORDER_SEQ>(sq, D);
     }
+}
+
+__global__ __launch_bounds__(64) void query_prep_kernel(const float *Q, int nq, int D, _Float16 *Qh, float *qinv, float *qna, int order,
+                                                        CandState cs, const float *center, float *qnrm)
+{
+    extern __shared__ __attribute__((aligned(16))) float sq[];
+    query_prep_body(Q, nq, D, Qh, qinv, qna, order, cs, center, qnrm, 1, (int)blockIdx.x, (int)threadIdx.x, true, sq);
 }
 
 void launch_query_prep(const float *Q, int nq, int D, void *Qh, float *qinv, float *qna, int order, CandState cs, hipStream_t s,
@@ -535,26 +549,10 @@ void launch_query_prep(const float *Q, int nq, int D, void *Qh, float *qinv, flo
 
 // R = sampled rows per wave: every query chunk fetched from L2 is used for R rows (with 32 query
 // slots and R = 1 the launch is bound by 8192 x 96 KB of L2 reads: 97 us; R = 4: a quarter of that)
+// one wave scores sample rows i0 .. i0 + R against every query slot
 template <int METRIC, int R>
-__global__ __launch_bounds__(256) void sample_scores_kernel(SampleArgs a)
+__device__ __forceinline__ void sample_wave(const SampleArgs &a, uint32_t i0, int lane)
 {
-    extern __shared__ __attribute__((aligned(16))) float sq[];
-    const uint32_t nnorm = a.qna ? (uint32_t)a.nsel : 0u; // the serial norm chains are dispatched first
-    if (blockIdx.x < nnorm) { // exact ||q||^2 in the reference's order, off the critical path
-        const int j = (int)blockIdx.x;
-        const float *q = a.Q + (int64_t)(a.qsel ? a.qsel[j] : j) * a.D;
-        const int Dpad = (a.D + 3) & ~3;
-        for (int i = threadIdx.x; i < Dpad; i += 256) sq[i] = i < a.D ? q[i] : 0.f;
-        __syncthreads();
-        if (threadIdx.x == 0)
-            a.qna[j] = a.order == ORDER_UNROLL4 ? exact_sq_norm_lds<ORDER_UNROLL4>(sq, a.D) : exact_sq_norm_lds<ORDER_SEQ>(sq, a.D);
-        return;
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t blk = blockIdx.x - nnorm;
-    if (blk == 0 && (int)threadIdx.x < a.nsel) a.cs.flags[a.qsel ? a.qsel[threadIdx.x] : threadIdx.x] = 0;
-    const uint32_t i0 = (blk * 4u + (uint32_t)wave) * R; // this wave's first sample index
-    if (i0 >= a.count) return;
     const int D = a.D;
     int64_t row[R];
     bool live[R], hidden[R];
@@ -569,6 +567,9 @@ __global__ __launch_bounds__(256) void sample_scores_kernel(SampleArgs a)
         hidden[r] = a.mask != nullptr && !a.mask[row[r]];
         x[r] = a.X + row[r] * (int64_t)D;
     }
+    float aux[R]; // keys mode: the row's norm term, asked for before the products (one round trip less at the end)
+#pragma unroll
+    for (int r = 0; r < R; r++) aux[r] = !a.keys ? 0.f : (METRIC == METRIC_L2 ? a.norm2[row[r]] : (METRIC == METRIC_COS ? a.rnorm[row[r]] : 0.f));
     const bool plain_dot = METRIC != METRIC_L2 || a.keys; // L2 keys come from the inner product too
     const bool want_norms = METRIC == METRIC_COS && !a.keys;
     for (int g0 = 0; g0 < a.nsel; g0 += SS_MAXQ) { // groups of 8 query slots; the rows stay hot in L1/L2
@@ -583,26 +584,44 @@ __global__ __launch_bounds__(256) void sample_scores_kernel(SampleArgs a)
 #pragma unroll
         for (int r = 0; r < R; r++) xx[r] = 0.f;
         if (a.aligned) {
-            for (int k = lane * 4; k < D; k += 256) {
-                f32x4 xv[R];
+            // the pieces of up to 1024 dimensions are asked for up front: the loop as first written waited for memory once per
+            // 256 dimensions (three round trips at 768, ~2 us each on rows nobody has touched)
+            constexpr int PF = R == 1 ? 4 : 1; // (several rows a wave: their pieces are the loads in flight, as before)
+            for (int k0 = lane * 4; k0 < D; k0 += 256 * PF) {
+                f32x4 xw[PF][R];
 #pragma unroll
-                for (int r = 0; r < R; r++) {
-                    xv[r] = *reinterpret_cast<const f32x4 *>(x[r] + k);
-                    if (want_norms) xx[r] += xv[r].x * xv[r].x + xv[r].y * xv[r].y + xv[r].z * xv[r].z + xv[r].w * xv[r].w;
+                for (int u = 0; u < PF; u++) {
+                    const int k = k0 + 256 * u;
+#pragma unroll
+                    for (int r = 0; r < R; r++)
+                        if (k < D) xw[u][r] = *reinterpret_cast<const f32x4 *>(x[r] + k);
                 }
 #pragma unroll
-                for (int j = 0; j < SS_MAXQ; j++) {
-                    if (j >= gn) break;
-                    const int qj = a.qsel ? a.qsel[g0 + j] : g0 + j;
-                    const f32x4 qv = *reinterpret_cast<const f32x4 *>(a.Q + (int64_t)qj * D + k);
-                    if (want_norms) qq[j] += qv.x * qv.x + qv.y * qv.y + qv.z * qv.z + qv.w * qv.w;
+                for (int u = 0; u < PF; u++) {
+                    const int k = k0 + 256 * u;
+                    if (k >= D) break;
+                    f32x4 xv[R];
 #pragma unroll
                     for (int r = 0; r < R; r++) {
-                        if (!plain_dot) {
-                            const float e0 = qv.x - xv[r].x, e1 = qv.y - xv[r].y, e2 = qv.z - xv[r].z, e3 = qv.w - xv[r].w;
-                            acc[j][r] += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
-                        } else {
-                            acc[j][r] += qv.x * xv[r].x + qv.y * xv[r].y + qv.z * xv[r].z + qv.w * xv[r].w;
+                        xv[r] = xw[u][r];
+                        if (a.center) xv[r] = xv[r] - *reinterpret_cast<const f32x4 *>(a.center + k);
+                        if (want_norms) xx[r] += xv[r].x * xv[r].x + xv[r].y * xv[r].y + xv[r].z * xv[r].z + xv[r].w * xv[r].w;
+                    }
+#pragma unroll
+                    for (int j = 0; j < SS_MAXQ; j++) {
+                        if (j >= gn) break;
+                        const int qj = a.qsel ? a.qsel[g0 + j] : g0 + j;
+                        f32x4 qv = *reinterpret_cast<const f32x4 *>(a.Q + (int64_t)qj * D + k);
+                        if (a.center) qv = qv - *reinterpret_cast<const f32x4 *>(a.center + k);
+                        if (want_norms) qq[j] += qv.x * qv.x + qv.y * qv.y + qv.z * qv.z + qv.w * qv.w;
+#pragma unroll
+                        for (int r = 0; r < R; r++) {
+                            if (!plain_dot) {
+                                const float e0 = qv.x - xv[r].x, e1 = qv.y - xv[r].y, e2 = qv.z - xv[r].z, e3 = qv.w - xv[r].w;
+                                acc[j][r] += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
+                            } else {
+                                acc[j][r] += qv.x * xv[r].x + qv.y * xv[r].y + qv.z * xv[r].z + qv.w * xv[r].w;
+                            }
                         }
                     }
                 }
@@ -613,13 +632,15 @@ __global__ __launch_bounds__(256) void sample_scores_kernel(SampleArgs a)
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     xv[r] = x[r][k];
+                    if (a.center) xv[r] -= a.center[k];
                     if (want_norms) xx[r] += xv[r] * xv[r];
                 }
 #pragma unroll
                 for (int j = 0; j < SS_MAXQ; j++) {
                     if (j >= gn) break;
                     const int qj = a.qsel ? a.qsel[g0 + j] : g0 + j;
-                    const float qv = a.Q[(int64_t)qj * D + k];
+                    float qv = a.Q[(int64_t)qj * D + k];
+                    if (a.center) qv -= a.center[k];
                     if (want_norms) qq[j] += qv * qv;
 #pragma unroll
                     for (int r = 0; r < R; r++) {
@@ -647,8 +668,8 @@ __global__ __launch_bounds__(256) void sample_scores_kernel(SampleArgs a)
                 const float t = wave_sum(acc[j][r]);
                 float v;
                 if (a.keys) { // as gemm_filter_kernel's key_of
-                    if (METRIC == METRIC_L2) v = fmaf(-2.0f, t, a.norm2[row[r]]);
-                    else if (METRIC == METRIC_COS) v = -t * a.rnorm[row[r]];
+                    if (METRIC == METRIC_L2) v = fmaf(-2.0f, t, aux[r]);
+                    else if (METRIC == METRIC_COS) v = -t * aux[r];
                     else v = -t;
                 } else if (METRIC == METRIC_L2) {
                     v = sqrtf(t);
@@ -657,19 +678,45 @@ __global__ __launch_bounds__(256) void sample_scores_kernel(SampleArgs a)
                 } else {
                     v = -t;
                 }
-                if (lane == 0 && live[r])
-                    a.cs.lists[(size_t)qj * a.cs.cap + i0 + r] = hidden[r] ? kEntryMax : pack_entry(v, (uint32_t)row[r]);
+                if (lane == 0 && live[r]) {
+                    const uint64_t ent = hidden[r] ? kEntryMax : pack_entry(v, (uint32_t)row[r]);
+                    a.cs.lists[(size_t)qj * a.cs.cap + i0 + r] = ent;
+                }
             }
         }
     }
 }
 
+template <int METRIC, int R>
+__global__ __launch_bounds__(256) void sample_scores_kernel(SampleArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float sq[];
+    const uint32_t nnorm = a.qna ? (uint32_t)a.nsel : 0u; // the serial norm chains are dispatched first
+    if (blockIdx.x < nnorm) { // exact ||q||^2 in the reference's order, off the critical path
+        const int j = (int)blockIdx.x;
+        const float *q = a.Q + (int64_t)(a.qsel ? a.qsel[j] : j) * a.D;
+        const int Dpad = (a.D + 3) & ~3;
+        for (int i = threadIdx.x; i < Dpad; i += 256) sq[i] = i < a.D ? q[i] : 0.f;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            a.qna[j] = a.order == ORDER_UNROLL4 ? exact_sq_norm_lds<ORDER_UNROLL4>(sq, a.D) : exact_sq_norm_lds<ORDER_SEQ>(sq, a.D);
+        return;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t blk = blockIdx.x - nnorm;
+    if (blk == 0 && (int)threadIdx.x < a.nsel) a.cs.flags[a.qsel ? a.qsel[threadIdx.x] : threadIdx.x] = 0;
+    const uint32_t i0 = (blk * 4u + (uint32_t)wave) * R; // this wave's first sample index
+    if (i0 >= a.count) return;
+    sample_wave<METRIC, R>(a, i0, lane);
+}
+
 void launch_sample_scores(int metric, int order, const float *X, int D, int64_t span, uint32_t count,
                           const uint32_t *rowmap, const uint8_t *mask, const float *Q, const int *qsel, int nsel,
-                          CandState cs, float *qna, hipStream_t s, const float *norm2, const float *rnorm)
+                          CandState cs, float *qna, hipStream_t s, const float *norm2, const float *rnorm, const float *center)
 {
     if (count == 0 || nsel <= 0) return;
     SampleArgs a;
+    a.center = (norm2 != nullptr && metric == METRIC_L2) ? center : nullptr;
     a.keys = norm2 != nullptr ? 1 : 0;
     a.norm2 = norm2;
     a.rnorm = rnorm;
@@ -701,12 +748,72 @@ void launch_sample_scores(int metric, int order, const float *X, int D, int64_t 
 constexpr int ST_THREADS = 1024;
 constexpr int ST_PER = 8;
 
+// the m-th smallest of list[0 .. count) (kEntryMax if there are fewer visible entries), by a workgroup of ST_THREADS threads;
+// the value is returned in wave 0
+__device__ __forceinline__ uint64_t sample_tau_body(const uint64_t *list, uint32_t count, int m, uint32_t (*wl)[20], int tid)
+{
+    // The threshold is a KEY with the row bits saturated: the selection runs on the entries' upper words alone (one DPP
+    // minimum per step instead of a 64-bit compare-and-select; equal keys are popped one a round, the first lane that holds
+    // one) -- the value is the one the 64-bit selection gave.
+    constexpr uint32_t NONE = 0xffffffffu; // (the upper word of kEntryMax: a hidden row, or beyond the sample)
+    const int lane = tid & 63, wave = tid >> 6;
+    uint32_t e[ST_PER];
+#pragma unroll
+    for (int i = 0; i < ST_PER; i++) {
+        const uint32_t idx = (uint32_t)tid + (uint32_t)ST_THREADS * i;
+        const uint64_t ent = idx >= count ? kEntryMax : list[idx];
+        e[i] = (uint32_t)(ent >> 32);
+    }
+    // each thread sorts its 8 keys once (19 compare-exchanges); a round then only looks at the heads
+    static_assert(ST_PER == 8, "the sorting network below is for 8 entries");
+#define LB_CE(i, j)                         \
+    {                                       \
+        const uint32_t x = e[i], y = e[j];  \
+        e[i] = x < y ? x : y;               \
+        e[j] = x < y ? y : x;               \
+    }
+    LB_CE(0, 1) LB_CE(2, 3) LB_CE(4, 5) LB_CE(6, 7) LB_CE(0, 2) LB_CE(1, 3) LB_CE(4, 6) LB_CE(5, 7) LB_CE(1, 2)
+    LB_CE(5, 6) LB_CE(0, 4) LB_CE(3, 7) LB_CE(1, 5) LB_CE(2, 6) LB_CE(1, 4) LB_CE(3, 6) LB_CE(2, 4) LB_CE(3, 5)
+    LB_CE(3, 4)
+#undef LB_CE
+    // Two levels, one barrier.  Level 1: every wave pops its own r smallest keys (wave-wide minimum on DPP lane permutes,
+    // no LDS round trip, no barrier) into wl[wave][0 .. r) -- ascending.  Level 2: one wave merges the 16 sorted runs, m pops.
+    // r = min(m, 4 + m / 4) < m for m > 5: should one wave hold more than r of the m smallest keys, the merge runs out
+    // of that wave's run and returns a LARGER value than the m-th smallest -- a looser threshold, which admits a few more
+    // rows and is as valid as the exact one (tau is only a filter; P ~ 1e-4 per search at m = 19).
+    const int r1 = m < 4 + m / 4 ? m : 4 + m / 4;
+    for (int r = 0; r < r1; r++) {
+        const uint32_t v = wave_min_u32(e[0]);
+        if (lane == 0) wl[wave][r] = v;
+        const uint64_t holders = __builtin_amdgcn_ballot_w64(e[0] == v);
+        if (v != NONE && lane == (int)__builtin_ctzll(holders)) { // exactly one lane pops its head
+#pragma unroll
+            for (int i = 0; i + 1 < ST_PER; i++) e[i] = e[i + 1];
+            e[ST_PER - 1] = NONE;
+        }
+    }
+    __syncthreads();
+    uint32_t kth = NONE;
+    if (wave == 0) {
+        static_assert(ST_THREADS / 64 == 16, "one row of 16 lanes merges the per-wave runs");
+        int ptr = 0; // lanes 0 .. 15: the head of wave `lane`'s run
+        for (int r = 0; r < m; r++) {
+            const uint32_t head = (lane < 16 && ptr < r1) ? wl[lane][ptr] : NONE;
+            kth = (uint32_t)__builtin_amdgcn_readfirstlane((int)row16_min_u32(head)); // (rows 1 .. 3 of the wave hold NONE)
+            if (kth == NONE) break; // fewer than m visible sample rows, or every run used up: no threshold
+            const uint64_t holders = __builtin_amdgcn_ballot_w64(head == kth);
+            if (lane == (int)__builtin_ctzll(holders)) ptr++;
+        }
+    }
+    return kth == NONE ? kEntryMax : (((uint64_t)kth << 32) | 0xffffffffull);
+}
+
 __global__ __launch_bounds__(ST_THREADS) void sample_tau_kernel(CandState cs, const int *qsel, int nsel, uint32_t count, int m,
                                                                 int zero_stripes, const float *Q, int D, float *qna, int order)
 {
     extern __shared__ __attribute__((aligned(16))) float sq[];
-    __shared__ uint64_t wl[ST_THREADS / 64][20]; // (m <= 64: r1 <= 20)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ uint32_t wl[ST_THREADS / 64][20]; // (m <= 64: r1 <= 20)
+    const int tid = threadIdx.x;
     if ((int)blockIdx.x >= nsel) { // optional riders (qna != null): exact ||q||^2 of slot blockIdx.x - nsel
         const int j = (int)blockIdx.x - nsel;
         const float *q = Q + (int64_t)(qsel ? qsel[j] : j) * D;
@@ -717,55 +824,9 @@ __global__ __launch_bounds__(ST_THREADS) void sample_tau_kernel(CandState cs, co
         return;
     }
     const int q = qsel ? qsel[blockIdx.x] : blockIdx.x;
-    const uint64_t *list = cs.lists + (size_t)q * cs.cap;
-    uint64_t e[ST_PER];
-#pragma unroll
-    for (int i = 0; i < ST_PER; i++) {
-        const uint32_t idx = (uint32_t)tid + (uint32_t)ST_THREADS * i;
-        e[i] = idx < count ? list[idx] : kEntryMax;
-    }
-    // each thread sorts its 8 entries once (19 compare-exchanges); a round then only looks at the heads
-    static_assert(ST_PER == 8, "the sorting network below is for 8 entries");
-#define LB_CE(i, j)                         \
-    {                                       \
-        const uint64_t x = e[i], y = e[j];  \
-        e[i] = x < y ? x : y;               \
-        e[j] = x < y ? y : x;               \
-    }
-    LB_CE(0, 1) LB_CE(2, 3) LB_CE(4, 5) LB_CE(6, 7) LB_CE(0, 2) LB_CE(1, 3) LB_CE(4, 6) LB_CE(5, 7) LB_CE(1, 2)
-    LB_CE(5, 6) LB_CE(0, 4) LB_CE(3, 7) LB_CE(1, 5) LB_CE(2, 6) LB_CE(1, 4) LB_CE(3, 6) LB_CE(2, 4) LB_CE(3, 5)
-    LB_CE(3, 4)
-#undef LB_CE
-    // Two levels, one barrier.  Level 1: every wave pops its own r smallest entries (wave-wide minimum on DPP lane permutes,
-    // no LDS round trip, no barrier) into wl[wave][0 .. r) -- ascending.  Level 2: one wave merges the 16 sorted runs, m pops.
-    // r = min(m, 4 + m / 4) < m for m > 5: should one wave hold more than r of the m smallest entries, the merge runs out
-    // of that wave's run and returns a LARGER value than the m-th smallest -- a looser threshold, which admits a few more
-    // rows and is as valid as the exact one (tau is only a filter; P ~ 1e-4 per search at m = 19).
-    const int r1 = m < 4 + m / 4 ? m : 4 + m / 4;
-    for (int r = 0; r < r1; r++) {
-        const uint64_t v = wave_min_u64(e[0]);
-        if (lane == 0) wl[wave][r] = v;
-        if (e[0] == v && v != kEntryMax) { // entries are unique: exactly one lane pops its head
-#pragma unroll
-            for (int i = 0; i + 1 < ST_PER; i++) e[i] = e[i + 1];
-            e[ST_PER - 1] = kEntryMax;
-        }
-    }
-    __syncthreads();
-    uint64_t kth = kEntryMax;
-    if (wave == 0) {
-        static_assert(ST_THREADS / 64 == 16, "one row of 16 lanes merges the per-wave runs");
-        int ptr = 0; // lanes 0 .. 15: the head of wave `lane`'s run
-        for (int r = 0; r < m; r++) {
-            const uint64_t head = (lane < 16 && ptr < r1) ? wl[lane][ptr] : kEntryMax;
-            const uint64_t v = row16_min_u64(head); // (rows 1 .. 3 of the wave hold kEntryMax)
-            kth = __shfl(v, 0);
-            if (kth == kEntryMax) break; // fewer than m visible sample rows, or every run used up: no threshold
-            if (lane < 16 && head == kth) ptr++;
-        }
-    }
+    const uint64_t kth = sample_tau_body(cs.lists + (size_t)q * cs.cap, count, m, wl, tid);
     if (tid == 0) {
-        cs.tau[q] = kth == kEntryMax ? kEntryMax : (kth | 0xffffffffull);
+        cs.tau[q] = kth;
         cs.cnt[q] = 0;
     }
     if (zero_stripes && tid < LB_STRIPES) cs.stripes[(blockIdx.x * LB_STRIPES + tid) * LB_STRIPE_PAD] = 0;

@@ -137,6 +137,29 @@ __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
     return ((uint64_t)hi << 32) | lo;
 }
 
+// the same on 32-bit keys (one v_min_u32 with a DPP operand per step)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t min_dpp_u32(uint32_t v)
+{
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
+    return o < v ? o : v;
+}
+__device__ __forceinline__ uint32_t row16_min_u32(uint32_t v)
+{
+    v = min_dpp_u32<0xB1, 0xf>(v);
+    v = min_dpp_u32<0x4E, 0xf>(v);
+    v = min_dpp_u32<0x141, 0xf>(v);
+    v = min_dpp_u32<0x140, 0xf>(v);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+    v = row16_min_u32(v);
+    v = min_dpp_u32<0x142, 0xa>(v);
+    v = min_dpp_u32<0x143, 0xc>(v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 #endif
 
 // ---------------------------------------------------------------------------
@@ -245,7 +268,8 @@ void launch_select(CandState cs, const int *qsel, int nsel, int kc, uint32_t boo
 void launch_sample_scores(int metric, int order, const float *X, int D, int64_t span, uint32_t count,
                           const uint32_t *rowmap, const uint8_t *mask, const float *Q, const int *qsel, int nsel,
                           CandState cs, float *qna, hipStream_t s, const float *norm2 = nullptr,
-                          const float *rnorm = nullptr);
+                          const float *rnorm = nullptr,
+                          const float *center = nullptr); // keys mode, L2: keys about this centre (norm2 = the centred norms)
 // tau[q] = m-th smallest of lists[q][0..count) with the row bits saturated, cnt[q] = 0
 bool sample_tau_supported(uint32_t count, int m);
 // zero_stripes: also reset the slots' striped admission counters (at most 8 slots: the scan path)

@@ -31,4 +31,4 @@ for B in [int(x) for x in os.environ.get('SWEEP', '1,2,4,8,9,16,24,32,48,64,96,9
     tm = idx.last_timing()
     idx.set_profiling(False)
     cls = " ".join(f"{c}={tm[c][0]*1e3:.0f}us/{tm[c][1]}" for c in ("gemm", "scan", "select", "rerank", "total"))
-    print(f"B={B:5d}  {t*1e3:8.3f} ms/batch  {B/t:10.0f} q/s  corpus-read-equivalent {4.0*rows*D/t/1e12:5.2f} TB/s  fallbacks {idx.last_fallbacks}  [{cls}]", flush=True)
+    print(f"B={B:5d}  {t*1e3:8.3f} ms/batch  {B/t:10.0f} q/s  corpus-read-equivalent {4.0*rows*D/t/1e12:5.2f} TB/s  fallbacks {idx.last_fallbacks} giveups {idx.fused_giveups}  [{cls}]", flush=True)
