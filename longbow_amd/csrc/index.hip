@@ -885,11 +885,6 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         }
         d_qinv = reinterpret_cast<float *>(static_cast<char *>(w->d_qh) + img);
         d_qnrm = d_qinv + nq;
-        // one launch: the image, the scales, the exact query norms (cosine) and the reset of the candidate state
-        // (the exact norm is a serial chain of D additions, 3.5 us at 768: up to 384 queries it rides in the threshold launch
-        // instead, where nothing waits for it)
-        launch_query_prep(d_q, nq, h->dim, w->d_qh, d_qinv, (metric == LB_METRIC_COSINE && !prep_riders) ? w->d_qna : nullptr, order,
-                          w->cs, s, centred ? h->d_center : nullptr, dot_lb ? d_qnrm : nullptr);
     }
     if (!use_narrow && route.split == 1) {
         gx = h->d_Xs;
@@ -913,6 +908,14 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     const bool granule_sample = sp.on && use_tall16 && sp.count % 16 == 0 && (rv.rowmap == nullptr || entries_pos) &&
                                 ((have_xh && granule_on && nq > light_max) || dot_lb || (centred && nq > light_max));
     const bool light_sample = sp.on && !fused && !granule_sample && nq <= light_max;
+    // (up to 8 queries: the query preparation rides in the sample launch -- one launch and one gap less in front of the pass)
+    const bool prep_rides = use_tall16 && light_sample && prep_riders;
+    if (use_tall16 && !prep_rides)
+        // one launch: the image, the scales, the exact query norms (cosine) and the reset of the candidate state
+        // (the exact norm is a serial chain of D additions, 3.5 us at 768: up to 384 queries it rides in the threshold launch
+        // instead, where nothing waits for it)
+        launch_query_prep(d_q, nq, h->dim, w->d_qh, d_qinv, (metric == LB_METRIC_COSINE && !prep_riders) ? w->d_qna : nullptr, order,
+                          w->cs, s, centred ? h->d_center : nullptr, dot_lb ? d_qnrm : nullptr);
     const bool norm_riders = prep_riders && metric == LB_METRIC_COSINE;
     // the last launch: key-space pruning + exact re-rank + proof in one (kernels_finish.hip); beta: how far beyond one error
     // bound the cut lies (the proof itself never depends on it)
@@ -959,8 +962,10 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         if (light_sample) {
             ProfScope p(w, s, prof, 1);
             // (centred keys: the same key about the image's centre, from the f32 rows)
+            const SamplePrep sprep{w->d_qh, d_qinv, dot_lb ? d_qnrm : nullptr, centred ? h->d_center : nullptr};
             launch_sample_scores(metric, order, h->d_X, h->dim, sp.span, sp.count, rv.rowmap, mask, d_q, nullptr, nq,
-                                 w->cs, nullptr, s, centred ? h->d_norm2c : h->d_norm2, h->d_rnorm, centred ? h->d_center : nullptr);
+                                 w->cs, nullptr, s, centred ? h->d_norm2c : h->d_norm2, h->d_rnorm, centred ? h->d_center : nullptr,
+                                 prep_rides ? &sprep : nullptr);
             launch_sample_tau(w->cs, nullptr, nq, sp.count, sp.m, false, s, d_q, h->dim,
                               norm_riders ? w->d_qna : nullptr, order);
         } else if (granule_sample) {

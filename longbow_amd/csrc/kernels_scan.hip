@@ -455,6 +455,11 @@ struct SampleArgs {
     int keys;
     const float *norm2, *rnorm;
     const float *center; // keys mode, L2 over the centred image: (q - c).(x - c) and norm2 = |x - c|^2 (or null)
+    // riding along (fp16 route, Qh != null): `nsel` more workgroups prepare a query each (query_prep_body) -- nothing in this
+    // launch reads what they write, the candidate pass two launches on does
+    _Float16 *Qh = nullptr;
+    float *qinv = nullptr, *qnrm = nullptr;
+    const float *pcenter = nullptr;
 };
 
 __device__ __forceinline__ float wave_sum(float v)
@@ -703,7 +708,13 @@ __global__ __launch_bounds__(256) void sample_scores_kernel(SampleArgs a)
         return;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t blk = blockIdx.x - nnorm;
+    const uint32_t nprep = a.Qh ? (uint32_t)a.nsel : 0u;
+    if (blockIdx.x < nnorm + nprep) { // (no query subset on this route: slot j is query j)
+        query_prep_body(a.Q, a.nsel, a.D, a.Qh, a.qinv, nullptr, a.order, a.cs, a.pcenter, a.qnrm, /*reset=*/0, (int)(blockIdx.x - nnorm), lane,
+                        wave == 0, sq);
+        return;
+    }
+    const uint32_t blk = blockIdx.x - nnorm - nprep;
     if (blk == 0 && (int)threadIdx.x < a.nsel) a.cs.flags[a.qsel ? a.qsel[threadIdx.x] : threadIdx.x] = 0;
     const uint32_t i0 = (blk * 4u + (uint32_t)wave) * R; // this wave's first sample index
     if (i0 >= a.count) return;
@@ -712,10 +723,17 @@ __global__ __launch_bounds__(256) void sample_scores_kernel(SampleArgs a)
 
 void launch_sample_scores(int metric, int order, const float *X, int D, int64_t span, uint32_t count,
                           const uint32_t *rowmap, const uint8_t *mask, const float *Q, const int *qsel, int nsel,
-                          CandState cs, float *qna, hipStream_t s, const float *norm2, const float *rnorm, const float *center)
+                          CandState cs, float *qna, hipStream_t s, const float *norm2, const float *rnorm, const float *center,
+                          const SamplePrep *prep)
 {
     if (count == 0 || nsel <= 0) return;
     SampleArgs a;
+    if (prep && qsel == nullptr && nsel <= SS_MAX_SLOTS) {
+        a.Qh = reinterpret_cast<_Float16 *>(prep->Qh);
+        a.qinv = prep->qinv;
+        a.qnrm = prep->qnrm;
+        a.pcenter = prep->center;
+    }
     a.center = (norm2 != nullptr && metric == METRIC_L2) ? center : nullptr;
     a.keys = norm2 != nullptr ? 1 : 0;
     a.norm2 = norm2;
@@ -728,8 +746,8 @@ void launch_sample_scores(int metric, int order, const float *X, int D, int64_t 
     static const int env_r = lb_tunable("LB_SAMPLE_ROWS_PER_WAVE", 0);
     const int R = (env_r == 1 || env_r == 2 || env_r == 4) ? env_r : (a.nsel > SS_MAXQ ? 4 : a.nsel > 4 ? 2 : 1); // measured at 8 slots: 61 -> 53 us for sample + threshold + select
     a.nblocks = (count + 4 * R - 1) / (4 * R);
-    dim3 grid(a.nblocks + (a.qna ? (unsigned)a.nsel : 0u)), block(256);
-    const size_t shmem = a.qna ? (size_t)((D + 3) & ~3) * sizeof(float) : 0;
+    dim3 grid(a.nblocks + (a.qna ? (unsigned)a.nsel : 0u) + (a.Qh ? (unsigned)a.nsel : 0u)), block(256);
+    const size_t shmem = (a.qna || a.Qh) ? (size_t)((D + 3) & ~3) * sizeof(float) : 0;
 #define LB_SS(M)                                                                                      \
     do {                                                                                              \
         if (R == 4) hipLaunchKernelGGL((sample_scores_kernel<M, 4>), grid, block, shmem, s, a);       \

@@ -265,11 +265,20 @@ void launch_select(CandState cs, const int *qsel, int nsel, int kc, uint32_t boo
 // as entries to lists[q][0..count) (also clears the slots' flags); cosine: `nsel` extra workgroups compute
 // the slots' exact ||q||^2 into qna in the requested order.  norm2/rnorm given ("keys" mode, up to 64 slots):
 // the entries carry the MFMA pipeline's candidate keys instead of distances
+// prep (or null): the launch also does launch_query_prep's work for its queries (image, scales, |q| bounds; not the exact
+// norms, not the state reset -- the threshold launch behind it sets the state): one launch and one gap less in front of a
+// small search's candidate pass
+struct SamplePrep {
+    void *Qh;
+    float *qinv, *qnrm;
+    const float *center;
+};
 void launch_sample_scores(int metric, int order, const float *X, int D, int64_t span, uint32_t count,
                           const uint32_t *rowmap, const uint8_t *mask, const float *Q, const int *qsel, int nsel,
                           CandState cs, float *qna, hipStream_t s, const float *norm2 = nullptr,
                           const float *rnorm = nullptr,
-                          const float *center = nullptr); // keys mode, L2: keys about this centre (norm2 = the centred norms)
+                          const float *center = nullptr,  // keys mode, L2: keys about this centre (norm2 = the centred norms)
+                          const SamplePrep *prep = nullptr);
 // tau[q] = m-th smallest of lists[q][0..count) with the row bits saturated, cnt[q] = 0
 bool sample_tau_supported(uint32_t count, int m);
 // zero_stripes: also reset the slots' striped admission counters (at most 8 slots: the scan path)

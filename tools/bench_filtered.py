@@ -26,7 +26,7 @@ for sel in [int(x) for x in os.environ.get("SELS", "100,50,10,1").split(",")]:
     else:
         idx.filter_column(meta, "<", sel)
     tf = time.perf_counter() - t0
-    for B in (1, 32, 256, 1024):
+    for B in [int(x) for x in os.environ.get("BS", "1,32,256,1024").split(",")]:
         od = torch.empty((B, K), device="cuda"); ol = torch.empty((B, K), dtype=torch.int64, device="cuda")
         q = Q[:B].contiguous()
         ts = []
