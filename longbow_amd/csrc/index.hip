@@ -632,13 +632,15 @@ void scan_with_retry(lb_gpu_index *h, Workspace *w, hipStream_t s, const float *
 // Every route is exact (re-rank + containment proof, else the exact scan redoes the query), so this is a cost choice.
 //   NARROW32 / NARROW64  256 x 32 or 128 x 64 tile, operands split to bf16 in registers: one HBM-bound corpus pass per
 //                        32 / 64 queries (kernels_gemm_narrow.hip)
-//   TALL                 256-row tiles on the split contraction (kernels_gemm_tall.hip): corpus image (split 1) or f32
+//   TALL2                256 x 256 tile on the split contraction (kernels_gemm_tall2.hip): corpus image (split 1) or f32
 //                        corpus split in registers (split 2)
+//   TALL16 / NARROW16    ONE fp16 product per element (kernels_gemm_tall16.hip): 256 x 256 tiles, or one 64- / 128-query
+//                        tile over the index's fp16 image (persistent workgroups, LDS-DMA ring)
 //   WIDE                 128 x 128 tile (kernels_gemm.hip): f32 MFMA (split 0: the strict mode's route beyond 384
-//                        queries), or the split contraction where the tall tile cannot run
+//                        queries), or the split contraction where the tall tiles cannot run
 // Candidate modes (lb_gpu_index_set_candidate_mode):
-//   LB_CAND_AUTO (default)    the cheapest route by the cost model below -- beyond the narrow tiles that is the tall tile
-//                             with the corpus split in registers (no second copy of the corpus), at every batch size
+//   LB_CAND_AUTO (default)    the cheapest route by the cost model below -- with the fp16 image that is the single-product
+//                             route at every batch size, the split contraction where the data's range rules fp16 keys out
 //   LB_CAND_F32_MFMA          as AUTO up to 384 queries, the f32-MFMA 128 x 128 tile beyond (rounds 1-2 default)
 //   LB_CAND_SPLIT_BF16        corpus image for everything beyond the narrow tiles
 //   LB_CAND_SPLIT_BF16_INREG  in-register split for everything beyond the narrow tiles

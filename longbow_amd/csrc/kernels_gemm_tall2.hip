@@ -1,13 +1,13 @@
 // kernels_gemm_tall2.hip -- candidate generation on the split-bf16 contraction, 256 rows x 256 queries per workgroup,
 // whole 128-B lines per row and K-step.
 //
-// Same contract as gemm_filter_tall_kernel (kernels_gemm_tall.hip): S = X_tile . Q_tile^T as hi*hi + hi*lo + lo*hi on
+// Contract: S = X_tile . Q_tile^T as hi*hi + hi*lo + lo*hi on
 // v_mfma_f32_32x32x16_bf16, metric key and admission test fused into the epilogue; ranking semantics of
 // BruteForceIndex.SearchVectors (internal/store/adaptive_index.go:161-225), per-pair arithmetic of the *Batch functions
 // (internal/simd/batch_operations.go:64-157) approximated for the CANDIDATE keys only (the reported distances come from the
 // exact re-rank).
 //
-// Why a second tall tile.  The 256 x 128 tile stages 64 B per row and K-step of 16: HALF a cache line.  The other half of the
+// Why this shape.  The 256 x 128 tile of rounds 2-3 (removed in round 4) staged 64 B per row and K-step of 16: HALF a cache line.  The other half of the
 // line is wanted one K-step later, by which time the CU's 32 KB vector L1 has turned over, so every line crosses the
 // L2 -> L1 -> LDS path twice (and, measured with rocprofv3, reaches the fabric 1.99 times per algorithmic byte).  At
 // 1024 queries the kernel asked its L2 for 8.8 TB/s of 64-B pieces -- half of what the same path delivers in whole lines
