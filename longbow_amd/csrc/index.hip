@@ -910,6 +910,26 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     const bool granule_sample = sp.on && use_tall16 && sp.count % 16 == 0 && (rv.rowmap == nullptr || entries_pos) &&
                                 ((have_xh && granule_on && nq > light_max) || dot_lb || (centred && nq > light_max));
     const bool light_sample = sp.on && !fused && !granule_sample && nq <= light_max;
+    // Up to 128 queries on the one-tile kernel over the image, one span: the candidate launch turns the sample into the
+    // thresholds ITSELF (its last nq workgroups, on shorter row ranges; kernels_gemm_tall16.hip, TAUIN) -- no threshold launch
+    // and no gap behind it in front of the pass.
+    static const bool tauin_on = lb_tunable("LB_TAUIN", 1) != 0;
+    const bool tauin = tauin_on && sp.on && sp.span >= n && use_tall16 && route.kind == ROUTE_NARROW16 && !fused &&
+                       (light_sample || granule_sample) && prep_riders &&
+                       tall16_tin_ok(h->dim, nq, sp.span, have_xh, rv.rowmap != nullptr, mask != nullptr, (prep_riders && metric == LB_METRIC_COSINE), sp.count, sp.m);
+    Tall16Tin tin{};
+    uint32_t tin_epoch = 0;
+    if (tauin) {
+        if (++w->fs_epoch == 0) w->fs_epoch = 1; // (0 = "never published")
+        tin_epoch = w->fs_epoch;
+        tin.count = sp.count;
+        tin.m = sp.m;
+        tin.tag = tin_epoch;
+        tin.fail_host = w->h_fail;
+        tin.Q = d_q;
+        tin.qna = (prep_riders && metric == LB_METRIC_COSINE) ? w->d_qna : nullptr;
+        tin.order = order;
+    }
     // (up to 8 queries: the query preparation rides in the sample launch -- one launch and one gap less in front of the pass)
     const bool prep_rides = use_tall16 && light_sample && prep_riders;
     if (use_tall16 && !prep_rides)
@@ -917,7 +937,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         // (the exact norm is a serial chain of D additions, 3.5 us at 768: up to 384 queries it rides in the threshold launch
         // instead, where nothing waits for it)
         launch_query_prep(d_q, nq, h->dim, w->d_qh, d_qinv, (metric == LB_METRIC_COSINE && !prep_riders) ? w->d_qna : nullptr, order,
-                          w->cs, s, centred ? h->d_center : nullptr, dot_lb ? d_qnrm : nullptr);
+                          w->cs, s, centred ? h->d_center : nullptr, dot_lb ? d_qnrm : nullptr, tauin);
     const bool norm_riders = prep_riders && metric == LB_METRIC_COSINE;
     // the last launch: key-space pruning + exact re-rank + proof in one (kernels_finish.hip); beta: how far beyond one error
     // bound the cut lies (the proof itself never depends on it)
@@ -948,7 +968,8 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
                                       true, s, /*tile64=*/true, /*split=*/true);
         else if (use_tall16)
             launch_gemm_filter_tall16(metric, h->d_X, centred ? h->d_norm2c : h->d_norm2, h->d_rnorm, b, e, h->dim, w->d_qh, d_qinv, nq,
-                                      mask, rowmap, w->cs, boot, s, have_xh ? h->d_Xh : nullptr, h->xh_cap, 0u, d_qnrm, gsum);
+                                      mask, rowmap, w->cs, boot, s, have_xh ? h->d_Xh : nullptr, h->xh_cap, 0u, d_qnrm, gsum,
+                                      (tauin && !boot && b == 0 && e == sp.span) ? &tin : nullptr);
         else if (use_tall2)
             launch_gemm_filter_tall2(metric, gx, h->d_norm2, h->d_rnorm, b, e, h->dim, w->d_qs, nq, mask, rowmap, w->cs,
                                      boot, wsplit, s);
@@ -958,18 +979,19 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     };
     int64_t pos = 0;
     int step = 0;
-    uint32_t fused_epoch = 0;
+    uint32_t fused_epoch = tin_epoch; // (a wait inside a launch that gave up is reported through one pinned word, whichever launch it was)
     if (sp.on) { // sampled threshold, then one pass over the span (see sample_plan)
         const uint32_t *smap = w->d_smap;
         if (light_sample) {
             ProfScope p(w, s, prof, 1);
             // (centred keys: the same key about the image's centre, from the f32 rows)
-            const SamplePrep sprep{w->d_qh, d_qinv, dot_lb ? d_qnrm : nullptr, centred ? h->d_center : nullptr};
+            const SamplePrep sprep{w->d_qh, d_qinv, dot_lb ? d_qnrm : nullptr, centred ? h->d_center : nullptr, tauin};
             launch_sample_scores(metric, order, h->d_X, h->dim, sp.span, sp.count, rv.rowmap, mask, d_q, nullptr, nq,
                                  w->cs, nullptr, s, centred ? h->d_norm2c : h->d_norm2, h->d_rnorm, centred ? h->d_center : nullptr,
                                  prep_rides ? &sprep : nullptr);
-            launch_sample_tau(w->cs, nullptr, nq, sp.count, sp.m, false, s, d_q, h->dim,
-                              norm_riders ? w->d_qna : nullptr, order);
+            if (!tauin)
+                launch_sample_tau(w->cs, nullptr, nq, sp.count, sp.m, false, s, d_q, h->dim,
+                                  norm_riders ? w->d_qna : nullptr, order);
         } else if (granule_sample) {
             {
                 ctx_check(w->ctx);
@@ -979,7 +1001,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
                                           (uint32_t)(sp.span / (int64_t)(sp.count / 16)), d_qnrm, gsum);
             }
             ProfScope p(w, s, prof, 1);
-            launch_sample_tau(w->cs, nullptr, nq, sp.count, sp.m, false, s, d_q, h->dim, norm_riders ? w->d_qna : nullptr, order);
+            if (!tauin) launch_sample_tau(w->cs, nullptr, nq, sp.count, sp.m, false, s, d_q, h->dim, norm_riders ? w->d_qna : nullptr, order);
         } else {
             {
                 std::lock_guard<std::mutex> g(h->smap_mu);

@@ -99,6 +99,14 @@ struct Tall16Args {
     uint32_t gstride;   // persistent forms, sample pass: 0 = position p is row row_begin + p; else the positions are granules of 16
                         // consecutive rows, granule j starting at row row_begin + j * gstride (an evenly spaced sample whose
                         // requests are still whole KiB of the K-blocked image)
+    // one-tile form, TAUIN instantiation: the thresholds are computed INSIDE the launch from the sample the launch before left
+    // in lists[q][0 .. tin_count) (see the kernel); tau[q] = 0 means "not out yet".  A wait that gives up stores tin_tag to
+    // the pinned tin_fail.
+    uint32_t tin_count, tin_tag, tin_dr;
+    int tin_m, tin_order;
+    uint32_t *tin_fail;
+    const float *tin_Q; // f32 queries [nq][D] and (cosine, or null) where their exact squared norms go
+    float *tin_qna;
 };
 
 // Persistent forms: the launch's positions [0, n_pos) are dealt to the workgroups (narrow form) / workgroup groups (256-query
@@ -909,7 +917,145 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
 // requested at rowmap[position]; candidate entries carry POSITIONS (the finish launch maps them to rows: posmap).  Needs at
 // least DIST + 3 K-steps per tile (the launcher checks), so that a tile's ids are older than everything the counted waits
 // leave in flight by the time they are read.
-template <int METRIC, int BN, bool BOOT, bool MAPPED>
+// positions a duty is worth: ~5 us of selection (+ D dependent additions of ~4.5 ns for the exact norm) against 0.077 ns per
+// dimension and row of the stream (6.7 TB/s over 256 workgroups, 2 bytes per element)
+static uint32_t tin_duty_rows(int D, bool with_norm)
+{
+    static const int pct = lb_tunable("LB_TIN_DR_PCT", 100);
+    const double ns = (5000.0 + (with_norm ? 4.5 * D : 0.0)) * 0.01 * pct;
+    return ((uint32_t)(ns / (0.077 * D)) + 15u) & ~15u;
+}
+
+// can a one-tile launch over n_pos positions on ng workgroups compute its nq thresholds itself?  (every duty workgroup keeps
+// at least a tile of rows; the sample fits the 512 x 16 keys of tin_duty)
+static bool tin_plan(int D, int nq, int64_t n_pos, int ng, bool with_norm, uint32_t count, int m, uint32_t &dr)
+{
+    if (nq < 1 || nq > ng / 2 || nq > 128 || n_pos >= ((int64_t)1 << 30) || count == 0 || count > (uint32_t)H_THREADS * 16u || m < 1 || m > 64) return false;
+    dr = tin_duty_rows(D, with_norm);
+    return (n_pos + (int64_t)nq * dr) / ng >= (int64_t)dr + 256;
+}
+
+// TAUIN: the last nd workgroups of the launch have a duty in front of their rows (a threshold each: ~5 us + an exact norm);
+// their ranges are dr positions shorter than the others', so that everybody ends together.  The ranges are h_range's over
+// V = n_pos + nd dr "virtual" positions, dr of which at the head of every duty workgroup's range are its duty.
+__device__ __forceinline__ void h_range_duty(uint32_t n_pos, int gi, int ng, int nd, uint32_t dr, uint32_t &lo, uint32_t &hi)
+{
+    const uint32_t V = n_pos + (uint32_t)nd * dr, q = V / (uint32_t)ng, r = V % (uint32_t)ng;
+    auto bound = [&](int i) { // first real position of workgroup i
+        const uint32_t v = q * (uint32_t)i + (r * (uint32_t)i) / (uint32_t)ng;
+        const int jd = i - (ng - nd); // duty workgroups in front of it
+        return (v - (jd > 0 ? (uint32_t)jd * dr : 0u)) & ~15u;
+    };
+    lo = bound(gi);
+    hi = gi + 1 < ng ? bound(gi + 1) : n_pos;
+    lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
+    hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)hi);
+}
+
+// The duty of workgroup ng - 1 - j of a TAUIN launch: tau[j] = the m-th smallest key of the sample entries
+// lists[j][0 .. count) with the row bits saturated (kernels_scan.hip: sample_tau_body, here on 512 threads with 16 keys
+// each), cnt[j] = 0, the exact ||q_j||^2 (cosine).  `scratch`: LDS nobody uses
+// before the first epilogue (>= 1 KB + a query row).
+__device__ __forceinline__ void tin_duty(const Tall16Args &a, int j, unsigned char *scratch)
+{
+    constexpr uint32_t NONE = 0xffffffffu;
+    constexpr int PER = 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t(*wl)[20] = reinterpret_cast<uint32_t(*)[20]>(scratch); // [8][20]
+    float *sq = reinterpret_cast<float *>(scratch + 1024);
+    const uint64_t *list = a.cs.lists + (size_t)j * a.cs.cap;
+    uint32_t e[PER];
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const uint32_t idx = (uint32_t)tid + (uint32_t)H_THREADS * i;
+        e[i] = idx < a.tin_count ? (uint32_t)(list[idx] >> 32) : NONE;
+    }
+    if (a.tin_qna) { // (the query row, for the norm below: in flight beside the entries)
+        const float *q = a.tin_Q + (int64_t)j * a.D;
+        for (int i = tid; i < a.D; i += H_THREADS) sq[i] = q[i];
+    }
+    // two sorted runs of 8 per thread (19 compare-exchanges each); a pop takes the smaller head
+#define LB_CE(i, j)                         \
+    {                                       \
+        const uint32_t x = e[i], y = e[j];  \
+        e[i] = x < y ? x : y;               \
+        e[j] = x < y ? y : x;               \
+    }
+#define LB_SORT8(o)                                                                                                              \
+    LB_CE(o + 0, o + 1) LB_CE(o + 2, o + 3) LB_CE(o + 4, o + 5) LB_CE(o + 6, o + 7) LB_CE(o + 0, o + 2) LB_CE(o + 1, o + 3)         \
+    LB_CE(o + 4, o + 6) LB_CE(o + 5, o + 7) LB_CE(o + 1, o + 2) LB_CE(o + 5, o + 6) LB_CE(o + 0, o + 4) LB_CE(o + 3, o + 7)         \
+    LB_CE(o + 1, o + 5) LB_CE(o + 2, o + 6) LB_CE(o + 1, o + 4) LB_CE(o + 3, o + 6) LB_CE(o + 2, o + 4) LB_CE(o + 3, o + 5)         \
+    LB_CE(o + 3, o + 4)
+    LB_SORT8(0)
+    LB_SORT8(8)
+#undef LB_SORT8
+#undef LB_CE
+    const int m = a.tin_m;
+    const int r1 = m < 4 + m / 4 ? m : 4 + m / 4; // (as sample_tau_body: a wave that held more of the m smallest gives a LOOSER threshold)
+    for (int r = 0; r < r1; r++) {
+        const uint32_t hd = e[0] < e[8] ? e[0] : e[8];
+        const uint32_t v = wave_min_u32(hd);
+        if (lane == 0) wl[wave][r] = v;
+        const uint64_t holders = __builtin_amdgcn_ballot_w64(hd == v);
+        if (v != NONE && lane == (int)__builtin_ctzll(holders)) { // exactly one lane pops a head
+            if (e[0] <= e[8]) {
+#pragma unroll
+                for (int i = 0; i < 7; i++) e[i] = e[i + 1];
+                e[7] = NONE;
+            } else {
+#pragma unroll
+                for (int i = 8; i < 15; i++) e[i] = e[i + 1];
+                e[15] = NONE;
+            }
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t kth = NONE;
+        int ptr = 0; // lanes 0 .. 7: the head of wave `lane`'s run
+        for (int r = 0; r < m; r++) {
+            const uint32_t head = (lane < H_THREADS / 64 && ptr < r1) ? wl[lane][ptr] : NONE;
+            kth = (uint32_t)__builtin_amdgcn_readfirstlane((int)row16_min_u32(head));
+            if (kth == NONE) break;
+            const uint64_t holders = __builtin_amdgcn_ballot_w64(head == kth);
+            if (lane == (int)__builtin_ctzll(holders)) ptr++;
+        }
+        if (lane == 0) {
+            const uint64_t tv = kth == NONE ? kEntryMax : (((uint64_t)kth << 32) | 0xffffffffull);
+            // the count first, then the threshold with release semantics: whoever sees the threshold appends behind a zeroed count
+            __hip_atomic_store(&a.cs.cnt[j], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (the asm wait stays beside the fence: ROCm 7.2 can drop the fence's own vmcnt wait, MI355X_MICROARCH.md)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&a.cs.tau[j], tv, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.tin_qna) { // D dependent additions in the reference's order (nothing waits for them but this workgroup's rows)
+#pragma clang fp contract(off)
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                const int D = a.D, dmain = D & ~3;
+                if (a.tin_order == 1) { // ORDER_UNROLL4
+                    for (int i = 0; i < dmain; i += 4) {
+                        const float v0 = sq[i], v1 = sq[i + 1], v2 = sq[i + 2], v3 = sq[i + 3];
+                        s0 = s0 + v0 * v0;
+                        s1 = s1 + v1 * v1;
+                        s2 = s2 + v2 * v2;
+                        s3 = s3 + v3 * v3;
+                    }
+                    for (int i = dmain; i < D; i++) s0 = s0 + sq[i] * sq[i];
+                    float t = s0 + s1;
+                    t = t + s2;
+                    t = t + s3;
+                    a.tin_qna[j] = t;
+                } else {
+                    for (int i = 0; i < D; i++) s0 = s0 + sq[i] * sq[i];
+                    a.tin_qna[j] = s0;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+template <int METRIC, int BN, bool BOOT, bool MAPPED, bool TAUIN = false>
 __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tall16Args a, int spx)
 {
     constexpr int TN = BN / 32;
@@ -918,12 +1064,17 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
     constexpr int NPS = 2 + NPB, DIST = NST - 1, H1 = 2;
     constexpr bool PIPE = BN != 256; // (at 256 queries there are no registers for a third set of fragments: barrier on top)
     (void)spx;
+    extern __shared__ __attribute__((aligned(16))) unsigned char hlds[];
     uint32_t lo, hi; // this workgroup's positions
-    h_range((uint32_t)(a.row_end - a.row_begin), (int)blockIdx.x, (int)gridDim.x, lo, hi);
+    if (TAUIN) {
+        h_range_duty((uint32_t)(a.row_end - a.row_begin), (int)blockIdx.x, (int)gridDim.x, a.nq, a.tin_dr, lo, hi);
+        if ((int)blockIdx.x >= (int)gridDim.x - a.nq) tin_duty(a, (int)gridDim.x - 1 - (int)blockIdx.x, hlds);
+    } else {
+        h_range((uint32_t)(a.row_end - a.row_begin), (int)blockIdx.x, (int)gridDim.x, lo, hi);
+    }
     if (hi <= lo) return;
     const int n_my = (int)((hi - lo + H_BM - 1) / H_BM); // its tiles: positions lo + 256 i ..
 
-    extern __shared__ __attribute__((aligned(16))) unsigned char hlds[];
     unsigned char *ring = hlds;
     float *s_auxp = reinterpret_cast<float *>(ring + NST * STAGE); // [2][512]
     const uint32_t ring_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)ring;
@@ -1037,7 +1188,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
     for (int tn = 0; tn < TN; tn++) {
         const int qj = tn * 32 + l31;
         const int qc = qj < a.nq ? qj : a.nq - 1;
-        uint64_t tau = BOOT ? 0ull : a.cs.tau[qc];
+        uint64_t tau = (BOOT || TAUIN) ? 0ull : a.cs.tau[qc];
         if (qj >= a.nq) tau = 0ull;
         const float tk = tau_key_of(tau);
         qs[tn] = a.qinv[qc];
@@ -1046,6 +1197,10 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
             const float G = a.gsum * a.qnrm[qc];
             m2qs[tn] = G > 0.f ? -qs[tn] / G : 0.f;
         }
+        // (TAUIN: nothing below consumes the scales before the first admission, so the compiler would leave their loads in
+        // flight and put the "s_waitcnt vmcnt(0)" INTO the admission branch, where it drains the DMA ring at every admitted
+        // element -- measured: 297 us instead of 238.  Consumed here they are waited for once, in front of the loop.)
+        if (TAUIN) asm volatile("" : "+v"(qs[tn]), "+v"(m2qs[tn]));
         const float scale = __builtin_bit_cast(float, (254u << 23) - __builtin_bit_cast(uint32_t, qs[tn]));
         tkc[tn] = METRIC != METRIC_COS ? tk : tk * scale;
 #ifdef LB_DIAG
@@ -1136,6 +1291,42 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
             else h_wait_vmcnt<3 * NPS>();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+        }
+        if (TAUIN && i == 0) { // the thresholds, published meanwhile by the launch's last nq workgroups
+            // Every wave reads ITS queries' thresholds with device-coherent vector loads (each drains the wave's part of the DMA
+            // ring once); a threshold of 0 is "not out yet" (the launch before left them so; a genuine one ends in 32 one-bits).
+            // Usually the first look finds them all: the duty takes ~6 us, the first epilogue comes ~16 us into the launch.
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            uint64_t tauv[TN];
+            bool ok = false;
+#pragma nounroll
+            for (uint32_t spin = 0; spin < 1500u && !ok; spin++) { // ~0.7 us a round: ~1 ms in all
+                bool all = true;
+#pragma unroll
+                for (int tn = 0; tn < TN; tn++) {
+                    const int qj = tn * 32 + l31;
+                    u32x2 tv;
+                    const uint64_t *tp = a.cs.tau + (qj < a.nq ? qj : 0);
+                    asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(tv) : "v"(tp) : "memory");
+                    tauv[tn] = ((uint64_t)tv[1] << 32) | tv[0];
+                    all = all && tauv[tn] != 0ull;
+                }
+                ok = __builtin_amdgcn_ballot_w64(!all) == 0ull;
+                if (!ok) __builtin_amdgcn_s_sleep(8);
+            }
+            if (!ok && tid == 0) *a.tin_fail = a.tin_tag; // (gave up: nothing is admitted, the host redoes the batch)
+#pragma unroll
+            for (int tn = 0; tn < TN; tn++) {
+                const int qj = tn * 32 + l31;
+                uint64_t tau = tauv[tn];
+                if (!ok || qj >= a.nq) tau = 0ull;
+                const float tk = tau_key_of(tau);
+                const float scale = __builtin_bit_cast(float, (254u << 23) - __builtin_bit_cast(uint32_t, qs[tn]));
+                tkc[tn] = METRIC != METRIC_COS ? tk : tk * scale;
+#ifdef LB_DIAG
+                if (a.abl == 8) tkc[tn] = -__builtin_huge_valf();
+#endif
+            }
         }
         // ---- epilogue of the tile (as the 256-query form: 2 VALU + 1 scalar branch per element, per-wave segments) ----------
         const float *s_aux = s_auxp + (i & 1) * 512;
@@ -1325,6 +1516,18 @@ static bool tall16_persistent_ok(int D, int nq, bool img, bool mapped, bool mask
     return true;
 }
 bool tall16_runs_persistent(int D, int nq, bool img, bool mapped, bool masked) { return tall16_persistent_ok(D, nq, img, mapped, masked); }
+bool tall16_tin_ok(int D, int nq, int64_t n_pos, bool img, bool mapped, bool masked, bool with_norm, uint32_t count, int m)
+{
+    static const int n16 = lb_tunable("LB_F16_NARROW", 1);
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n;
+    }();
+    uint32_t dr;
+    return img && n16 && nq <= 128 && tall16_persistent_ok(D, nq, img, mapped, masked) && tin_plan(D, nq, n_pos, (cus / 8) * 8, with_norm, count, m, dr);
+}
 bool tall16_entries_are_positions(int D, int nq, bool img, bool mapped, bool masked)
 {
     return mapped && tall16_persistent_ok(D, nq, img, true, masked);
@@ -1336,10 +1539,11 @@ bool tall16_entries_are_positions(int D, int nq, bool img, bool mapped, bool mas
 static void tall16_window(int metric, const float *X, const float *norm2, const float *rnorm, int64_t row_begin, int64_t row_end,
                           int D, const void *Qh, const float *qinv, int nq, int q_stride, const uint8_t *mask,
                           const uint32_t *rowmap, CandState cs, bool boot, hipStream_t s, const void *Xh, int64_t xh_cap,
-                          bool may_split, uint32_t gstride, const float *qnrm, float gsum)
+                          bool may_split, uint32_t gstride, const float *qnrm, float gsum, const Tall16Tin *tin = nullptr)
 {
     if (row_end <= row_begin || nq <= 0) return;
     Tall16Args a;
+    a.tin_fail = nullptr;
     a.gstride = gstride;
     a.qnrm = qnrm;
     a.gsum = gsum;
@@ -1397,6 +1601,19 @@ static void tall16_window(int metric, const float *X, const float *norm2, const 
             // ring, side inputs, flush flags + counters, admission segments
             const size_t nshmem = ring_b + 2 * 512 * sizeof(float) + 16 + 2 * 256 * 4 + 8 * (bn == 256 ? 272 : 360) * 12;
             dim3 ngrid((unsigned)(spx * 8));
+            bool tauin = false;
+            uint32_t dr = 0;
+            if (tin && !boot && gstride == 0 && tin_plan(D, nq, row_end - row_begin, (int)ngrid.x, tin->qna != nullptr, tin->count, tin->m, dr)) {
+                tauin = true; // thresholds inside the launch (see the kernel)
+                a.tin_count = tin->count; a.tin_m = tin->m; a.tin_tag = tin->tag;
+                a.tin_fail = tin->fail_host; a.tin_Q = tin->Q; a.tin_qna = tin->qna; a.tin_order = tin->order; a.tin_dr = dr;
+            }
+#define LB_NARROW16T(M, N, P)                                                                                                  \
+    do {                                                                                                                       \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_filter_narrow16p_kernel<M, N, false, P, true>),         \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)nshmem);                                    \
+        hipLaunchKernelGGL((gemm_filter_narrow16p_kernel<M, N, false, P, true>), ngrid, dim3(H_THREADS), nshmem, s, a, spx);   \
+    } while (0)
 #define LB_NARROW16(M, N, B, P)                                                                                        \
     do {                                                                                                               \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_filter_narrow16p_kernel<M, N, B, P>),           \
@@ -1410,7 +1627,15 @@ static void tall16_window(int metric, const float *X, const float *norm2, const 
     } while (0)
 #define LB_NARROW16_M(M)                                     \
     do {                                                     \
-        if (mapped) {                                        \
+        if (tauin) {                                         \
+            if (mapped) {                                    \
+                if (bn == 64) LB_NARROW16T(M, 64, true);     \
+                else LB_NARROW16T(M, 128, true);             \
+            } else {                                         \
+                if (bn == 64) LB_NARROW16T(M, 64, false);    \
+                else LB_NARROW16T(M, 128, false);            \
+            }                                                \
+        } else if (mapped) {                                 \
             if (boot) LB_NARROW16_B(M, true, true);          \
             else LB_NARROW16_B(M, false, true);              \
         } else {                                             \
@@ -1424,6 +1649,7 @@ static void tall16_window(int metric, const float *X, const float *norm2, const 
 #undef LB_NARROW16_M
 #undef LB_NARROW16_B
 #undef LB_NARROW16
+#undef LB_NARROW16T
             return;
         }
         const size_t pshmem = (img ? (size_t)4 * (H_BM * H_BK * 2 + H_B_BYTES) : (size_t)H_NST * H_STAGE_BYTES) + 2 * 512 * sizeof(float) +
@@ -1513,11 +1739,12 @@ static void tall16_window(int metric, const float *X, const float *norm2, const 
 void launch_gemm_filter_tall16(int metric, const float *X, const float *norm2, const float *rnorm, int64_t row_begin,
                                int64_t row_end, int D, const void *Qh, const float *qinv, int nq, const uint8_t *mask,
                                const uint32_t *rowmap, CandState cs, bool boot, hipStream_t s, const void *Xh, int64_t xh_cap,
-                               uint32_t gstride, const float *qnrm, float gsum)
+                               uint32_t gstride, const float *qnrm, float gsum, const Tall16Tin *tin)
 {
     // (the granule-strided sample view exists in the persistent forms only)
     if (gstride != 0 && (!boot || !tall16_persistent_ok(D, nq, Xh != nullptr, rowmap != nullptr, mask != nullptr))) return;
-    tall16_window(metric, X, norm2, rnorm, row_begin, row_end, D, Qh, qinv, nq, nq, mask, rowmap, cs, boot, s, Xh, xh_cap, true, gstride, qnrm, gsum);
+    tall16_window(metric, X, norm2, rnorm, row_begin, row_end, D, Qh, qinv, nq, nq, mask, rowmap, cs, boot, s, Xh, xh_cap, true, gstride, qnrm, gsum,
+                  tin);
 }
 
 } // namespace lb

@@ -460,6 +460,7 @@ struct SampleArgs {
     _Float16 *Qh = nullptr;
     float *qinv = nullptr, *qnrm = nullptr;
     const float *pcenter = nullptr;
+    int tau_zero = 0; // the riding preparation leaves tau = 0 ("not out yet") for a candidate launch that computes its own
 };
 
 __device__ __forceinline__ float wave_sum(float v)
@@ -532,24 +533,26 @@ __device__ __forceinline__ void query_prep_body(const float *Q, int nq, int D, _
             cs.cnt[q] = 0;
             cs.tau[q] = kEntryMax;
         }
-        if (reset != 0) cs.flags[q] = 0;
+        if (reset == 3) cs.tau[q] = 0ull; // "not out yet": the candidate launch computes the thresholds itself (TAUIN)
+        if (reset == 1 || reset == 2) cs.flags[q] = 0;
         if (qna) qna[q] = order == ORDER_UNROLL4 ? exact_sq_norm_lds<ORDER_UNROLL4>(sq, D) : exact_sq_norm_lds<ORDER_SEQ>(sq, D);
     }
 }
 
 __global__ __launch_bounds__(64) void query_prep_kernel(const float *Q, int nq, int D, _Float16 *Qh, float *qinv, float *qna, int order,
-                                                        CandState cs, const float *center, float *qnrm)
+                                                        CandState cs, const float *center, float *qnrm, int tau_zero)
 {
     extern __shared__ __attribute__((aligned(16))) float sq[];
     query_prep_body(Q, nq, D, Qh, qinv, qna, order, cs, center, qnrm, 1, (int)blockIdx.x, (int)threadIdx.x, true, sq);
+    if (tau_zero && threadIdx.x == 0) cs.tau[blockIdx.x] = 0ull; // "not out yet" (TAUIN)
 }
 
 void launch_query_prep(const float *Q, int nq, int D, void *Qh, float *qinv, float *qna, int order, CandState cs, hipStream_t s,
-                       const float *center, float *qnrm)
+                       const float *center, float *qnrm, bool tau_zero)
 {
     if (nq <= 0) return;
     hipLaunchKernelGGL(query_prep_kernel, dim3((unsigned)nq), dim3(64), (size_t)((D + 3) & ~3) * sizeof(float), s, Q, nq, D,
-                       reinterpret_cast<_Float16 *>(Qh), qinv, center ? nullptr : qna, order, cs, center, qnrm);
+                       reinterpret_cast<_Float16 *>(Qh), qinv, center ? nullptr : qna, order, cs, center, qnrm, tau_zero ? 1 : 0);
 }
 
 // R = sampled rows per wave: every query chunk fetched from L2 is used for R rows (with 32 query
@@ -710,8 +713,8 @@ __global__ __launch_bounds__(256) void sample_scores_kernel(SampleArgs a)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t nprep = a.Qh ? (uint32_t)a.nsel : 0u;
     if (blockIdx.x < nnorm + nprep) { // (no query subset on this route: slot j is query j)
-        query_prep_body(a.Q, a.nsel, a.D, a.Qh, a.qinv, nullptr, a.order, a.cs, a.pcenter, a.qnrm, /*reset=*/0, (int)(blockIdx.x - nnorm), lane,
-                        wave == 0, sq);
+        query_prep_body(a.Q, a.nsel, a.D, a.Qh, a.qinv, nullptr, a.order, a.cs, a.pcenter, a.qnrm, /*reset=*/a.tau_zero ? 3 : 0,
+                        (int)(blockIdx.x - nnorm), lane, wave == 0, sq);
         return;
     }
     const uint32_t blk = blockIdx.x - nnorm - nprep;
@@ -733,6 +736,7 @@ void launch_sample_scores(int metric, int order, const float *X, int D, int64_t 
         a.qinv = prep->qinv;
         a.qnrm = prep->qnrm;
         a.pcenter = prep->center;
+        a.tau_zero = prep->tau_zero ? 1 : 0;
     }
     a.center = (norm2 != nullptr && metric == METRIC_L2) ? center : nullptr;
     a.keys = norm2 != nullptr ? 1 : 0;

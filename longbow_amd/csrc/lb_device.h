@@ -221,11 +221,28 @@ void launch_gemm_filter_tall2(int metric, const float *X, const float *norm2, co
 // ONE fp16 product per (row, query, k) on 256 x 256 tiles (kernels_gemm_tall16.hip): Qh / qinv from launch_queries_to_f16
 // (fp16 image of the batch, each query scaled by a power of two to a norm in [1, 2); qinv = 1 / scale); X = f32 corpus
 void launch_queries_to_f16(const float *Q, int nq, int D, void *Qh, float *qinv, hipStream_t s);
+// The one-tile persistent kernel over the image (<= 128 queries) can turn the sample the launch before it left in
+// lists[q][0 .. count) into the thresholds ITSELF (its last nq workgroups do, on shorter row ranges; everybody picks the
+// thresholds up in front of its first epilogue): no threshold launch, no gap behind it.  The launch before must leave
+// tau[q] = 0 ("not out yet": launch_query_prep / SamplePrep, tau_zero); a bounded wait that gives up stores `tag` to the
+// pinned fail_host and admits nothing (the host redoes the batch).  Q / qna / order: the duty workgroups also compute the
+// exact ||q||^2 (cosine; qna null otherwise).
+struct Tall16Tin {
+    uint32_t count;
+    int m;
+    uint32_t tag;
+    uint32_t *fail_host;
+    const float *Q;
+    float *qna;
+    int order;
+};
+bool tall16_tin_ok(int D, int nq, int64_t n_pos, bool img, bool mapped, bool masked, bool with_norm, uint32_t count, int m);
 // the same image and scales, plus the exact ||q||^2 in `order` (qna, or null) and the reset of the queries' candidate state:
 // one launch for what a search over this route needs from its batch (kernels_scan.hip)
 void launch_query_prep(const float *Q, int nq, int D, void *Qh, float *qinv, float *qna, int order, CandState cs, hipStream_t s,
                        const float *center = nullptr, // center: the image of q - center (L2 over the centred corpus image)
-                       float *qnrm = nullptr);        // [nq] upper bounds of |q| (the dot product's lower-bound key)
+                       float *qnrm = nullptr,         // [nq] upper bounds of |q| (the dot product's lower-bound key)
+                       bool tau_zero = false);        // thresholds left at 0 = "not out yet" (a TAUIN candidate launch follows)
 // Xh (or null): the corpus's K-blocked fp16 image [Dp / 32][xh_cap][32] from launch_corpus_to_f16, in step with X; used by
 // unfiltered searches (half the bytes to stage, a four-stage ring)
 void launch_gemm_filter_tall16(int metric, const float *X, const float *norm2, const float *rnorm, int64_t row_begin,
@@ -234,8 +251,9 @@ void launch_gemm_filter_tall16(int metric, const float *X, const float *norm2, c
                                int64_t xh_cap = 0,
                                uint32_t gstride = 0,  // boot launches of the persistent forms: positions = granules of 16 rows,
                                                       // gstride rows apart (an evenly spaced sample read in whole KiB)
-                               const float *qnrm = nullptr, float gsum = 0.f); // dot product on the persistent forms: upper bounds
+                               const float *qnrm = nullptr, float gsum = 0.f, // dot product on the persistent forms: upper bounds
                                                       // of |q| (launch_query_prep) and gamma_a + gamma_o -- the lower-bound key
+                               const struct Tall16Tin *tin = nullptr); // thresholds inside the launch (tall16_tin_ok)
 void launch_corpus_to_f16(const float *X, int64_t row_begin, int64_t row_end, int D, void *Xh, int64_t cap, hipStream_t s,
                           const float *center = nullptr); // center (or null; [>= D + 8]): the image holds fp16(x - center)
 int corpus_f16_plane_dims(); // dimensions per plane of that image (its rows are zero-padded to a multiple of it)
@@ -272,6 +290,7 @@ struct SamplePrep {
     void *Qh;
     float *qinv, *qnrm;
     const float *center;
+    bool tau_zero; // leave tau = 0 ("not out yet": a TAUIN candidate launch follows)
 };
 void launch_sample_scores(int metric, int order, const float *X, int D, int64_t span, uint32_t count,
                           const uint32_t *rowmap, const uint8_t *mask, const float *Q, const int *qsel, int nsel,
