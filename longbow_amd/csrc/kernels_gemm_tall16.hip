@@ -114,6 +114,23 @@ struct Tall16Args {
 // round-robin left 16 tiles to some workgroups and 15 to others at 1M rows: 4 % of the pass), and a short launch (the 8192-row
 // sample) spreads over all of them.  A range's last tile is partial: positions beyond it read its last row again (L2 hits)
 // and carry a NaN side input.
+// sample / bootstrap epilogue: the entries of positions p .. p + 3 (p a multiple of 4) of one query's list.  vec: the list is
+// 16-B aligned at every such p (cap a multiple of 4) -- two 16-B stores instead of four of 8 (a store instruction of this
+// epilogue touches 32 lists: a quarter of the instructions, 32-B segments instead of 8-B ones)
+__device__ __forceinline__ void h_store_entries4(uint64_t *list, uint32_t p, uint32_t last_pos, const uint64_t (&ent)[4], bool vec)
+{
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    if (vec && p + 3u <= last_pos) {
+        u64x2 *d = reinterpret_cast<u64x2 *>(list + p);
+        d[0] = u64x2{ent[0], ent[1]};
+        d[1] = u64x2{ent[2], ent[3]};
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            if (p + (uint32_t)e <= last_pos) list[p + (uint32_t)e] = ent[e];
+    }
+}
+
 __device__ __forceinline__ void h_range(uint32_t n_pos, int gi, int ng, uint32_t &lo, uint32_t &hi)
 {
     const uint32_t q = n_pos / (uint32_t)ng, r = n_pos % (uint32_t)ng; // n_pos gi / ng = q gi + r gi / ng (no 64-bit division)
@@ -545,6 +562,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
     const int last_q = a.nq - 1;
     const uint32_t last_pos = (uint32_t)(a.row_end - a.row_begin - 1); // positions of this launch: corpus row = row_begin + position (sample pass: h_rowof)
     const uint32_t gstride = BOOT ? a.gstride : 0u;
+    const bool boot_vec = BOOT && (a.cs.cap & 3u) == 0u && (reinterpret_cast<uintptr_t>(a.cs.lists) & 15) == 0; // (h_store_entries4)
     // dot product: |x| of the lower-bound key, padded for the f32 roundings of the key's own fma (they are relative to the first
     // term, up to 1 / (gamma_a + gamma_o) times |x|) and of the stored norm
     const float dot_pad = 1.0f + (a.gsum > 0.f ? 6.0e-7f / a.gsum : 0.f) + 1.0e-5f + 1.05f * (float)(a.D + 8) * 5.9604645e-8f;
@@ -836,12 +854,16 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_tall16p_kernel(Tall1
                 if (BOOT) { // sample pass: the entry of position p goes to list[p] (rows beyond the range: none)
                     if (qok) {
 #pragma unroll
-                        for (int x = 0; x < 16; x++) {
-                            const float kp = METRIC != METRIC_COS ? fmaf(acc[tm][tn][x], m2qs[tn], aux[x >> 2][x & 3])
-                                                                 : acc[tm][tn][x] * aux[x >> 2][x & 3];
-                            const uint32_t px = pos0 + (uint32_t)(8 * (x >> 2) + (x & 3));
-                            if (px <= last_pos)
-                                list[px] = pack_entry(METRIC != METRIC_COS ? kp : kp * qs[tn], (uint32_t)a.row_begin + h_rowof(px, gstride));
+                        for (int g = 0; g < 4; g++) { // four consecutive positions a lane: 32 B of the query's list in two stores
+                            uint64_t ent[4];
+                            const uint32_t pg = pos0 + (uint32_t)(8 * g);
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                const int x = 4 * g + e;
+                                const float kp = METRIC != METRIC_COS ? fmaf(acc[tm][tn][x], m2qs[tn], aux[g][e]) : acc[tm][tn][x] * aux[g][e];
+                                ent[e] = pack_entry(METRIC != METRIC_COS ? kp : kp * qs[tn], (uint32_t)a.row_begin + h_rowof(pg + (uint32_t)e, gstride));
+                            }
+                            h_store_entries4(list, pg, last_pos, ent, boot_vec);
                         }
                     }
                     continue;
@@ -1087,6 +1109,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
     const int last_q = a.nq - 1;
     const uint32_t last_pos = hi - 1;
     const uint32_t gstride = BOOT ? a.gstride : 0u;
+    const bool boot_vec = BOOT && (a.cs.cap & 3u) == 0u && (reinterpret_cast<uintptr_t>(a.cs.lists) & 15) == 0; // (h_store_entries4)
     // dot product: |x| of the lower-bound key, padded for the f32 roundings of the key's own fma (they are relative to the first
     // term, up to 1 / (gamma_a + gamma_o) times |x|) and of the stored norm
     const float dot_pad = 1.0f + (a.gsum > 0.f ? 6.0e-7f / a.gsum : 0.f) + 1.0e-5f + 1.05f * (float)(a.D + 8) * 5.9604645e-8f;
@@ -1352,11 +1375,16 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
             if (BOOT) {
                 if (qok) {
 #pragma unroll
-                    for (int x = 0; x < 16; x++) {
-                        const float kp = METRIC != METRIC_COS ? fmaf(acc[tn][x], m2qs[tn], aux[x >> 2][x & 3]) : acc[tn][x] * aux[x >> 2][x & 3];
-                        const uint32_t px = pos0 + (uint32_t)(8 * (x >> 2) + (x & 3));
-                        if (px <= last_pos)
-                            list[px] = pack_entry(METRIC != METRIC_COS ? kp : kp * qs[tn], (uint32_t)a.row_begin + h_rowof(px, gstride));
+                    for (int g = 0; g < 4; g++) { // four consecutive positions a lane: 32 B of the query's list in two stores
+                        uint64_t ent[4];
+                        const uint32_t pg = pos0 + (uint32_t)(8 * g);
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const int x = 4 * g + e;
+                            const float kp = METRIC != METRIC_COS ? fmaf(acc[tn][x], m2qs[tn], aux[g][e]) : acc[tn][x] * aux[g][e];
+                            ent[e] = pack_entry(METRIC != METRIC_COS ? kp : kp * qs[tn], (uint32_t)a.row_begin + h_rowof(pg + (uint32_t)e, gstride));
+                        }
+                        h_store_entries4(list, pg, last_pos, ent, boot_vec);
                     }
                 }
                 continue;
