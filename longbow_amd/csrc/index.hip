@@ -271,6 +271,10 @@ struct lb_gpu_index {
     float *d_center = nullptr, *d_norm2c = nullptr;
     uint32_t *d_cstats = nullptr;
     bool xh_centred = false, xh_c_ok = false;
+    // what the image loses, measured: max over its rows of |x - fp16(x)| / |x| (kernels_gemm_tall16.hip: f16_residual_kernel);
+    // 0 = not measured (the per-element worst case 2^-11 stands in)
+    uint32_t *d_xh_rho2 = nullptr;
+    float xh_rho = 0.f;
     bool xh_offset_dom = false;  // |c|^2 is several times the largest centred |x - c|^2: plain L2 keys cancel on this data, so
                                  // AUTO keeps batched searches on the centred image whatever the cost model says of other routes
     int64_t xh_declined_n = 0;   // a centred image was out of fp16's range at this many rows: not tried again below twice that
@@ -851,7 +855,17 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     // residual terms
     // ... or (split 3) one fp16 product: 2^-11 per operand, the subnormal term under the route's norm conditions, and the
     // f32 accumulation of D products (kernels_gemm_tall16.hip)
+    // ... with the index's fp16 image the operands' share is MEASURED instead: |q.x - q~.x~| <= |q||x - x~| + |q - q~||x~|, the
+    // residual norms taken when the image was written (rho_x = max over rows of |x - x~| / |x|, sync_f16_image) and when the
+    // query image is (rho_q per query, query_prep_body) -- a third to a half of the worst case for data that fills the
+    // mantissa, subnormal effects included:  gamma(q) = 1.05 (rho_x + A (1 + rho_x) + 2^-21) + 1.05 (1 + rho_x)(1 + A) rho_q,
+    // A = (D + 8) 2^-24 the f32 accumulation of D exact products
+    static const bool rho_on = lb_tunable("LB_MEASURED_RHO", 1) != 0;
+    const bool measured = rho_on && route.split == 3 && have_xh && h->xh_rho > 0.f && h->xh_rho < 4.0e-4f; // (else the worst case is the better bound)
+    const float accA = (float)(h->dim + 8) * u24;
+    const float qrho_k = measured ? 1.05f * (1.0f + h->xh_rho) * (1.0f + accA) : 0.f;
     const float gamma = route.split == 0   ? 1.05f * (float)(h->dim + 8) * u24
+                        : measured         ? 1.05f * (h->xh_rho + accA * (1.0f + h->xh_rho) + 4.7683716e-7f)
                         : route.split == 3 ? 1.05f * (9.765625e-4f + 4.7683716e-7f + (float)(h->dim + 8) * u24 +
                                                       2.9802322e-8f * std::sqrt((float)h->dim) * 65.0f)
                                            : 1.05f * ((float)(3 * h->dim / 16 + 24) * u24 + 3.0f * 3.8146973e-6f);
@@ -867,17 +881,18 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         launch_split_bf16(d_q, w->d_qs, nq, h->dim, s);
     };
     if (!use_narrow && (route.split == 1 || route.split == 2)) split_queries(); // the tall / wide split kernels take the batch as an image
-    float *d_qinv = nullptr, *d_qnrm = nullptr;
+    float *d_qinv = nullptr, *d_qnrm = nullptr, *d_qrho = nullptr;
     // dot product on the persistent fp16 kernels: LOWER-BOUND keys -(q.x)~ / G - |x|, G = (gamma_a + gamma_o) |q| (a few very long
     // rows then sort to the front of the lists and are scored exactly instead of widening every row's error bound)
     const float gsum = gamma + 1.05f * (float)(h->dim + 8) * u24;
+    const float rho_gain = (measured && gsum > 0.f) ? qrho_k / gsum : 0.f; // (dot: G(q) = (gsum + qrho_k rho_q) |q|, folded into qnrm)
     const bool dot_lb = metric == LB_METRIC_DOT && use_tall16 &&
                         tall16_runs_persistent(h->dim, nq, have_xh, rv.rowmap != nullptr, mask != nullptr);
     const bool own_keys = centred || dot_lb; // keys only the persistent kernels produce: sample and boot chunks must come from them
     static const int riders_max = lb_tunable("LB_NORM_RIDERS_MAXQ", 384);
     const bool prep_riders = sp.on && nq <= riders_max; // (cosine: the exact query norms come out of the threshold launch)
     if (use_tall16) { // fp16 image of the batch (scaled per query) + the inverse scales
-        const size_t img = (((size_t)nq * (size_t)((h->dim + 31) & ~31) * 2) + 255) & ~(size_t)255, need = img + 2 * (size_t)nq * sizeof(float);
+        const size_t img = (((size_t)nq * (size_t)((h->dim + 31) & ~31) * 2) + 255) & ~(size_t)255, need = img + 3 * (size_t)nq * sizeof(float);
         if (w->d_qh_bytes < need) {
             if (w->d_qh) (void)hipFree(w->d_qh);
             w->d_qh = nullptr;
@@ -887,6 +902,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         }
         d_qinv = reinterpret_cast<float *>(static_cast<char *>(w->d_qh) + img);
         d_qnrm = d_qinv + nq;
+        d_qrho = measured ? d_qnrm + nq : nullptr;
     }
     if (!use_narrow && route.split == 1) {
         gx = h->d_Xs;
@@ -937,7 +953,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         // (the exact norm is a serial chain of D additions, 3.5 us at 768: up to 384 queries it rides in the threshold launch
         // instead, where nothing waits for it)
         launch_query_prep(d_q, nq, h->dim, w->d_qh, d_qinv, (metric == LB_METRIC_COSINE && !prep_riders) ? w->d_qna : nullptr, order,
-                          w->cs, s, centred ? h->d_center : nullptr, dot_lb ? d_qnrm : nullptr, tauin);
+                          w->cs, s, centred ? h->d_center : nullptr, dot_lb ? d_qnrm : nullptr, tauin, d_qrho, rho_gain);
     const bool norm_riders = prep_riders && metric == LB_METRIC_COSINE;
     // the last launch: key-space pruning + exact re-rank + proof in one (kernels_finish.hip); beta: how far beyond one error
     // bound the cut lies (the proof itself never depends on it)
@@ -985,7 +1001,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
         if (light_sample) {
             ProfScope p(w, s, prof, 1);
             // (centred keys: the same key about the image's centre, from the f32 rows)
-            const SamplePrep sprep{w->d_qh, d_qinv, dot_lb ? d_qnrm : nullptr, centred ? h->d_center : nullptr, tauin};
+            const SamplePrep sprep{w->d_qh, d_qinv, dot_lb ? d_qnrm : nullptr, centred ? h->d_center : nullptr, tauin, d_qrho, rho_gain};
             launch_sample_scores(metric, order, h->d_X, h->dim, sp.span, sp.count, rv.rowmap, mask, d_q, nullptr, nq,
                                  w->cs, nullptr, s, centred ? h->d_norm2c : h->d_norm2, h->d_rnorm, centred ? h->d_center : nullptr,
                                  prep_rides ? &sprep : nullptr);
@@ -1078,7 +1094,8 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
             const bool ckeys = centred && use_tall16; // (the keys of this search were taken about the image's centre)
             launch_finish(metric, order, h->d_X, h->dim, d_q, nq, w->d_qna, w->cs, k, ckeys ? h->d_cstats : h->d_maxnorm2, gamma, finish_beta,
                           h->has_ids ? h->d_ids : nullptr, entries_pos ? rv.rowmap : nullptr, d_dist, d_lab, s, w->h_flags, w->d_done, w->d_xcnt,
-                          w->d_xscratch, kFinishSplitMaxQ, smax, ckeys ? h->d_center : nullptr, dot_lb ? h->d_norm2 : nullptr, d_qnrm, gsum);
+                          w->d_xscratch, kFinishSplitMaxQ, smax, ckeys ? h->d_center : nullptr, dot_lb ? h->d_norm2 : nullptr, d_qnrm, gsum,
+                          dot_lb ? nullptr : d_qrho, qrho_k);
         }
     }
     std::vector<int> bad;
@@ -1346,6 +1363,8 @@ void drop_f16_image(lb_gpu_index *h)
     h->d_norm2c = nullptr;
     h->xh_rows = h->xh_cap = 0;
     h->xh_centred = h->xh_c_ok = h->xh_offset_dom = false;
+    h->xh_rho = 0.f;
+    if (h->d_xh_rho2) (void)hipMemset(h->d_xh_rho2, 0, sizeof(uint32_t));
 }
 
 // Recompute the visible-row list from d_mask (caller holds the exclusive lock).  The list is used
@@ -1525,6 +1544,20 @@ void sync_f16_image(lb_gpu_index *h)
                 for (float v : hc) c2 += (double)v * (double)v;
                 h->xh_offset_dom = c2 > 4.0 * (double)mx;
             }
+            { // the loss of the new rows' images, measured (the candidate keys' error bound: search_batch_device, gamma)
+                if (!h->d_xh_rho2) {
+                    LB_HIP(hipMalloc(&h->d_xh_rho2, sizeof(uint32_t)));
+                    LB_HIP(hipMemsetAsync(h->d_xh_rho2, 0, sizeof(uint32_t), s));
+                }
+                launch_f16_residual(h->d_X, h->xh_rows, h->n, h->dim, h->xh_centred ? h->d_center : nullptr, h->d_xh_rho2, s);
+                uint32_t rb = 0;
+                LB_HIP(hipMemcpyAsync(&rb, h->d_xh_rho2, sizeof rb, hipMemcpyDeviceToHost, s));
+                LB_HIP(hipStreamSynchronize(s));
+                const float r2 = __builtin_bit_cast(float, rb);
+                // (a ratio beyond the worst case of normal fp16 values, 2^-22, means elements in the subnormal range or flushed
+                // to zero carry weight: still a valid bound as long as it is finite and small enough to be of use)
+                h->xh_rho = (rb < 0x7f800000u && r2 <= 1.0e-4f) ? std::sqrt(r2) * 1.000001f : 0.f;
+            }
             LB_HIP(hipStreamSynchronize(s));
             h->xh_rows = h->n;
         }
@@ -1696,6 +1729,7 @@ void lb_gpu_index_free(lb_gpu_index *h)
         if (h->d_norm2c) (void)hipFree(h->d_norm2c);
         if (h->d_center) (void)hipFree(h->d_center);
         if (h->d_cstats) (void)hipFree(h->d_cstats);
+        if (h->d_xh_rho2) (void)hipFree(h->d_xh_rho2);
         for (int i = 0; i < 2; i++) {
             if (h->h_stage[i]) (void)hipHostFree(h->h_stage[i]);
             if (h->stage_ev[i]) (void)hipEventDestroy(h->stage_ev[i]);

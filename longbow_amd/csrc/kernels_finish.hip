@@ -47,6 +47,8 @@ struct FinishArgs {
     int k;
     const uint32_t *maxnorm2;
     float gamma, beta;
+    const float *qrho; // or null: per-query share of the keys' error bound, gamma(q) = gamma + qrho_k * qrho[q] (index.hip: measured residuals)
+    float qrho_k;
     const int64_t *ids;
     const uint32_t *posmap; // or null: the lists carry positions of this row list (a filtered view), not corpus rows
     const float *center;    // or null (L2 only): the keys were taken about this centre -- key + |q - c|^2 ~ d^2, the proof's norms
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(FN_THREADS) void finish_kernel(FinishArgs a)
 #endif
 
     // ---- the cut ------------------------------------------------------------------------------------------------------
-    const float ga = a.gamma;
+    const float ga = a.gamma + (a.qrho ? a.qrho_k * a.qrho[qi] : 0.f);
     const float xmax = sqrtf(__builtin_bit_cast(float, a.maxnorm2[0])) * 1.000001f;
     const float ak = entry_key(pivot);
     // what the proof at the end takes off f(cut), evaluated at a_k: the cut lies (1 + beta) of it beyond a_k -- one part for the
@@ -687,10 +689,13 @@ size_t finish_scratch_bytes(int nq_split_max, uint32_t smax) { return (size_t)nq
 void launch_finish(int metric, int order, const float *X, int D, const float *Q, int nq, const float *qna, CandState cs, int k,
                    const uint32_t *d_maxnorm2, float gamma, float beta, const int64_t *ids, const uint32_t *posmap, float *out_dist,
                    int64_t *out_labels, hipStream_t s, uint32_t *flags_host, uint32_t *done, uint32_t *xcnt, void *xscratch,
-                   int nq_split_max, uint32_t smax, const float *center, const float *lb_norm2, const float *lb_qnrm, float lb_gsum)
+                   int nq_split_max, uint32_t smax, const float *center, const float *lb_norm2, const float *lb_qnrm, float lb_gsum,
+                   const float *qrho, float qrho_k)
 {
     if (nq <= 0) return;
     FinishArgs a;
+    a.qrho = qrho;
+    a.qrho_k = qrho_k;
     a.center = metric == METRIC_L2 ? center : nullptr;
     a.lb_norm2 = metric == METRIC_DOT ? lb_norm2 : nullptr;
     a.lb_qnrm = lb_qnrm;

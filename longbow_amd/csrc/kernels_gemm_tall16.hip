@@ -1488,7 +1488,44 @@ __global__ __launch_bounds__(256) void corpus_to_f16_kernel(const float *X, int6
     *reinterpret_cast<f16x8 *>(Xh + ((int64_t)(k0 / H_XP) * cap + row) * H_XP + (k0 % H_XP)) = v;
 }
 
+// What the fp16 image loses, MEASURED: stat = max over rows of |x - fp16(x)|^2 / |x|^2 (float bits; x - center for the centred
+// image), one wave a row.  |q.x - q~.x~| <= |q| |x - x~| + |q - q~| |x~| by Cauchy-Schwarz on the residual VECTORS: with the
+// measured ratios (~0.3 x 2^-11 for data that fills the mantissa) the candidate keys' rigorous error bound is a third to a half
+// of the per-element worst case 2^-11 + 2^-11 -- and with it the rows the finish launch has to score exactly.  (Elements that
+// fall into fp16's subnormal range or flush to zero are in the residual like everything else.)
+__global__ __launch_bounds__(256) void f16_residual_kernel(const float *X, int64_t row_begin, int64_t row_end, int D, const float *center,
+                                                          uint32_t *stat)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = row_begin + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= row_end) return;
+    const float *src = X + row * (int64_t)D;
+    float r2 = 0.f, n2 = 0.f;
+    for (int i = lane; i < D; i += 64) {
+        const float v = center ? src[i] - center[i] : src[i];
+        const float d = v - (float)(_Float16)v; // (exact: the two are within a factor of two of each other, or the second is 0)
+        r2 = fmaf(d, d, r2);
+        n2 = fmaf(v, v, n2);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        r2 += __shfl_xor(r2, off);
+        n2 += __shfl_xor(n2, off);
+    }
+    if (lane == 0 && n2 > 0.f && r2 > 0.f) {
+        // (f32 sums of D non-negative terms: relative error below (D + 8) 2^-24 each; the ratio is padded for both)
+        const float ratio = (r2 / n2) * (1.0f + 4.0f * (float)(D + 8) * 5.9604645e-8f);
+        atomicMax(stat, __builtin_bit_cast(uint32_t, ratio)); // (non-negative floats order as their bits; NaN / inf end up on top: the caller checks)
+    }
+}
+
 } // namespace
+
+void launch_f16_residual(const float *X, int64_t row_begin, int64_t row_end, int D, const float *center, uint32_t *stat, hipStream_t s)
+{
+    if (row_end <= row_begin) return;
+    hipLaunchKernelGGL(f16_residual_kernel, dim3((unsigned)((row_end - row_begin + 3) / 4)), dim3(256), 0, s, X, row_begin, row_end, D, center, stat);
+}
 
 #ifdef LB_DIAG
 void read_tall16_probe(unsigned long long out[8], bool reset)

@@ -461,6 +461,8 @@ struct SampleArgs {
     float *qinv = nullptr, *qnrm = nullptr;
     const float *pcenter = nullptr;
     int tau_zero = 0; // the riding preparation leaves tau = 0 ("not out yet") for a candidate launch that computes its own
+    float *qrho = nullptr;
+    float rho_gain = 0.f;
 };
 
 __device__ __forceinline__ float wave_sum(float v)
@@ -497,7 +499,8 @@ __device__ __forceinline__ float exact_sq_norm_lds(const float *sq, int D)
 // the other two itself, from another workgroup), 0 = nothing.  active: this thread belongs to the ONE wave that does the work
 // (every thread of the workgroup makes the call: there is a barrier inside).
 __device__ __forceinline__ void query_prep_body(const float *Q, int nq, int D, _Float16 *Qh, float *qinv, float *qna, int order, CandState cs,
-                                                const float *center, float *qnrm, int reset, int q, int lane, bool active, float *sq)
+                                                const float *center, float *qnrm, int reset, int q, int lane, bool active, float *sq,
+                                                float *qrho = nullptr, float rho_gain = 0.f)
 {
     const float *src = Q + (int64_t)q * D;
     const int Dpad = (D + 3) & ~3;
@@ -524,11 +527,26 @@ __device__ __forceinline__ void query_prep_body(const float *Q, int nq, int D, _
     __syncthreads();
     if (!active) return;
     const int Dp = (D + 31) & ~31; // (dimensions beyond D: zero -- they add nothing to a product)
-    for (int i = lane; i < Dp; i += 64) Qh[((int64_t)(i >> 5) * nq + q) * 32 + (i & 31)] = i < D ? (_Float16)(sq[i] * scale) : (_Float16)0.f;
+    float r2 = 0.f; // |scaled q - its fp16 image|^2 (the scaling is a power of two: the ratio to |q|^2 is the unscaled one)
+    for (int i = lane; i < Dp; i += 64) {
+        const float v = i < D ? sq[i] * scale : 0.f;
+        const _Float16 hv = (_Float16)v;
+        Qh[((int64_t)(i >> 5) * nq + q) * 32 + (i & 31)] = hv;
+        const float d = v - (float)hv;
+        r2 = fmaf(d, d, r2);
+    }
+    if (qrho) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) r2 += __shfl_xor(r2, off);
+    }
     if (lane == 0) {
         qinv[q] = inv;
+        // (f32 sums of D non-negative terms: relative error below (D + 8) 2^-24 each)
+        const float s2 = s * scale * scale;
+        const float rho = (s2 > 0.f && s2 < 3.0e38f) ? sqrtf((r2 / s2) * (1.0f + 4.0f * (float)(D + 8) * 5.9604645e-8f)) * 1.000001f : 1.0f;
+        if (qrho) qrho[q] = rho;
         // (s is an f32 sum in some order: relative error below (D + 8) 2^-24)
-        if (qnrm) qnrm[q] = (s < 3.0e38f) ? sqrtf(s) * (1.000002f + 1.05f * (float)(D + 8) * 5.9604645e-8f) : s;
+        if (qnrm) qnrm[q] = ((s < 3.0e38f) ? sqrtf(s) * (1.000002f + 1.05f * (float)(D + 8) * 5.9604645e-8f) : s) * (1.0f + rho_gain * rho);
         if (reset == 1) {
             cs.cnt[q] = 0;
             cs.tau[q] = kEntryMax;
@@ -540,19 +558,19 @@ __device__ __forceinline__ void query_prep_body(const float *Q, int nq, int D, _
 }
 
 __global__ __launch_bounds__(64) void query_prep_kernel(const float *Q, int nq, int D, _Float16 *Qh, float *qinv, float *qna, int order,
-                                                        CandState cs, const float *center, float *qnrm, int tau_zero)
+                                                        CandState cs, const float *center, float *qnrm, int tau_zero, float *qrho, float rho_gain)
 {
     extern __shared__ __attribute__((aligned(16))) float sq[];
-    query_prep_body(Q, nq, D, Qh, qinv, qna, order, cs, center, qnrm, 1, (int)blockIdx.x, (int)threadIdx.x, true, sq);
+    query_prep_body(Q, nq, D, Qh, qinv, qna, order, cs, center, qnrm, 1, (int)blockIdx.x, (int)threadIdx.x, true, sq, qrho, rho_gain);
     if (tau_zero && threadIdx.x == 0) cs.tau[blockIdx.x] = 0ull; // "not out yet" (TAUIN)
 }
 
 void launch_query_prep(const float *Q, int nq, int D, void *Qh, float *qinv, float *qna, int order, CandState cs, hipStream_t s,
-                       const float *center, float *qnrm, bool tau_zero)
+                       const float *center, float *qnrm, bool tau_zero, float *qrho, float rho_gain)
 {
     if (nq <= 0) return;
     hipLaunchKernelGGL(query_prep_kernel, dim3((unsigned)nq), dim3(64), (size_t)((D + 3) & ~3) * sizeof(float), s, Q, nq, D,
-                       reinterpret_cast<_Float16 *>(Qh), qinv, center ? nullptr : qna, order, cs, center, qnrm, tau_zero ? 1 : 0);
+                       reinterpret_cast<_Float16 *>(Qh), qinv, center ? nullptr : qna, order, cs, center, qnrm, tau_zero ? 1 : 0, qrho, rho_gain);
 }
 
 // R = sampled rows per wave: every query chunk fetched from L2 is used for R rows (with 32 query
@@ -714,7 +732,7 @@ __global__ __launch_bounds__(256) void sample_scores_kernel(SampleArgs a)
     const uint32_t nprep = a.Qh ? (uint32_t)a.nsel : 0u;
     if (blockIdx.x < nnorm + nprep) { // (no query subset on this route: slot j is query j)
         query_prep_body(a.Q, a.nsel, a.D, a.Qh, a.qinv, nullptr, a.order, a.cs, a.pcenter, a.qnrm, /*reset=*/a.tau_zero ? 3 : 0,
-                        (int)(blockIdx.x - nnorm), lane, wave == 0, sq);
+                        (int)(blockIdx.x - nnorm), lane, wave == 0, sq, a.qrho, a.rho_gain);
         return;
     }
     const uint32_t blk = blockIdx.x - nnorm - nprep;
@@ -737,6 +755,8 @@ void launch_sample_scores(int metric, int order, const float *X, int D, int64_t 
         a.qnrm = prep->qnrm;
         a.pcenter = prep->center;
         a.tau_zero = prep->tau_zero ? 1 : 0;
+        a.qrho = prep->qrho;
+        a.rho_gain = prep->rho_gain;
     }
     a.center = (norm2 != nullptr && metric == METRIC_L2) ? center : nullptr;
     a.keys = norm2 != nullptr ? 1 : 0;

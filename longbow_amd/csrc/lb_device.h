@@ -242,7 +242,9 @@ bool tall16_tin_ok(int D, int nq, int64_t n_pos, bool img, bool mapped, bool mas
 void launch_query_prep(const float *Q, int nq, int D, void *Qh, float *qinv, float *qna, int order, CandState cs, hipStream_t s,
                        const float *center = nullptr, // center: the image of q - center (L2 over the centred corpus image)
                        float *qnrm = nullptr,         // [nq] upper bounds of |q| (the dot product's lower-bound key)
-                       bool tau_zero = false);        // thresholds left at 0 = "not out yet" (a TAUIN candidate launch follows)
+                       bool tau_zero = false,         // thresholds left at 0 = "not out yet" (a TAUIN candidate launch follows)
+                       float *qrho = nullptr,         // [nq] |q - fp16 image of q| / |q|, padded: the query's share of the keys' error bound
+                       float rho_gain = 0.f);         // qnrm[q] *= 1 + rho_gain * qrho[q] (dot product: folds that share into G)
 // Xh (or null): the corpus's K-blocked fp16 image [Dp / 32][xh_cap][32] from launch_corpus_to_f16, in step with X; used by
 // unfiltered searches (half the bytes to stage, a four-stage ring)
 void launch_gemm_filter_tall16(int metric, const float *X, const float *norm2, const float *rnorm, int64_t row_begin,
@@ -256,6 +258,9 @@ void launch_gemm_filter_tall16(int metric, const float *X, const float *norm2, c
                                const struct Tall16Tin *tin = nullptr); // thresholds inside the launch (tall16_tin_ok)
 void launch_corpus_to_f16(const float *X, int64_t row_begin, int64_t row_end, int D, void *Xh, int64_t cap, hipStream_t s,
                           const float *center = nullptr); // center (or null; [>= D + 8]): the image holds fp16(x - center)
+// *stat = max(*stat, max over the rows of |x - fp16(x)|^2 / |x|^2) as float bits (x - center for the centred image): the
+// measured loss of the image, from which the candidate keys' error bound is taken (index.hip: gamma)
+void launch_f16_residual(const float *X, int64_t row_begin, int64_t row_end, int D, const float *center, uint32_t *stat, hipStream_t s);
 int corpus_f16_plane_dims(); // dimensions per plane of that image (its rows are zero-padded to a multiple of it)
 // under a row list (mapped) the persistent kernels gather out of the image and leave POSITIONS of the list in the candidate
 // entries (the finish launch maps them back: posmap); true when a launch with these parameters does so
@@ -291,6 +296,8 @@ struct SamplePrep {
     float *qinv, *qnrm;
     const float *center;
     bool tau_zero; // leave tau = 0 ("not out yet": a TAUIN candidate launch follows)
+    float *qrho;   // as launch_query_prep
+    float rho_gain;
 };
 void launch_sample_scores(int metric, int order, const float *X, int D, int64_t span, uint32_t count,
                           const uint32_t *rowmap, const uint8_t *mask, const float *Q, const int *qsel, int nsel,
@@ -317,7 +324,8 @@ void launch_finish(int metric, int order, const float *X, int D, const float *Q,
                    int64_t *out_labels, hipStream_t s, uint32_t *flags_host, uint32_t *done, uint32_t *xcnt, void *xscratch,
                    int nq_split_max, uint32_t smax,
                    const float *center = nullptr, // L2 keys taken about this centre: d_maxnorm2 = the centred maximum norm
-                   const float *lb_norm2 = nullptr, const float *lb_qnrm = nullptr, float lb_gsum = 0.f); // dot: lower-bound keys
+                   const float *lb_norm2 = nullptr, const float *lb_qnrm = nullptr, float lb_gsum = 0.f, // dot: lower-bound keys
+                   const float *qrho = nullptr, float qrho_k = 0.f); // gamma(q) = gamma + qrho_k * qrho[q] (launch_query_prep)
 
 // ||q||^2 per selected query slot in the requested accumulation order (cosine).
 void launch_query_norms(int order, const float *Q, const int *qsel, int nsel, int D, float *qna,
