@@ -927,7 +927,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
                                 ((have_xh && granule_on && nq > light_max) || dot_lb || (centred && nq > light_max));
     const bool light_sample = sp.on && !fused && !granule_sample && nq <= light_max;
     // Up to 128 queries on the one-tile kernel over the image, one span: the candidate launch turns the sample into the
-    // thresholds ITSELF (its last nq workgroups, on shorter row ranges; kernels_gemm_tall16.hip, TAUIN) -- no threshold launch
+    // thresholds ITSELF (its first nq workgroups, on shorter row ranges; kernels_gemm_tall16.hip, TAUIN) -- no threshold launch
     // and no gap behind it in front of the pass.
     static const bool tauin_on = lb_tunable("LB_TAUIN", 1) != 0;
     const bool tauin = tauin_on && sp.on && sp.span >= n && use_tall16 && route.kind == ROUTE_NARROW16 && !fused &&

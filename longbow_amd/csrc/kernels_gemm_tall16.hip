@@ -957,16 +957,19 @@ static bool tin_plan(int D, int nq, int64_t n_pos, int ng, bool with_norm, uint3
     return (n_pos + (int64_t)nq * dr) / ng >= (int64_t)dr + 256;
 }
 
-// TAUIN: the last nd workgroups of the launch have a duty in front of their rows (a threshold each: ~5 us + an exact norm);
+// TAUIN: the FIRST nd workgroups of the launch have a duty in front of their rows (a threshold each: ~5 us + an exact norm);
 // their ranges are dr positions shorter than the others', so that everybody ends together.  The ranges are h_range's over
-// V = n_pos + nd dr "virtual" positions, dr of which at the head of every duty workgroup's range are its duty.
+// V = n_pos + nd dr "virtual" positions, dr of which at the head of every duty workgroup's range are its duty.  (The first,
+// not the last: workgroups are dispatched in index order, so whenever any workgroup of the launch runs, the duty workgroups
+// have been dispatched before it and depend on nobody -- a launch that shares the GPU with another persistent launch and is
+// only partly resident still gets its thresholds.)
 __device__ __forceinline__ void h_range_duty(uint32_t n_pos, int gi, int ng, int nd, uint32_t dr, uint32_t &lo, uint32_t &hi)
 {
     const uint32_t V = n_pos + (uint32_t)nd * dr, q = V / (uint32_t)ng, r = V % (uint32_t)ng;
     auto bound = [&](int i) { // first real position of workgroup i
         const uint32_t v = q * (uint32_t)i + (r * (uint32_t)i) / (uint32_t)ng;
-        const int jd = i - (ng - nd); // duty workgroups in front of it
-        return (v - (jd > 0 ? (uint32_t)jd * dr : 0u)) & ~15u;
+        const int jd = i < nd ? i : nd; // duty workgroups in front of it
+        return (v - (uint32_t)jd * dr) & ~15u;
     };
     lo = bound(gi);
     hi = gi + 1 < ng ? bound(gi + 1) : n_pos;
@@ -974,7 +977,7 @@ __device__ __forceinline__ void h_range_duty(uint32_t n_pos, int gi, int ng, int
     hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)hi);
 }
 
-// The duty of workgroup ng - 1 - j of a TAUIN launch: tau[j] = the m-th smallest key of the sample entries
+// The duty of workgroup j < nq of a TAUIN launch: tau[j] = the m-th smallest key of the sample entries
 // lists[j][0 .. count) with the row bits saturated (kernels_scan.hip: sample_tau_body, here on 512 threads with 16 keys
 // each), cnt[j] = 0, the exact ||q_j||^2 (cosine).  `scratch`: LDS nobody uses
 // before the first epilogue (>= 1 KB + a query row).
@@ -1090,7 +1093,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
     uint32_t lo, hi; // this workgroup's positions
     if (TAUIN) {
         h_range_duty((uint32_t)(a.row_end - a.row_begin), (int)blockIdx.x, (int)gridDim.x, a.nq, a.tin_dr, lo, hi);
-        if ((int)blockIdx.x >= (int)gridDim.x - a.nq) tin_duty(a, (int)gridDim.x - 1 - (int)blockIdx.x, hlds);
+        if ((int)blockIdx.x < a.nq) tin_duty(a, (int)blockIdx.x, hlds);
     } else {
         h_range((uint32_t)(a.row_end - a.row_begin), (int)blockIdx.x, (int)gridDim.x, lo, hi);
     }
@@ -1315,7 +1318,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
-        if (TAUIN && i == 0) { // the thresholds, published meanwhile by the launch's last nq workgroups
+        if (TAUIN && i == 0) { // the thresholds, published meanwhile by the launch's first nq workgroups
             // Every wave reads ITS queries' thresholds with device-coherent vector loads (each drains the wave's part of the DMA
             // ring once); a threshold of 0 is "not out yet" (the launch before left them so; a genuine one ends in 32 one-bits).
             // Usually the first look finds them all: the duty takes ~6 us, the first epilogue comes ~16 us into the launch.

@@ -222,7 +222,7 @@ void launch_gemm_filter_tall2(int metric, const float *X, const float *norm2, co
 // (fp16 image of the batch, each query scaled by a power of two to a norm in [1, 2); qinv = 1 / scale); X = f32 corpus
 void launch_queries_to_f16(const float *Q, int nq, int D, void *Qh, float *qinv, hipStream_t s);
 // The one-tile persistent kernel over the image (<= 128 queries) can turn the sample the launch before it left in
-// lists[q][0 .. count) into the thresholds ITSELF (its last nq workgroups do, on shorter row ranges; everybody picks the
+// lists[q][0 .. count) into the thresholds ITSELF (its first nq workgroups do, on shorter row ranges; everybody picks the
 // thresholds up in front of its first epilogue): no threshold launch, no gap behind it.  The launch before must leave
 // tau[q] = 0 ("not out yet": launch_query_prep / SamplePrep, tau_zero); a bounded wait that gives up stores `tag` to the
 // pinned fail_host and admits nothing (the host redoes the batch).  Q / qna / order: the duty workgroups also compute the

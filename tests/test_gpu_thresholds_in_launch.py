@@ -1,5 +1,5 @@
 """Searches of 1 .. 128 queries over the fp16 image whose candidate launch computes its own thresholds (kernels_gemm_tall16.hip,
-TAUIN: the last nq workgroups turn the sample into tau, everybody picks it up in front of its first epilogue): every batch
+TAUIN: the first nq workgroups turn the sample into tau, everybody picks it up in front of its first epilogue): every batch
 size around the kernel's tile limits, all three metrics, unfiltered and over a row list, against the oracle (reference
 semantics: BruteForceIndex.SearchVectors, internal/store/adaptive_index.go:159-230) and against the same queries searched one
 by one.  300k x 256 is large enough for the launch to take that form in the library's default mode (tall16_tin_ok)."""
@@ -39,4 +39,42 @@ def test_batches_whose_candidate_launch_computes_its_thresholds(oracle, metric):
             lab, dist = idx.SearchBatch(Q[:nq], k)
             assert_same(lab, dist, whole[0][:nq], whole[1][:nq], f"metric {metric} filtered {filtered} nq {nq} route {idx.last_route}")
             assert idx.last_fallbacks == 0, (metric, filtered, nq, idx.last_fallbacks)
+    idx.Close()
+
+
+def test_searches_side_by_side_get_their_thresholds_without_giving_up(oracle):
+    """Four callers with combining off: their candidate launches (one persistent workgroup per CU each) share the GPU, so a
+    launch may be only partly resident while it waits for its thresholds.  The duty workgroups are the launch's FIRST ones --
+    dispatched before any other -- so nobody waits for a workgroup that cannot start: no give-ups, and every list is the one
+    the query gets alone."""
+    import threading
+    gpu_or_skip()
+    rng = np.random.default_rng(5)
+    n, d, k = 300_000, 256, 10
+    X = rng.standard_normal((n, d)).astype(F)
+    Q = np.ascontiguousarray(X[rng.integers(0, n, 32)] + rng.standard_normal((32, d)).astype(F) * F(0.3))
+    idx = new_index(d, 1)
+    idx.Add(None, X)
+    want = [idx.Search(Q[i], k) for i in range(32)]
+    oi, od = oracle.search_batch(1, Q[:4], X, k, nthreads=8)
+    for i in range(4):
+        assert_same(want[i][0], want[i][1], oi[i], od[i], f"query {i} alone vs oracle")
+    idx.set_search_combining(False)
+    errors = []
+
+    def caller(t):
+        try:
+            for rep in range(40):
+                for i in range(t, 32, 4):
+                    lab, dist = idx.Search(Q[i], k)
+                    if not (np.array_equal(lab, want[i][0]) and np.array_equal(dist, want[i][1])):
+                        errors.append(f"thread {t} query {i} rep {rep}: differs from the search on its own")
+        except Exception as e:  # noqa: BLE001
+            errors.append(f"thread {t}: {type(e).__name__}: {e}")
+
+    ths = [threading.Thread(target=caller, args=(t,)) for t in range(4)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errors, errors[:5]
+    assert idx.fused_giveups == 0, idx.fused_giveups
     idx.Close()
