@@ -1642,12 +1642,14 @@ static void tall16_window(int metric, const float *X, const float *norm2, const 
         // A batch that ends 1 .. 64 queries into a 256-query tile: the whole tiles on the 256-wide kernel, the rest on the
         // one-tile kernel (a second pass over the image at its HBM rate, 0.24 ms per 1M x 768, instead of one more 256-wide
         // query tile that is mostly padding: 0.38 ms beside the others).  1M x 768: 257 queries 1.13 -> 0.98 ms, 320: 1.00 ->
-        // 0.91, 640: 1.59 -> 1.53; a tail of 65 .. 128 on the 128-query tile measured level (384, 896) and is not split.
+        // 0.91, 640: 1.59 -> 1.53; a tail of 65 .. 128 goes to the 128-query tile (round 4: 352 queries 1.00 -> 0.95 ms, 384:
+        // 0.90 -> 0.85, 640: 1.39 -> 1.34, 896 level).
         // Each launch sees its own window of the batch: the image, the scales and the candidate state from its first query
         // on; q_stride stays the batch's.
         const int tail = nq % H_BN;
         static const int split_tail = lb_tunable("LB_F16_SPLIT_TAIL", 1);
-        if (img && may_split && split_tail && nq > H_BN && tail >= 1 && tail <= 64) {
+        static const int split_tail_max = lb_tunable("LB_F16_SPLIT_TAIL_MAX", 128); // (65 .. 128 on the 128-query tile: 384 queries 0.90 -> 0.85 ms, 640: 1.39 -> 1.34)
+        if (img && may_split && split_tail && nq > H_BN && tail >= 1 && tail <= split_tail_max) {
             const int head = nq - tail;
             tall16_window(metric, X, norm2, rnorm, row_begin, row_end, D, Qh, qinv, head, q_stride, mask, rowmap, cs, boot, s, Xh,
                           xh_cap, false, gstride, qnrm, gsum);

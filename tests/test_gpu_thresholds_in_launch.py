@@ -78,3 +78,27 @@ def test_searches_side_by_side_get_their_thresholds_without_giving_up(oracle):
     assert not errors, errors[:5]
     assert idx.fused_giveups == 0, idx.fused_giveups
     idx.Close()
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_batches_that_end_65_to_128_queries_into_a_256_query_tile(oracle, metric):
+    """such a batch runs its whole 256-query tiles on the 256-wide kernel and the rest on the 128-query one (a second pass over
+    the image; kernels_gemm_tall16.hip, tall16_window): the lists must be the ones the queries get in any other grouping"""
+    gpu_or_skip()
+    rng = np.random.default_rng(300 + metric)
+    n, d, k = 300_000, 128, 10
+    X = rng.standard_normal((n, d)).astype(F)
+    Q = np.ascontiguousarray(X[rng.integers(0, n, 384)] + rng.standard_normal((384, d)).astype(F) * F(0.3))
+    idx = new_index(d, metric)
+    idx.Add(None, X)
+    whole = idx.SearchBatch(Q, k)                      # 256 + 128
+    assert idx.last_fallbacks == 0
+    oi, od = oracle.search_batch(metric, Q[250:262], X, k, nthreads=8)
+    assert_same(whole[0][250:262], whole[1][250:262], oi, od, f"metric {metric} nq 384 route {idx.last_route}")
+    for nq in (321, 352, 383):                         # 256 + 65 / 96 / 127
+        lab, dist = idx.SearchBatch(Q[:nq], k)
+        assert_same(lab, dist, whole[0][:nq], whole[1][:nq], f"metric {metric} nq {nq} route {idx.last_route}")
+    a = idx.SearchBatch(Q[:256], k)
+    b = idx.SearchBatch(Q[256:], k)
+    assert_same(np.concatenate([a[0], b[0]]), np.concatenate([a[1], b[1]]), whole[0], whole[1], f"metric {metric} 256 | 128")
+    idx.Close()
