@@ -506,10 +506,26 @@ __device__ __forceinline__ void query_prep_body(const float *Q, int nq, int D, _
     const int Dpad = (D + 3) & ~3;
     float s = 0.f;
     if (active) {
-        for (int i = lane; i < Dpad; i += 64) {
-            const float v = i < D ? (center ? src[i] - center[i] : src[i]) : 0.f;
-            sq[i] = v;
-            s += v * v;
+        // (eight pieces of the row asked for before the first is used: one memory round trip per 512 dimensions instead of
+        // one per 64; the sums run in the same order as before)
+        constexpr int PF = 8;
+        for (int i0 = lane; i0 < Dpad; i0 += 64 * PF) {
+            float v[PF], c[PF];
+#pragma unroll
+            for (int u = 0; u < PF; u++) {
+                const int i = i0 + 64 * u;
+                v[u] = i < D ? src[i] : 0.f;
+                c[u] = (center && i < D) ? center[i] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < PF; u++) {
+                const int i = i0 + 64 * u;
+                if (i < Dpad) {
+                    const float x = v[u] - c[u]; // (x - 0 = x exactly)
+                    sq[i] = x;
+                    s += x * x;
+                }
+            }
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
@@ -856,21 +872,21 @@ __global__ __launch_bounds__(ST_THREADS) void sample_tau_kernel(CandState cs, co
     extern __shared__ __attribute__((aligned(16))) float sq[];
     __shared__ uint32_t wl[ST_THREADS / 64][20]; // (m <= 64: r1 <= 20)
     const int tid = threadIdx.x;
-    if ((int)blockIdx.x >= nsel) { // optional riders (qna != null): exact ||q||^2 of slot blockIdx.x - nsel
-        const int j = (int)blockIdx.x - nsel;
-        const float *q = Q + (int64_t)(qsel ? qsel[j] : j) * D;
-        const int Dpad = (D + 3) & ~3;
-        for (int i = tid; i < Dpad; i += ST_THREADS) sq[i] = i < D ? q[i] : 0.f;
-        __syncthreads();
-        if (tid == 0) qna[j] = order == ORDER_UNROLL4 ? exact_sq_norm_lds<ORDER_UNROLL4>(sq, D) : exact_sq_norm_lds<ORDER_SEQ>(sq, D);
-        return;
-    }
     const int q = qsel ? qsel[blockIdx.x] : blockIdx.x;
+    // qna != null (cosine): the exact ||q||^2 of this query rides along -- its D dependent additions (3.5 us at 768) are done by
+    // one lane of wave 1 while wave 0 merges the runs; the row is staged here, the selection's barrier publishes it.  (Rider
+    // workgroups of their own doubled the launch's workgroups: 1024 queries 25 -> 15 us.)
+    if (qna) {
+        const float *qr = Q + (int64_t)q * D;
+        const int Dpad = (D + 3) & ~3;
+        for (int i = tid; i < Dpad; i += ST_THREADS) sq[i] = i < D ? qr[i] : 0.f;
+    }
     const uint64_t kth = sample_tau_body(cs.lists + (size_t)q * cs.cap, count, m, wl, tid);
     if (tid == 0) {
         cs.tau[q] = kth;
         cs.cnt[q] = 0;
     }
+    if (qna && tid == 64) qna[blockIdx.x] = order == ORDER_UNROLL4 ? exact_sq_norm_lds<ORDER_UNROLL4>(sq, D) : exact_sq_norm_lds<ORDER_SEQ>(sq, D);
     if (zero_stripes && tid < LB_STRIPES) cs.stripes[(blockIdx.x * LB_STRIPES + tid) * LB_STRIPE_PAD] = 0;
 }
 
@@ -932,7 +948,7 @@ void launch_sample_tau(CandState cs, const int *qsel, int nsel, uint32_t count, 
 {
     if (nsel <= 0) return;
     const size_t shmem = qna ? (size_t)((D + 3) & ~3) * sizeof(float) : 0;
-    hipLaunchKernelGGL(sample_tau_kernel, dim3(qna ? 2 * nsel : nsel), dim3(ST_THREADS), shmem, s, cs, qsel, nsel, count,
+    hipLaunchKernelGGL(sample_tau_kernel, dim3(nsel), dim3(ST_THREADS), shmem, s, cs, qsel, nsel, count,
                        m, (zero_stripes && cs.stripes != nullptr) ? 1 : 0, Q, D, qna, order);
 }
 
