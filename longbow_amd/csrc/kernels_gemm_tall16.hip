@@ -1340,7 +1340,9 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
                 ok = __builtin_amdgcn_ballot_w64(!all) == 0ull;
                 if (!ok) __builtin_amdgcn_s_sleep(8);
             }
-            if (!ok && tid == 0) *a.tin_fail = a.tin_tag; // (gave up: nothing is admitted, the host redoes the batch)
+            // (gave up: this WAVE admits nothing -- whichever wave it is must say so, the proof behind the pass relies on every
+            // row below the threshold having been admitted -- and the host redoes the batch)
+            if (!ok && lane == 0) *a.tin_fail = a.tin_tag;
 #pragma unroll
             for (int tn = 0; tn < TN; tn++) {
                 const int qj = tn * 32 + l31;
