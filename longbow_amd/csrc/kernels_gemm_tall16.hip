@@ -1052,6 +1052,9 @@ __device__ __forceinline__ void tin_duty(const Tall16Args &a, int j, unsigned ch
             // (the asm wait stays beside the fence: ROCm 7.2 can drop the fence's own vmcnt wait, MI355X_MICROARCH.md)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef LB_DIAG
+            if (a.abl != 12) // (12: the threshold never comes out -- every wave's wait gives up; tests/test_gpu_thresholds_in_launch.py)
+#endif
             __hip_atomic_store(&a.cs.tau[j], tv, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             if (a.tin_qna) { // D dependent additions in the reference's order (nothing waits for them but this workgroup's rows)
 #pragma clang fp contract(off)

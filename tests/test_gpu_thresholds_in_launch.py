@@ -102,3 +102,30 @@ def test_batches_that_end_65_to_128_queries_into_a_256_query_tile(oracle, metric
     b = idx.SearchBatch(Q[256:], k)
     assert_same(np.concatenate([a[0], b[0]]), np.concatenate([a[1], b[1]]), whole[0], whole[1], f"metric {metric} 256 | 128")
     idx.Close()
+
+
+def test_a_wait_for_the_thresholds_that_gives_up_is_reported_and_the_batch_redone(oracle, monkeypatch):
+    """diagnostic build, LB_F16_ABL=12: the duty workgroups never publish their thresholds, every wave's bounded wait (~1 ms)
+    gives up, admits nothing and says so through the pinned word; the host redoes the batch on the exact path -- the lists
+    are still the oracle's, and the give-up is counted."""
+    from tests.gpu_util import diag_lib
+    lib = diag_lib()
+    rng = np.random.default_rng(12)
+    n, d, k = 300_000, 256, 10
+    X = rng.standard_normal((n, d)).astype(F)
+    Q = np.ascontiguousarray(X[rng.integers(0, n, 8)] + rng.standard_normal((8, d)).astype(F) * F(0.3))
+    idx = new_index(d, 1, lib=lib)
+    idx.Add(None, X)
+    oi, od = oracle.search_batch(1, Q, X, k, nthreads=8)
+    lab, dist = idx.SearchBatch(Q[:6], k)
+    assert_same(lab, dist, oi[:6], od[:6], "before")
+    assert idx.fused_giveups == 0 and idx.last_fallbacks == 0
+    monkeypatch.setenv("LB_F16_ABL", "12")
+    lab, dist = idx.SearchBatch(Q[:6], k)
+    monkeypatch.delenv("LB_F16_ABL")
+    assert_same(lab, dist, oi[:6], od[:6], "wait gave up")
+    assert idx.fused_giveups == 1 and idx.last_fallbacks == 6, (idx.fused_giveups, idx.last_fallbacks)
+    lab, dist = idx.SearchBatch(Q, k)
+    assert_same(lab, dist, oi, od, "after")
+    assert idx.fused_giveups == 1 and idx.last_fallbacks == 0
+    idx.Close()
