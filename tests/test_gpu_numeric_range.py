@@ -133,3 +133,32 @@ def test_dot_product_with_a_few_very_long_rows_stays_on_the_matrix_cores(oracle)
         assert_same(lab[:m], dist[:m], oi[:m], od[:m], f"long rows, forced fp16, nq {nq}")
         assert idx.last_fallbacks <= max(1, nq // 100), (nq, idx.last_fallbacks)
     idx.Close()
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_rounding_errors_that_all_point_the_same_way(oracle, metric):
+    """Every element of the corpus and of the queries sits just above a midpoint between two fp16 values, all positive: the image
+    rounds every element UP by half an ulp, so the candidate keys' errors add coherently instead of cancelling -- the worst case
+    for an error bound taken from the measured residual NORMS (search_batch_device: gamma(q) = ... rho_x ... rho_q).  The lists
+    must still be the oracle's; a bound that were only statistical would lose neighbours here."""
+    gpu_or_skip()
+    rng = np.random.default_rng(400 + metric)
+    n, d, k = 270_000, 64, 10
+
+    def above_midpoints(shape):
+        m = rng.integers(1024, 2048, shape).astype(np.float64)          # 11-bit significands of fp16 values in [1, 2)
+        return ((m + 0.5 + 1.0 / 64.0) * 2.0 ** -10).astype(F)            # just above the midpoint to the next one
+
+    X = np.ascontiguousarray(above_midpoints((n, d)))
+    Q = np.ascontiguousarray(above_midpoints((64, d)))
+    assert np.all(X.astype(np.float16).astype(F) > X)                      # (the image rounds every element up)
+    idx = new_index(d, metric)
+    idx.Add(None, X)
+    oi, od = oracle.search_batch(metric, Q[:8], X, k, nthreads=8)
+    for mode in (3, 4):
+        idx.set_candidate_mode(mode)
+        for nq in (4, 8, 64):
+            lab, dist = idx.SearchBatch(Q[:nq], k)
+            m8 = min(nq, 8)
+            assert_same(lab[:m8], dist[:m8], oi[:m8], od[:m8], f"metric {metric} mode {mode} nq {nq} route {idx.last_route}")
+    idx.Close()
