@@ -27,7 +27,7 @@
 
 using namespace lb;
 
-namespace lb { extern int g_adc_ablation; extern int g_gemm_ablation; extern int g_gemm_glds; void read_clock_probe(unsigned long long out[8], bool reset); int debug_gemm_occupancy(); void read_fused_probe(unsigned long long out[8], bool reset); void read_tall2_probe(unsigned long long out[8], bool reset); void read_tall16_probe(unsigned long long out[8], bool reset); }
+namespace lb { extern int g_adc_ablation; extern int g_gemm_ablation; extern int g_gemm_glds; void read_clock_probe(unsigned long long out[8], bool reset); int debug_gemm_occupancy(); void read_fused_probe(unsigned long long out[8], bool reset); void read_tall2_probe(unsigned long long out[8], bool reset); void read_tall16_probe(unsigned long long out[8], bool reset); void read_finish_probe(unsigned long long out[8], bool reset); }
 
 namespace {
 
@@ -2202,6 +2202,7 @@ void lb_debug_read_clock_probe(unsigned long long *out, int reset) { lb::read_cl
 void lb_debug_read_fused_probe(unsigned long long *out, int reset) { lb::read_fused_probe(out, reset != 0); }
 void lb_debug_read_tall2_probe(unsigned long long *out, int reset) { lb::read_tall2_probe(out, reset != 0); }
 void lb_debug_read_tall16_probe(unsigned long long *out, int reset) { lb::read_tall16_probe(out, reset != 0); }
+void lb_debug_read_finish_probe(unsigned long long *out, int reset) { lb::read_finish_probe(out, reset != 0); }
 #endif
 
 // ---- candidate re-rank (processChunkInternal) ------------------------------------------

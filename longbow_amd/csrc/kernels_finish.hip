@@ -38,6 +38,30 @@ constexpr int FN_THREADS = 256;
 constexpr int FN_R16 = 16, FN_SD = 1024, FN_LD16 = FN_SD + 4; // SPLIT: 16 rows x up to 1024 dims per stage
 constexpr int FN_DK = 32, FN_LDT = FN_DK + 4;                 // tiled: 256 rows x 32 dims per stage (one 128-B line per row)
 
+#ifdef LB_DIAG
+__device__ unsigned long long g_finish_probe[8]; // [0] members summed over queries, [1] queries, [2] list entries summed, [3] largest member count
+#endif
+
+// four LDS-DMA requests of 1 KiB behind one M0 write: the instruction offset moves the LDS destination and the global address
+// alike (the caller pre-compensates the sources), as in the candidate kernels
+__device__ __forceinline__ void fn_dma16x4(const void *g0, const void *g1, const void *g2, const void *g3, uint32_t lds_addr)
+{
+    uint32_t save;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\t"
+                 "global_load_lds_dwordx4 %2, off offset:1024\n\t"
+                 "global_load_lds_dwordx4 %3, off offset:2048\n\t"
+                 "global_load_lds_dwordx4 %4, off offset:3072\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(save) : "v"(g0), "v"(g1), "v"(g2), "v"(g3), "s"(lds_addr) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void fn_wait_vmcnt()
+{
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+    asm volatile("" ::: "memory");
+}
+
 struct FinishArgs {
     const float *X;
     int D;
@@ -62,6 +86,8 @@ struct FinishArgs {
     uint32_t *flags_host;
     uint32_t smax;    // members a query may have (power of two)
     int aligned;      // D % 4 == 0 and 16-B aligned rows / queries
+    int nst;          // tiled form: stages of the row ring (2 .. 4, what the LDS beside the member arrays allows); 0 = the
+                      // register-staged tile (several workgroups per CU)
     // SPLIT form
     uint32_t *done;   // [nq] arrival tickets (zero between launches)
     uint32_t *xcnt;   // [nq] members written to the scratch block (zero between launches)
@@ -374,6 +400,14 @@ __global__ __launch_bounds__(FN_THREADS) void finish_kernel(FinishArgs a)
     const uint32_t ns_all = scal[3];
     // every row there is was admitted and is a member: nothing lies outside S
     const bool complete = tau == kEntryMax && ns_all == n && raw <= a.cs.cap && ns_all <= smax;
+#ifdef LB_DIAG
+    if (tid == 0 && g == 0) { // (tools/bench_filtered.py: how many rows a query's finish re-ranks)
+        atomicAdd(&g_finish_probe[0], (unsigned long long)ns_all);
+        atomicAdd(&g_finish_probe[1], 1ull);
+        atomicAdd(&g_finish_probe[2], (unsigned long long)n);
+        atomicMax(&g_finish_probe[3], (unsigned long long)ns_all);
+    }
+#endif
     __syncthreads();
     if (a.posmap) // a filtered view: positions -> corpus rows (ascending, so the (key, position) order is the (key, row) order)
         for (uint32_t c = tid; c < nm; c += FN_THREADS) s_rows[c] = a.posmap[s_rows[c]];
@@ -506,9 +540,11 @@ __global__ __launch_bounds__(FN_THREADS) void finish_kernel(FinishArgs a)
                 scmp[c] = cmp;
             }
         }
-    } else {
-        // 256 members at a time, one per lane; their rows come through LDS in coalesced 128-B pieces (32 dims per stage, the
-        // next stage's loads in flight under the current stage's chains)
+    } else if (a.nst == 0) {
+        // more than one workgroup per CU (beyond 256 queries): 256 members at a time, one per lane, their rows staged through
+        // registers into a padded LDS tile, 32 dims per stage (the next stage's loads in flight under the current stage's
+        // chains) -- 56 KB of LDS, two workgroups to a CU, whose gathers and selections overlap (1024 queries: 152 us against
+        // 177 with the ring below, which takes a CU's LDS for one workgroup)
         float *tile = work;                    // [256][FN_LDT]
         float *sq = tile + FN_THREADS * FN_LDT; // [Dpad]
         const int Dpad = (D + 31) & ~31;
@@ -579,6 +615,112 @@ __global__ __launch_bounds__(FN_THREADS) void finish_kernel(FinishArgs a)
                 scmp[c] = cmp;
             }
         }
+    } else if (nm > 0) {
+        // 256 members at a time, one per lane.  Their rows come in by LDS-DMA, 32 dims (one 128-B line per row) per stage, into a
+        // ring of nst stages of [256 rows][128 B]: nst - 1 stages are in flight while one is walked, and the ring runs on across
+        // the groups of 256 (the stages of all groups are one stream).  The gather is bound by memory latency (one workgroup per
+        // query, a CU to itself up to 256 queries), and loads staged through registers were no way to deepen it: the compiler
+        // waits for vmcnt(0) in front of the LDS writes at the loop header whatever the code says (measured: two register
+        // stages in flight cost what one did).  A DMA request is not tracked by the compiler; the waits here are counted.
+        // Layout: the eight 16-B pieces of row r's line sit at position p ^ (r & 7) -- a lane asks for the piece that belongs
+        // where its request lands, and the walk (lane t = row t, piece after piece) reads conflict-free.
+        // None of this changes a row's sum: every chain runs over its row's elements in the reference's order.
+        const int Dpad = (D + 31) & ~31;
+        float *sq = work;                                                  // [Dpad]
+        unsigned char *ring = reinterpret_cast<unsigned char *>(sq + Dpad); // [nst][256][128 B]
+        const uint32_t ring_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)ring;
+        const int nst = a.nst, dist = nst - 1;
+        for (int i = tid; i < Dpad; i += FN_THREADS) sq[i] = i < D ? q[i] : 0.f;
+        const int nchunks = (D + FN_DK - 1) / FN_DK;
+        const int ngroups = (int)((nm + FN_THREADS - 1) / FN_THREADS);
+        const int total = ngroups * nchunks; // stages
+        // request cursor: chunk rc of group rg into slot rslot.  A wave asks for 64 rows of a stage in eight requests of 8 rows x
+        // 128 B (lane l: row l / 8 of the eight, position l % 8).
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const int lrow = lane >> 3, piece = (lane & 7) ^ (lrow & 7); // (the rows of a request start at a multiple of 8)
+        const unsigned char *rsrc[8];
+        int rg = 0, rc = 0, rslot = 0;
+        auto set_group = [&](int grp) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint32_t c = (uint32_t)grp * FN_THREADS + (uint32_t)((wv * 8 + j) * 8 + lrow);
+                const uint32_t row = s_rows[c < nm ? c : nm - 1]; // (lanes beyond the last member: its row again, never walked)
+                // (the request's instruction offset moves the LDS destination AND the global address: compensated here)
+                rsrc[j] = reinterpret_cast<const unsigned char *>(a.X + (int64_t)row * D) - (j & 3) * 1024;
+            }
+        };
+        auto request = [&]() { // the cursor's stage (beyond the last one: the last one again, into a slot nobody reads)
+            int kx = rc * FN_DK + piece * 4;
+            if (kx > D - 4) kx = D - 4; // pieces past D are never consumed
+            const uint32_t dst = ring_base + (uint32_t)rslot * (FN_THREADS * 128u) + (uint32_t)wv * 8192u;
+            fn_dma16x4(rsrc[0] + kx * 4, rsrc[1] + kx * 4, rsrc[2] + kx * 4, rsrc[3] + kx * 4, dst);
+            fn_dma16x4(rsrc[4] + kx * 4, rsrc[5] + kx * 4, rsrc[6] + kx * 4, rsrc[7] + kx * 4, dst + 4096u);
+            rslot = rslot + 1 == nst ? 0 : rslot + 1;
+            if (rc + 1 < nchunks) rc++;
+            else if (rg + 1 < ngroups) { rg++; rc = 0; set_group(rg); }
+        };
+        __syncthreads(); // s_rows (posmap applied), sq
+        set_group(0);
+        for (int st = 0; st < dist; st++) request();
+        AccR<ORDER> acc, nb;
+        acc.zero();
+        nb.zero();
+        int cslot = 0, cc = 0, cg = 0;
+        for (int sidx = 0; sidx < total; sidx++) {
+            // stage sidx has landed for this wave: at most the dist - 1 younger stages (8 requests each) are out; behind the
+            // barrier it has landed for all, and everybody is done with the stage before -- whose slot the next request takes
+            if (dist >= 3) fn_wait_vmcnt<16>();
+            else if (dist == 2) fn_wait_vmcnt<8>();
+            else fn_wait_vmcnt<0>();
+            __syncthreads();
+            request();
+            const int d0 = cc * FN_DK;
+            const int n4 = (min(D, d0 + FN_DK) - d0) >> 2;
+            const unsigned char *xr = ring + cslot * (FN_THREADS * 128) + tid * 128;
+            auto walk = [&](int gq) {
+                const f32x4 xv = *reinterpret_cast<const f32x4 *>(xr + ((gq ^ (tid & 7)) << 4));
+                const f32x4 qv = *reinterpret_cast<const f32x4 *>(&sq[d0 + gq * 4]);
+                if (METRIC == METRIC_COS) {
+                    nb.template add<0>(xv.x * xv.x);
+                    nb.template add<1>(xv.y * xv.y);
+                    nb.template add<2>(xv.z * xv.z);
+                    nb.template add<3>(xv.w * xv.w);
+                }
+                if (METRIC == METRIC_L2) {
+                    const float e0 = qv.x - xv.x, e1 = qv.y - xv.y, e2 = qv.z - xv.z, e3 = qv.w - xv.w;
+                    acc.template add<0>(e0 * e0);
+                    acc.template add<1>(e1 * e1);
+                    acc.template add<2>(e2 * e2);
+                    acc.template add<3>(e3 * e3);
+                } else {
+                    acc.template add<0>(qv.x * xv.x);
+                    acc.template add<1>(qv.y * xv.y);
+                    acc.template add<2>(qv.z * xv.z);
+                    acc.template add<3>(qv.w * xv.w);
+                }
+            };
+            if (n4 == FN_DK / 4) { // a whole chunk: no guards, so that the eight pieces' LDS reads go out together
+#pragma unroll
+                for (int gq = 0; gq < FN_DK / 4; gq++) walk(gq);
+            } else {
+                for (int gq = 0; gq < n4; gq++) walk(gq);
+            }
+            cslot = cslot + 1 == nst ? 0 : cslot + 1;
+            if (++cc == nchunks) { // the group's rows are complete
+                const uint32_t c = (uint32_t)cg * FN_THREADS + (uint32_t)tid;
+                if (c < nm) {
+                    float dist_, cmp;
+                    exact_values<METRIC>(acc.total(), nb.total(), na, D, dist_, cmp);
+                    skey[c] = pack_entry(dist_, s_rows[c]);
+                    scmp[c] = cmp;
+                }
+                acc.zero();
+                nb.zero();
+                cc = 0;
+                cg++;
+            }
+        }
+        fn_wait_vmcnt<0>(); // the requests beyond the last stage: nothing may land in LDS once the ring is given up
     }
     __syncthreads();
 
@@ -683,6 +825,17 @@ __global__ __launch_bounds__(FN_THREADS) void finish_kernel(FinishArgs a)
 
 } // namespace
 
+#ifdef LB_DIAG
+void read_finish_probe(unsigned long long out[8], bool reset)
+{
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_finish_probe), sizeof(unsigned long long) * 8);
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_finish_probe), z, sizeof(z));
+    }
+}
+#endif
+
 size_t finish_scratch_bytes(int nq_split_max, uint32_t smax) { return (size_t)nq_split_max * smax * 12; }
 
 // smax: members a query may have; the split form serves up to `nq_split_max` queries (scratch xent / xcmp sized for them)
@@ -716,7 +869,21 @@ void launch_finish(int metric, int order, const float *X, int D, const float *Q,
     const bool big = cs.cap > 8192u; // list entries per thread: 32 (cap 8192) or 64 (k > 512: cap 16384)
     const size_t common = (size_t)smax * 16;
     const size_t sh_split = common + ((size_t)FN_R16 * FN_LD16 + FN_SD) * 4;
-    const size_t sh_tiled = common + ((size_t)FN_THREADS * FN_LDT + (size_t)((D + 31) & ~31)) * 4;
+    // tiled form: the query + a ring of up to four stages of 256 rows x 128 B beside the member arrays (the kernel's static
+    // arrays take ~1.2 KB of the 160 KB); fewer than two stages fit only for very long queries with k > 512 -- those walk
+    // their members straight from memory (the generic form)
+    const size_t lds_max = 160 * 1024 - 2048, tiled_fixed = common + (size_t)((D + 31) & ~31) * 4;
+    static const int nst_max = lb_tunable("LB_FINISH_NST", 4);
+    int nst = tiled_fixed < lds_max ? (int)((lds_max - tiled_fixed) / ((size_t)FN_THREADS * 128)) : 0;
+    if (nst > nst_max) nst = nst_max;
+    if (nst > 4) nst = 4;
+    static const int ring_maxq = lb_tunable("LB_FINISH_RING_MAXQ", 256);
+    const size_t sh_regtile = common + ((size_t)FN_THREADS * FN_LDT + (size_t)((D + 31) & ~31)) * 4;
+    // beyond 256 queries several workgroups share a CU: the register-staged tile (56 KB) lets two of them overlap
+    if (nq > ring_maxq && sh_regtile <= lds_max) nst = 0;
+    else if (!split && nst < 2) a.aligned = 0;
+    a.nst = nst;
+    const size_t sh_tiled = !a.aligned ? common : (nst == 0 ? sh_regtile : tiled_fixed + (size_t)nst * FN_THREADS * 128);
     const size_t shmem = split ? sh_split : sh_tiled;
     dim3 grid = split ? dim3((unsigned)G, (unsigned)nq) : dim3((unsigned)nq);
 #define LB_FN(M, O, S, P)                                                                                  \

@@ -1730,6 +1730,8 @@ static void tall16_window(int metric, const float *X, const float *norm2, const 
         const size_t pshmem = (img ? (size_t)4 * (H_BM * H_BK * 2 + H_B_BYTES) : (size_t)H_NST * H_STAGE_BYTES) + 2 * 512 * sizeof(float) +
                               16 + 2 * H_BN * 4 + 8 * (img ? 272 : 104) * 12; // ring, side inputs, flush flags + counters, admission segments
         const bool pnt = a.n_q_tiles <= 1;
+        static const int mapped_nt_on = lb_tunable("LB_F16_MAPPED_NT", 1); // (10 % visible, 256 queries: 243 -> 227 us; 50 %: 544 -> 535)
+        const bool mapped_nt = mapped_nt_on && pnt;
         dim3 pgrid((unsigned)(spx * 8));
 #define LB_TALL16P(M, N, I, B, P)                                                                                       \
     do {                                                                                                                \
@@ -1739,8 +1741,9 @@ static void tall16_window(int metric, const float *X, const float *norm2, const 
     } while (0)
 #define LB_TALL16P_M(M)                                        \
     do {                                                       \
-        if (mapped) { /* (only over the image; the corpus lines of a row list are not streamed: default cache policy) */ \
+        if (mapped) { /* (only over the image) */              \
             if (boot) LB_TALL16P(M, false, true, true, true);  \
+            else if (mapped_nt) LB_TALL16P(M, true, true, false, true); \
             else LB_TALL16P(M, false, true, false, true);      \
         } else if (boot) { /* (a short launch: the cache policy does not matter) */ \
             if (img) LB_TALL16P(M, false, true, true, false);  \

@@ -13,6 +13,9 @@ rows = int(sys.argv[1]) if len(sys.argv) > 1 else 1_250_000
 D = int(sys.argv[2]) if len(sys.argv) > 2 else 1536
 K = int(os.environ.get('K', '100'))
 lib = _lib.require_gpu(0)
+import ctypes as C
+raw = C.CDLL(_lib.SO_PATH)
+have_probe = hasattr(raw, "lb_debug_read_finish_probe")  # diagnostic build: members the finish launch re-ranks per query
 X = torch.empty((rows, D), device="cuda"); Q = torch.empty((1024, D), device="cuda")
 lib.lb_gpu_fill_uniform_device(0, X.data_ptr(), X.numel(), 12345, 0, None)
 lib.lb_gpu_fill_uniform_device(0, Q.data_ptr(), Q.numel(), 42, 0, None)
@@ -36,10 +39,15 @@ for sel in [int(x) for x in os.environ.get("SELS", "100,50,10,1").split(",")]:
             ts.append(time.perf_counter() - t0)
         t = sorted(ts[2:])[len(ts[2:]) // 2]
         idx.set_profiling(True)
+        probe = (C.c_ulonglong * 8)()
+        if have_probe: raw.lb_debug_read_finish_probe(probe, 1)
         idx.search_device(B, q.data_ptr(), K, od.data_ptr(), ol.data_ptr())
+        if have_probe: raw.lb_debug_read_finish_probe(probe, 1)
         tm = idx.last_timing()
         idx.set_profiling(False)
         cls = " ".join(f"{c}={tm[c][0]*1e3:.0f}us/{tm[c][1]}" for c in ("gemm", "scan", "select", "rerank"))
         vis = rows * sel / 100.0
+        if have_probe and probe[1]:
+            cls += f" members/query {probe[0] / probe[1]:.0f} (max {probe[3]}) of {probe[2] / probe[1]:.0f} list entries"
         print(f"sel {sel:3d} %  B={B:5d}  {t*1e3:8.3f} ms/batch  {B/t:10.0f} q/s  visible-f32-bytes/8TBs {4.0*vis*D/t/8e12:5.3f}  "
               f"route {idx.last_route[2]}  fallbacks {idx.last_fallbacks}  [{cls}]  (filter set in {tf*1e3:.1f} ms incl. column upload)", flush=True)
