@@ -624,6 +624,8 @@ __global__ __launch_bounds__(FN_THREADS) void finish_kernel(FinishArgs a)
         // stages in flight cost what one did).  A DMA request is not tracked by the compiler; the waits here are counted.
         // Layout: the eight 16-B pieces of row r's line sit at position p ^ (r & 7) -- a lane asks for the piece that belongs
         // where its request lands, and the walk (lane t = row t, piece after piece) reads conflict-free.
+        // (Two members per lane for 257 .. 512 members -- half the stages, the ring as two stages of 512 rows -- measured slower:
+        // 122 against 113 us on the config-5 share, 270 members per query.)
         // None of this changes a row's sum: every chain runs over its row's elements in the reference's order.
         const int Dpad = (D + 31) & ~31;
         float *sq = work;                                                  // [Dpad]

@@ -21,6 +21,8 @@ lib.lb_gpu_fill_uniform_device(0, X.data_ptr(), X.numel(), 12345, 0, None)
 lib.lb_gpu_fill_uniform_device(0, Q.data_ptr(), Q.numel(), 42, 0, None)
 idx = gpu.NewIndexWithConfig(gpu.GPUConfig(0, D, 2)); idx.reserve(rows); idx.add_device(rows, X.data_ptr())
 meta = np.random.default_rng(5).integers(0, 100, rows).astype(np.int64)
+if os.environ.get("META") == "sorted":  # the visible rows are one contiguous block (what the scatter itself costs: compare)
+    meta = (np.arange(rows, dtype=np.int64) * 100) // rows
 print(f"rows {rows} dim {D} LB_ROWMAP_MAX_PCT={os.environ.get('LB_ROWMAP_MAX_PCT', '(default 95)')}", flush=True)
 for sel in [int(x) for x in os.environ.get("SELS", "100,50,10,1").split(",")]:
     t0 = time.perf_counter()
