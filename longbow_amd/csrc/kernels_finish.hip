@@ -329,10 +329,12 @@ __global__ __launch_bounds__(FN_THREADS) void finish_kernel(FinishArgs a)
     const float nqn = sqrtf(nq2) * (1.000002f + go);         // >= the real |q| (nq2 is an f32 sum in some order)
 
     const uint32_t kk = n < (uint32_t)k ? n : (uint32_t)k;
+    const bool dot_lb = METRIC == METRIC_DOT && a.lb_norm2 != nullptr;
+    // (lower-bound dot keys: the cut comes from the k-th smallest UPPER bound below, a_k is not used -- one selection less)
 #ifdef LB_DIAG
-    const uint64_t pivot = a.abl == 2 ? (e[0] | 0xffffffffull) : radix_kth_regs<PER>(e, kk, hist, wsum, scal, red, tid);
+    const uint64_t pivot = (a.abl == 2 || dot_lb) ? (e[0] | 0xffffffffull) : radix_kth_regs<PER>(e, kk, hist, wsum, scal, red, tid);
 #else
-    const uint64_t pivot = radix_kth_regs<PER>(e, kk, hist, wsum, scal, red, tid);
+    const uint64_t pivot = dot_lb ? (e[0] | 0xffffffffull) : radix_kth_regs<PER>(e, kk, hist, wsum, scal, red, tid);
 #endif
 
     // ---- the cut ------------------------------------------------------------------------------------------------------
@@ -345,7 +347,6 @@ __global__ __launch_bounds__(FN_THREADS) void finish_kernel(FinishArgs a)
                     (METRIC == METRIC_COS ? nqn : 1.0f); // (cosine: the slack is in distance units, keys are |q| times that)
     float cutk = ak + (1.0f + a.beta) * E;
     if (!(cutk >= ak)) cutk = ak; // (NaN / overflow: the proof below decides)
-    const bool dot_lb = METRIC == METRIC_DOT && a.lb_norm2 != nullptr;
     float lbG = 0.f;
     if (dot_lb) {
         // Lower-bound keys: -q.x >= key' G for every row, and -q.x <= (key' + 2 |x|) G.  So the k-th smallest of the UPPER
