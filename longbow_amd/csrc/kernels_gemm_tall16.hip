@@ -107,6 +107,7 @@ struct Tall16Args {
     uint32_t *tin_fail;
     const float *tin_Q; // f32 queries [nq][D] and (cosine, or null) where their exact squared norms go
     float *tin_qna;
+    int qsplit; // one-tile form, sample pass of a 129 .. 256-query batch: the launch's two halves take 128 queries each
 };
 
 // Persistent forms: the launch's positions [0, n_pos) are dealt to the workgroups (narrow form) / workgroup groups (256-query
@@ -1093,12 +1094,29 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
     constexpr bool PIPE = BN != 256; // (at 256 queries there are no registers for a third set of fragments: barrier on top)
     (void)spx;
     extern __shared__ __attribute__((aligned(16))) unsigned char hlds[];
+    int bi = (int)blockIdx.x, ng = (int)gridDim.x;
+    if (BOOT && a.qsplit) {
+        // The sample of a 129 .. 256-query batch: each half of the launch scores all sampled positions for 128 of the queries
+        // (its window of the query image, the scales and the candidate state), 64 positions a workgroup on every CU -- the
+        // 256-query kernel walks the 8192 rows as 32 whole tiles on 32 CUs (38 us at 768 dimensions, 60 at 1536 under a row list).
+        ng >>= 1;
+        const int half = bi >= ng ? 1 : 0;
+        bi -= half * ng;
+        const int qoff = half * 128;
+        a.Qh += (int64_t)qoff * H_BK;
+        a.qinv += qoff;
+        if (a.qnrm) a.qnrm += qoff;
+        a.cs.lists += (size_t)qoff * a.cs.cap;
+        a.cs.cnt += qoff;
+        a.cs.tau += qoff;
+        a.nq = half ? a.nq - 128 : 128;
+    }
     uint32_t lo, hi; // this workgroup's positions
     if (TAUIN) {
-        h_range_duty((uint32_t)(a.row_end - a.row_begin), (int)blockIdx.x, (int)gridDim.x, a.nq, a.tin_dr, lo, hi);
-        if ((int)blockIdx.x < a.nq) tin_duty(a, (int)blockIdx.x, hlds);
+        h_range_duty((uint32_t)(a.row_end - a.row_begin), bi, ng, a.nq, a.tin_dr, lo, hi);
+        if (bi < a.nq) tin_duty(a, bi, hlds);
     } else {
-        h_range((uint32_t)(a.row_end - a.row_begin), (int)blockIdx.x, (int)gridDim.x, lo, hi);
+        h_range((uint32_t)(a.row_end - a.row_begin), bi, ng, lo, hi);
     }
     if (hi <= lo) return;
     const int n_my = (int)((hi - lo + H_BM - 1) / H_BM); // its tiles: positions lo + 256 i ..
@@ -1617,6 +1635,7 @@ static void tall16_window(int metric, const float *X, const float *norm2, const 
     if (row_end <= row_begin || nq <= 0) return;
     Tall16Args a;
     a.tin_fail = nullptr;
+    a.qsplit = 0;
     a.gstride = gstride;
     a.qnrm = qnrm;
     a.gsum = gsum;
@@ -1669,8 +1688,12 @@ static void tall16_window(int metric, const float *X, const float *norm2, const 
         static const int n16 = lb_tunable("LB_F16_NARROW", 1);
         // (the 256-query instance of this kernel measured level with the 4 x 2-wave tile below -- 0.43 ms per pass, bound by MFMA +
         // LDS work either way -- and is not built)
-        if (img && nq <= 128 && n16) { // one query tile of 64 / 128: the pass is the image's HBM stream
-            const int bn = nq <= 64 ? 64 : 128;
+        // (the sample of 129 .. 256 queries: two 128-query halves on the one-tile kernel, see the kernel)
+        static const int qsplit_on = lb_tunable("LB_F16_SAMPLE_QSPLIT", 1);
+        const bool qsplit = img && n16 && boot && gstride != 0 && nq > 128 && nq <= 256 && qsplit_on && tin == nullptr;
+        a.qsplit = qsplit ? 1 : 0;
+        if (img && (nq <= 128 || qsplit) && n16) { // one query tile of 64 / 128: the pass is the image's HBM stream
+            const int bn = (nq <= 64 && !qsplit) ? 64 : 128;
             const size_t ring_b = bn == 64 ? (size_t)6 * (H_BM * H_BK * 2 + 64 * H_BK * 2)
                                            : (bn == 128 ? (size_t)5 * (H_BM * H_BK * 2 + 128 * H_BK * 2) : (size_t)4 * (H_BM * H_BK * 2 + 256 * H_BK * 2));
             // ring, side inputs, flush flags + counters, admission segments
