@@ -107,7 +107,8 @@ struct Tall16Args {
     uint32_t *tin_fail;
     const float *tin_Q; // f32 queries [nq][D] and (cosine, or null) where their exact squared norms go
     float *tin_qna;
-    int qsplit; // one-tile form, sample pass of a 129 .. 256-query batch: the launch's two halves take 128 queries each
+    int qsplit; // one-tile form, sample pass of a batch beyond 128 queries: 0, or the number of 128-query windows the launch's
+                // workgroups divide into
 };
 
 // Persistent forms: the launch's positions [0, n_pos) are dealt to the workgroups (narrow form) / workgroup groups (256-query
@@ -1096,20 +1097,22 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm_filter_narrow16p_kernel(Tal
     extern __shared__ __attribute__((aligned(16))) unsigned char hlds[];
     int bi = (int)blockIdx.x, ng = (int)gridDim.x;
     if (BOOT && a.qsplit) {
-        // The sample of a 129 .. 256-query batch: each half of the launch scores all sampled positions for 128 of the queries
-        // (its window of the query image, the scales and the candidate state), 64 positions a workgroup on every CU -- the
-        // 256-query kernel walks the 8192 rows as 32 whole tiles on 32 CUs (38 us at 768 dimensions, 60 at 1536 under a row list).
-        ng >>= 1;
-        const int half = bi >= ng ? 1 : 0;
-        bi -= half * ng;
-        const int qoff = half * 128;
+        // The sample of a batch of more than 128 queries: the launch's workgroups form a.qsplit groups, each scoring ALL sampled
+        // positions for its window of 128 queries (its part of the query image, the scales and the candidate state) -- 64
+        // positions a workgroup on every CU at 256 queries, where the 256-query kernel walks the 8192 rows as 32 whole tiles
+        // on 32 CUs (38 us at 768 dimensions, 60 at 1536 under a row list).
+        ng /= a.qsplit;
+        const int win = bi / ng;
+        if (win >= a.qsplit) return; // (the grid is not a multiple of the window count)
+        bi -= win * ng;
+        const int qoff = win * 128;
         a.Qh += (int64_t)qoff * H_BK;
         a.qinv += qoff;
         if (a.qnrm) a.qnrm += qoff;
         a.cs.lists += (size_t)qoff * a.cs.cap;
         a.cs.cnt += qoff;
         a.cs.tau += qoff;
-        a.nq = half ? a.nq - 128 : 128;
+        a.nq = a.nq - qoff < 128 ? a.nq - qoff : 128;
     }
     uint32_t lo, hi; // this workgroup's positions
     if (TAUIN) {
@@ -1671,9 +1674,15 @@ static void tall16_window(int metric, const float *X, const float *norm2, const 
         // Each launch sees its own window of the batch: the image, the scales and the candidate state from its first query
         // on; q_stride stays the batch's.
         const int tail = nq % H_BN;
+        // (the sample of more than 128 queries: windows of 128 on the one-tile kernel in ONE launch, see the kernel)
+        static const int qsplit_on = lb_tunable("LB_F16_SAMPLE_QSPLIT", 1);
+        static const int qsplit_maxq = lb_tunable("LB_F16_SAMPLE_QSPLIT_MAXQ", 1024);
+        static const int n16_on = lb_tunable("LB_F16_NARROW", 1);
+        const bool qsplit = img && n16_on && boot && gstride != 0 && nq > 128 && nq <= qsplit_maxq && (nq + 127) / 128 <= spx * 8 && qsplit_on && tin == nullptr;
+        a.qsplit = qsplit ? (nq + 127) / 128 : 0;
         static const int split_tail = lb_tunable("LB_F16_SPLIT_TAIL", 1);
         static const int split_tail_max = lb_tunable("LB_F16_SPLIT_TAIL_MAX", 128); // (65 .. 128 on the 128-query tile: 384 queries 0.90 -> 0.85 ms, 640: 1.39 -> 1.34)
-        if (img && may_split && split_tail && nq > H_BN && tail >= 1 && tail <= split_tail_max) {
+        if (img && may_split && split_tail && nq > H_BN && tail >= 1 && tail <= split_tail_max && !qsplit) {
             const int head = nq - tail;
             tall16_window(metric, X, norm2, rnorm, row_begin, row_end, D, Qh, qinv, head, q_stride, mask, rowmap, cs, boot, s, Xh,
                           xh_cap, false, gstride, qnrm, gsum);
@@ -1688,10 +1697,6 @@ static void tall16_window(int metric, const float *X, const float *norm2, const 
         static const int n16 = lb_tunable("LB_F16_NARROW", 1);
         // (the 256-query instance of this kernel measured level with the 4 x 2-wave tile below -- 0.43 ms per pass, bound by MFMA +
         // LDS work either way -- and is not built)
-        // (the sample of 129 .. 256 queries: two 128-query halves on the one-tile kernel, see the kernel)
-        static const int qsplit_on = lb_tunable("LB_F16_SAMPLE_QSPLIT", 1);
-        const bool qsplit = img && n16 && boot && gstride != 0 && nq > 128 && nq <= 256 && qsplit_on && tin == nullptr;
-        a.qsplit = qsplit ? 1 : 0;
         if (img && (nq <= 128 || qsplit) && n16) { // one query tile of 64 / 128: the pass is the image's HBM stream
             const int bn = (nq <= 64 && !qsplit) ? 64 : 128;
             const size_t ring_b = bn == 64 ? (size_t)6 * (H_BM * H_BK * 2 + 64 * H_BK * 2)
