@@ -35,7 +35,7 @@ constexpr int kScanMaxQ = 8;          // queries per scan launch (register accum
 constexpr int kGemmMinQ = 17;         // below this the exact scan path is used for everything
 constexpr int kMaxBatch = 4096;       // queries per internal batch (workspace sizing)
 constexpr size_t kStageBytes = 32u << 20; // pinned staging slab (x2)
-constexpr int kFinishSplitMaxQ = 16;      // largest batch the finish launch serves with several workgroups per query
+constexpr int kFinishSplitMaxQ = 64;      // largest batch the finish launch serves with several workgroups per query
 constexpr uint32_t kFinishSmaxMax = 4096; // most members (rows re-ranked exactly) a query may have
 
 struct Event {

@@ -86,6 +86,8 @@ struct FinishArgs {
     uint32_t *flags_host;
     uint32_t smax;    // members a query may have (power of two)
     int aligned;      // D % 4 == 0 and 16-B aligned rows / queries
+    int split_ring;   // SPLIT form with the tiled form's row ring as its scoring scheme (17 .. 128 queries: a few workgroups per
+                      // query so that every CU gathers; the 16-row scheme is the latency form for up to 16 queries)
     int nst;          // tiled form: stages of the row ring (2 .. 4, what the LDS beside the member arrays allows); 0 = the
                       // register-staged tile (several workgroups per CU)
     // SPLIT form
@@ -430,7 +432,7 @@ __global__ __launch_bounds__(FN_THREADS) void finish_kernel(FinishArgs a)
             skey[c] = pack_entry(dist, s_rows[c]);
             scmp[c] = cmp;
         }
-    } else if (SPLIT) {
+    } else if (SPLIT && !a.split_ring) {
         // 16 rows at a time, whole (up to 1024 dims per stage): 256 lanes fetch, then 16 (SEQ) / 64 (UNROLL4: four lanes per
         // row, one per accumulator chain) walk the rows out of LDS in the reference's order
         float *tile = work;                  // [16][FN_LD16]
@@ -863,12 +865,6 @@ void launch_finish(int metric, int order, const float *X, int D, const float *Q,
     a.xent = reinterpret_cast<uint64_t *>(xscratch);
     a.xcmp = reinterpret_cast<float *>(a.xent + (size_t)nq_split_max * smax);
     a.aligned = (D % 4 == 0) && D >= 4 && ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && ((reinterpret_cast<uintptr_t>(Q) & 15) == 0);
-    // few queries: G workgroups per query (G divides 256)
-    static const int g_force = lb_tunable("LB_FINISH_G", 0);
-    int G = nq <= 4 ? 32 : (nq <= 16 ? 16 : 1);
-    if (g_force > 0) G = g_force;
-    if (nq > nq_split_max || !done || !xcnt || !xscratch) G = 1;
-    const bool split = G > 1;
     const bool big = cs.cap > 8192u; // list entries per thread: 32 (cap 8192) or 64 (k > 512: cap 16384)
     const size_t common = (size_t)smax * 16;
     const size_t sh_split = common + ((size_t)FN_R16 * FN_LD16 + FN_SD) * 4;
@@ -880,14 +876,32 @@ void launch_finish(int metric, int order, const float *X, int D, const float *Q,
     int nst = tiled_fixed < lds_max ? (int)((lds_max - tiled_fixed) / ((size_t)FN_THREADS * 128)) : 0;
     if (nst > nst_max) nst = nst_max;
     if (nst > 4) nst = 4;
+    // few queries: G workgroups per query (G divides 256)
+    static const int g_force = lb_tunable("LB_FINISH_G", 0);
+    int G = nq <= 4 ? 32 : (nq <= 16 ? 16 : 1);
+    if (g_force > 0) G = g_force;
+    const bool can_split = nq <= nq_split_max && done && xcnt && xscratch;
+    if (!can_split) G = 1;
+    // 17 .. 64 queries with many bytes to gather per query (k x D from 128 Ki: k = 200 at 1536 dimensions is 1.6 MB of rows):
+    // one workgroup per query leaves most CUs idle and each query's gather to one CU's share of the bandwidth -- 8 / 4
+    // workgroups per query share its members (list position mod G), each through the row ring, and hand their exact values
+    // to the last one to arrive as the split form does.  Config-5 share at 32 queries: finish 99 -> 67 us; at k = 100 x 768
+    // dimensions (0.5 MB per query) and from 65 queries it is level, and stays one workgroup per query.
+    static const int split_ring_on = lb_tunable("LB_FINISH_SPLIT_RING", 1);
+    static const int split_ring_maxq = lb_tunable("LB_FINISH_SPLIT_RING_MAXQ", 64);
+    const bool split_ring = G == 1 && split_ring_on && nq > 16 && nq <= split_ring_maxq && (int64_t)k * D >= 131072 && can_split &&
+                            a.aligned && nst >= 2;
+    if (split_ring) G = nq <= 32 ? 8 : 4;
+    const bool split = G > 1;
     static const int ring_maxq = lb_tunable("LB_FINISH_RING_MAXQ", 256);
     const size_t sh_regtile = common + ((size_t)FN_THREADS * FN_LDT + (size_t)((D + 31) & ~31)) * 4;
     // beyond 256 queries several workgroups share a CU: the register-staged tile (56 KB) lets two of them overlap
     if (nq > ring_maxq && sh_regtile <= lds_max) nst = 0;
     else if (!split && nst < 2) a.aligned = 0;
+    a.split_ring = split_ring ? 1 : 0;
     a.nst = nst;
     const size_t sh_tiled = !a.aligned ? common : (nst == 0 ? sh_regtile : tiled_fixed + (size_t)nst * FN_THREADS * 128);
-    const size_t shmem = split ? sh_split : sh_tiled;
+    const size_t shmem = (split && !split_ring) ? sh_split : sh_tiled;
     dim3 grid = split ? dim3((unsigned)G, (unsigned)nq) : dim3((unsigned)nq);
 #define LB_FN(M, O, S, P)                                                                                  \
     do {                                                                                                   \

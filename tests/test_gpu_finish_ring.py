@@ -7,7 +7,9 @@ internal/store/adaptive_index.go:161-225; the metrics of internal/simd/simd.go:1
 * dimensions that are not a multiple of 32 (the last chunk of a row is partial: its pieces beyond the row are clamped and
   never walked), dimensions below one chunk, and a dimension that is not a multiple of 4 (the generic walk);
 * both accumulation orders, every metric, user ids, a filtered view (positions mapped back to rows);
-* batches on both sides of the 256-query limit (beyond it the register-staged tile serves).
+* batches on both sides of the 256-query limit (beyond it the register-staged tile serves);
+* 17 .. 64 queries with k x D from 128 Ki: several workgroups per query share its members through the ring and hand
+  their exact values to the last one to arrive.
 """
 import numpy as np
 import pytest
@@ -29,6 +31,8 @@ F = np.float32
     (64, 48, 1100, 0),    # smax 4096: two stages, 64 list entries per thread
     (70, 20, 50, 0),      # not a multiple of 4: generic walk
     (128, 257, 120, 0),   # beyond 256 queries: the register-staged tile
+    (768, 24, 200, 0),    # k x D beyond 128 Ki at 17 .. 32 queries: eight workgroups per query share the members (split + ring)
+    (1536, 40, 100, 1),   # ... four per query at 33 .. 64
 ])
 def test_tiled_finish_matches_oracle(oracle, metric, d, nq, k, order):
     gpu_or_skip()
@@ -49,7 +53,7 @@ def test_tiled_finish_with_ids_and_a_filtered_view(oracle, metric):
     """user ids in the labels; a selective predicate (the persistent kernels leave positions of the row list in the entries,
     the finish maps them back) with more than 256 members per query"""
     gpu_or_skip()
-    n, d, nq, k = 300000, 256, 48, 260
+    n, d, nq, k = 300000, 512, 48, 260  # (k x D beyond 128 Ki: several workgroups per query)
     rng = np.random.default_rng(77 + metric)
     X = rng.random((n, d), dtype=F)
     Q = rng.random((nq, d), dtype=F)
