@@ -35,7 +35,7 @@ constexpr int kScanMaxQ = 8;          // queries per scan launch (register accum
 constexpr int kGemmMinQ = 17;         // below this the exact scan path is used for everything
 constexpr int kMaxBatch = 4096;       // queries per internal batch (workspace sizing)
 constexpr size_t kStageBytes = 32u << 20; // pinned staging slab (x2)
-constexpr int kFinishSplitMaxQ = 64;      // largest batch the finish launch serves with several workgroups per query
+constexpr int kFinishSplitMaxQ = 128;     // largest batch the finish launch serves with several workgroups per query
 constexpr uint32_t kFinishSmaxMax = 4096; // most members (rows re-ranked exactly) a query may have
 
 struct Event {
@@ -725,7 +725,10 @@ static Route choose_route(int nq, int64_t n, int D, int cmode, bool narrow_ok, b
         if (have_f16_image && nq <= 128) { // (one query tile: the 64- / 128-query form of the persistent kernel)
             // + what the route pays per query beside the stream: twice (beyond 1024 dimensions four times) the candidates to
             // select and re-rank
-            const double q1 = D > 1024 ? 0.0016 : 0.0007;
+            // (round 4: 0.0016 -> 0.0008 beyond 1024 dimensions -- the finish launch re-ranks ~270 rows per query where select +
+            // re-rank scored 1024; with 0.0016 a row list of 125k x 1536 went to the 64-query split tile at exactly 64 and 128
+            // queries: 0.30 / 0.40 ms where the image serves them in 0.24 / 0.31)
+            const double q1 = D > 1024 ? 0.0008 : 0.0007;
             add(ROUTE_NARROW16, 3, route_ms(kCostNarrow16, n, D, 1) + q1 * nq);
         }
         else add(ROUTE_TALL16, 3, route_ms(have_f16_image ? kCostTall16Img : kCostTall16, n, D, tiles256));
@@ -789,7 +792,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     if (!h->nonfinite && nq < narrow_min && have_xh && f16_range_ok && allow_f16 &&
         (cmode == LB_CAND_F16 || (cmode == LB_CAND_AUTO && h->f16_skip.load(std::memory_order_relaxed) == 0))) {
         const double scan_ms = 1e-6 * (double)n * ((double)h->dim * 0.00066 + 0.04);
-        const double copy_ms = route_ms(kCostNarrow16, n, h->dim, 1) + (h->dim > 1024 ? 0.0016 : 0.0007) * nq;
+        const double copy_ms = route_ms(kCostNarrow16, n, h->dim, 1) + (h->dim > 1024 ? 0.0008 : 0.0007) * nq;
         small_on_copy = cmode == LB_CAND_F16 || copy_ms < scan_ms;
     }
     // (dimensions that are not multiples of 32: the MFMA tiles over f32 rows do not apply; the fp16 copy does)

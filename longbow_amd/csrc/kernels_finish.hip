@@ -882,16 +882,17 @@ void launch_finish(int metric, int order, const float *X, int D, const float *Q,
     if (g_force > 0) G = g_force;
     const bool can_split = nq <= nq_split_max && done && xcnt && xscratch;
     if (!can_split) G = 1;
-    // 17 .. 64 queries with many bytes to gather per query (k x D from 128 Ki: k = 200 at 1536 dimensions is 1.6 MB of rows):
-    // one workgroup per query leaves most CUs idle and each query's gather to one CU's share of the bandwidth -- 8 / 4
+    // 17 .. 128 queries with many bytes to gather per query (k x D from 128 Ki: k = 200 at 1536 dimensions is 1.6 MB of rows):
+    // one workgroup per query leaves CUs idle and each query's gather to one CU's share of the bandwidth -- 8 / 4 / 2
     // workgroups per query share its members (list position mod G), each through the row ring, and hand their exact values
-    // to the last one to arrive as the split form does.  Config-5 share at 32 queries: finish 99 -> 67 us; at k = 100 x 768
-    // dimensions (0.5 MB per query) and from 65 queries it is level, and stays one workgroup per query.
+    // to the last one to arrive as the split form does.  Config-5 share: finish 99 -> 67 us at 32 queries, 104 -> 74 at 128
+    // (135 members a workgroup: one group of the ring instead of 256 + 14); at k = 100 x 768 dimensions (0.5 MB per query) it
+    // is level, and stays one workgroup per query.
     static const int split_ring_on = lb_tunable("LB_FINISH_SPLIT_RING", 1);
-    static const int split_ring_maxq = lb_tunable("LB_FINISH_SPLIT_RING_MAXQ", 64);
+    static const int split_ring_maxq = lb_tunable("LB_FINISH_SPLIT_RING_MAXQ", 128);
     const bool split_ring = G == 1 && split_ring_on && nq > 16 && nq <= split_ring_maxq && (int64_t)k * D >= 131072 && can_split &&
                             a.aligned && nst >= 2;
-    if (split_ring) G = nq <= 32 ? 8 : 4;
+    if (split_ring) G = nq <= 32 ? 8 : (nq <= 64 ? 4 : 2);
     const bool split = G > 1;
     static const int ring_maxq = lb_tunable("LB_FINISH_RING_MAXQ", 256);
     const size_t sh_regtile = common + ((size_t)FN_THREADS * FN_LDT + (size_t)((D + 31) & ~31)) * 4;

@@ -8,7 +8,7 @@ internal/store/adaptive_index.go:161-225; the metrics of internal/simd/simd.go:1
   never walked), dimensions below one chunk, and a dimension that is not a multiple of 4 (the generic walk);
 * both accumulation orders, every metric, user ids, a filtered view (positions mapped back to rows);
 * batches on both sides of the 256-query limit (beyond it the register-staged tile serves);
-* 17 .. 64 queries with k x D from 128 Ki: several workgroups per query share its members through the ring and hand
+* 17 .. 128 queries with k x D from 128 Ki: several workgroups per query share its members through the ring and hand
   their exact values to the last one to arrive.
 """
 import numpy as np
@@ -33,6 +33,7 @@ F = np.float32
     (128, 257, 120, 0),   # beyond 256 queries: the register-staged tile
     (768, 24, 200, 0),    # k x D beyond 128 Ki at 17 .. 32 queries: eight workgroups per query share the members (split + ring)
     (1536, 40, 100, 1),   # ... four per query at 33 .. 64
+    (1536, 100, 100, 0),  # ... two at 65 .. 128
 ])
 def test_tiled_finish_matches_oracle(oracle, metric, d, nq, k, order):
     gpu_or_skip()
