@@ -230,3 +230,38 @@ def test_config5_filtered_hybrid_share(oracle):
         ri, rs = oracle.rrf(lab[b], sparse[b], 60, K5)
         assert np.array_equal(fi[b], ri) and np.array_equal(fs[b], rs)
     idx.Close()
+
+
+def test_config5_share_smaller_batches_stay_on_the_image():
+    """The config-5 share (1.25M x 1536 dot, 10 % visible) at 32 / 64 / 128 queries: every batch is answered from the fp16
+    image by the one-tile kernel under the row list (at exactly 64 and 128 queries -- whole query tiles of the split-bf16
+    kernel -- the cost model of round 3 sent it to the f32 rows: 0.30 / 0.40 ms instead of 0.25 / 0.28), nothing falls back to
+    the scan, and each query's list equals the one it gets inside the 256-query batch."""
+    gpu_or_skip()
+    torch = pytest.importorskip("torch")
+    from longbow_amd import _lib, gpu
+    lib = _lib.load()
+    rows, D, K2 = 1_250_000, 1536, 200
+    X = torch.empty((rows, D), device="cuda")
+    Q = torch.empty((256, D), device="cuda")
+    assert lib.lb_gpu_fill_uniform_device(0, X.data_ptr(), X.numel(), 12345, 0, None) == 0
+    assert lib.lb_gpu_fill_uniform_device(0, Q.data_ptr(), Q.numel(), 42, 0, None) == 0
+    idx = gpu.NewIndexWithConfig(gpu.GPUConfig(DeviceID=0, Dimension=D, Metric=2))
+    idx.add_device(rows, X.data_ptr())
+    del X
+    meta = np.random.default_rng(5).integers(0, 100, rows).astype(np.int64)
+    idx.filter_column(meta, "<", 10)
+    dd = torch.empty((256, K2), device="cuda")
+    dl = torch.empty((256, K2), dtype=torch.int64, device="cuda")
+    idx.search_device(256, Q.data_ptr(), K2, dd.data_ptr(), dl.data_ptr())
+    assert idx.last_fallbacks == 0
+    lab, dist = dl.cpu().numpy(), dd.cpu().numpy()
+    assert np.all(meta[lab] < 10), "a hidden row was returned"
+    for B in (32, 64, 128):
+        bd = torch.empty((B, K2), device="cuda")
+        bl = torch.empty((B, K2), dtype=torch.int64, device="cuda")
+        idx.search_device(B, Q.data_ptr(), K2, bd.data_ptr(), bl.data_ptr())
+        assert idx.last_fallbacks == 0
+        assert idx.last_route[0] == 7, (B, idx.last_route)  # ROUTE_NARROW16: the one-tile kernel over the fp16 image
+        assert np.array_equal(bl.cpu().numpy(), lab[:B]) and np.array_equal(bd.cpu().numpy(), dist[:B]), B
+    idx.Close()
