@@ -677,7 +677,7 @@ constexpr RouteCost kCostTall2Image{0.001150, 0.1300, 0.000640, 0.000220, 0.09};
 constexpr RouteCost kCostWideF32{0.001940, 0.0600, 0.000640, 0.0, 0.09};
 constexpr RouteCost kCostTall16{0.000540, 0.0800, 0.000660, 0.000140, 0.19}; // per 256-query tile, one fp16 product, persistent form: 0.49 ms per
                                                                              // tile at 1M x 768, a single tile streams the corpus at 6 TB/s
-constexpr RouteCost kCostTall16Img{0.000460, 0.0500, 0.000330, 0.000040, 0.19}; // the same from the corpus's fp16 image: 0.40 ms per tile at
+constexpr RouteCost kCostTall16Img{0.000460, 0.0500, 0.000330, 0.000040, 0.15}; // the same from the corpus's fp16 image: 0.40 ms per tile at
                                                                                 // 1M x 768, never bound by the stream (1.5 GB)
 constexpr RouteCost kCostNarrow16{0.000100, 0.0300, 0.000340, 0.000030, 0.08};  // up to 64 queries over the fp16 copy: its HBM stream (6 TB/s)
 inline double route_ms(const RouteCost &c, int64_t n, int D, int tiles)
@@ -718,9 +718,13 @@ static Route choose_route(int nq, int64_t n, int D, int cmode, bool narrow_ok, b
     // one fp16 product instead of three bf16 ones (split code 3): AUTO and the explicit LB_CAND_F16, while the corpus norms
     // allow it (f16_ok) and there are enough tiles to fill the chip
     static const int f16_on = lb_tunable("LB_F16", 1);
+    // (a filtered view of a corpus that has its fp16 image: from the size a sampled threshold exists for, the cost model
+    // decides -- round 3's gate of 128 Mi elements kept 100k x 768 views on the 64-query split tile: 0.21 / 0.30 / 0.50 ms at
+    // 128 / 256 / 512 queries where the image serves them in 0.16 / 0.20 / 0.28)
+    static const int64_t f16_view_min = lb_tunable("LB_F16_VIEW_MIN", 65536);
     // (over the fp16 copy the route needs neither dim % 32 == 0 nor aligned queries: both images are zero-padded planes)
     if ((narrow_ok || have_f16_image) && f16_ok && f16_on && !image && (nq > 32 || have_f16_image) &&
-        (cmode == LB_CAND_F16 || (cmode == LB_CAND_AUTO && (n >= 262144 || (have_f16_image && n * (int64_t)D >= ((int64_t)128 << 20))))))
+        (cmode == LB_CAND_F16 || (cmode == LB_CAND_AUTO && (n >= 262144 || (have_f16_image && n >= f16_view_min)))))
     { // (below: launch overheads decide, and the narrow tiles win; a filtered view of a large corpus counts by its elements)
         if (have_f16_image && nq <= 128) { // (one query tile: the 64- / 128-query form of the persistent kernel)
             // + what the route pays per query beside the stream: twice (beyond 1024 dimensions four times) the candidates to
@@ -728,7 +732,7 @@ static Route choose_route(int nq, int64_t n, int D, int cmode, bool narrow_ok, b
             // (round 4: 0.0016 -> 0.0008 beyond 1024 dimensions -- the finish launch re-ranks ~270 rows per query where select +
             // re-rank scored 1024; with 0.0016 a row list of 125k x 1536 went to the 64-query split tile at exactly 64 and 128
             // queries: 0.30 / 0.40 ms where the image serves them in 0.24 / 0.31)
-            const double q1 = D > 1024 ? 0.0008 : 0.0007;
+            const double q1 = D > 1024 ? 0.0008 : 0.0004;
             add(ROUTE_NARROW16, 3, route_ms(kCostNarrow16, n, D, 1) + q1 * nq);
         }
         else add(ROUTE_TALL16, 3, route_ms(have_f16_image ? kCostTall16Img : kCostTall16, n, D, tiles256));
@@ -736,6 +740,11 @@ static Route choose_route(int nq, int64_t n, int D, int cmode, bool narrow_ok, b
     if (cmode == LB_CAND_F32_MFMA || cmode == LB_CAND_AUTO || nc == 0) add(ROUTE_WIDE, 0, route_ms(kCostWideF32, n, D, tiles128));
 #ifdef LB_DIAG
     { // A/B (tools/route_grid.py): force a route when it is available for this batch (read per call: the tool flips it)
+        if (getenv("LB_TRACE_ROUTE")) {
+            fprintf(stderr, "[route] nq %d n %lld D %d cmode %d narrow_ok %d f16_ok %d image %d:", nq, (long long)n, D, cmode, (int)narrow_ok, (int)f16_ok, (int)have_f16_image);
+            for (int i = 0; i < nc; i++) fprintf(stderr, " kind %d/%d %.3f ms", cand[i].kind, cand[i].split, cand[i].cost_ms);
+            fprintf(stderr, "\n");
+        }
         const char *e = getenv("LB_FORCE_ROUTE");
         const int force = e ? atoi(e) : 0;
         for (int i = 0; i < nc; i++)
@@ -792,7 +801,7 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     if (!h->nonfinite && nq < narrow_min && have_xh && f16_range_ok && allow_f16 &&
         (cmode == LB_CAND_F16 || (cmode == LB_CAND_AUTO && h->f16_skip.load(std::memory_order_relaxed) == 0))) {
         const double scan_ms = 1e-6 * (double)n * ((double)h->dim * 0.00066 + 0.04);
-        const double copy_ms = route_ms(kCostNarrow16, n, h->dim, 1) + (h->dim > 1024 ? 0.0008 : 0.0007) * nq;
+        const double copy_ms = route_ms(kCostNarrow16, n, h->dim, 1) + (h->dim > 1024 ? 0.0008 : 0.0004) * nq;
         small_on_copy = cmode == LB_CAND_F16 || copy_ms < scan_ms;
     }
     // (dimensions that are not multiples of 32: the MFMA tiles over f32 rows do not apply; the fp16 copy does)
