@@ -677,9 +677,9 @@ constexpr RouteCost kCostTall2Image{0.001150, 0.1300, 0.000640, 0.000220, 0.09};
 constexpr RouteCost kCostWideF32{0.001940, 0.0600, 0.000640, 0.0, 0.09};
 constexpr RouteCost kCostTall16{0.000540, 0.0800, 0.000660, 0.000140, 0.19}; // per 256-query tile, one fp16 product, persistent form: 0.49 ms per
                                                                              // tile at 1M x 768, a single tile streams the corpus at 6 TB/s
-constexpr RouteCost kCostTall16Img{0.000460, 0.0500, 0.000330, 0.000040, 0.15}; // the same from the corpus's fp16 image: 0.40 ms per tile at
+constexpr RouteCost kCostTall16Img{0.000460, 0.0500, 0.000330, 0.000040, 0.11}; // the same from the corpus's fp16 image: 0.40 ms per tile at
                                                                                 // 1M x 768, never bound by the stream (1.5 GB)
-constexpr RouteCost kCostNarrow16{0.000100, 0.0300, 0.000340, 0.000030, 0.08};  // up to 64 queries over the fp16 copy: its HBM stream (6 TB/s)
+constexpr RouteCost kCostNarrow16{0.000100, 0.0300, 0.000340, 0.000030, 0.06};  // up to 64 queries over the fp16 copy: its HBM stream (6 TB/s)
 inline double route_ms(const RouteCost &c, int64_t n, int D, int tiles)
 {
     const double nd = 1e-6 * (double)n;
@@ -732,7 +732,7 @@ static Route choose_route(int nq, int64_t n, int D, int cmode, bool narrow_ok, b
             // (round 4: 0.0016 -> 0.0008 beyond 1024 dimensions -- the finish launch re-ranks ~270 rows per query where select +
             // re-rank scored 1024; with 0.0016 a row list of 125k x 1536 went to the 64-query split tile at exactly 64 and 128
             // queries: 0.30 / 0.40 ms where the image serves them in 0.24 / 0.31)
-            const double q1 = D > 1024 ? 0.0008 : 0.0004;
+            const double q1 = D > 1024 ? 0.0008 : 0.0003;
             add(ROUTE_NARROW16, 3, route_ms(kCostNarrow16, n, D, 1) + q1 * nq);
         }
         else add(ROUTE_TALL16, 3, route_ms(have_f16_image ? kCostTall16Img : kCostTall16, n, D, tiles256));
@@ -800,8 +800,8 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     bool small_on_copy = false;
     if (!h->nonfinite && nq < narrow_min && have_xh && f16_range_ok && allow_f16 &&
         (cmode == LB_CAND_F16 || (cmode == LB_CAND_AUTO && h->f16_skip.load(std::memory_order_relaxed) == 0))) {
-        const double scan_ms = 1e-6 * (double)n * ((double)h->dim * 0.00066 + 0.04);
-        const double copy_ms = route_ms(kCostNarrow16, n, h->dim, 1) + (h->dim > 1024 ? 0.0008 : 0.0004) * nq;
+        const double scan_ms = 0.04 + 1e-6 * (double)n * ((double)h->dim * 0.00066 + 0.04); // (0.04: sample, thresholds, select + emit)
+        const double copy_ms = route_ms(kCostNarrow16, n, h->dim, 1) + (h->dim > 1024 ? 0.0008 : 0.0003) * nq;
         small_on_copy = cmode == LB_CAND_F16 || copy_ms < scan_ms;
     }
     // (dimensions that are not multiples of 32: the MFMA tiles over f32 rows do not apply; the fp16 copy does)
@@ -1495,11 +1495,14 @@ void sync_split_image(lb_gpu_index *h)
 void sync_f16_image(lb_gpu_index *h)
 {
     const int cm = h->cand_mode.load();
+    // (round 4: from 65,536 rows -- the size from which a sampled threshold exists -- instead of 262,144: 100k x 768 at 256 queries
+    // 0.298 -> 0.163 ms, 1024: 0.82 -> 0.43; 200k x 768: 0.49 -> 0.21, 1.25 -> 0.57; +50 % of a corpus of this size is 0.15-0.4 GB)
+    static const int64_t f16_image_min_rows = lb_tunable("LB_F16_IMAGE_MIN_ROWS", 65536);
     const bool l2 = h->metric == LB_METRIC_EUCLIDEAN;
     // (L2: the image is centred, so what must fit fp16 are the centred norms -- known once the centre is)
     const bool range_ok = l2 ? (!h->nonfinite && (h->xh_declined_n == 0 || h->n >= 2 * h->xh_declined_n)) : h->f16_ok;
     const bool want = h->xh_mode.load() != 0 && !h->xh_failed && range_ok && h->n > 0 &&
-                      (cm == LB_CAND_F16 || (cm == LB_CAND_AUTO && h->n >= 262144));
+                      (cm == LB_CAND_F16 || (cm == LB_CAND_AUTO && h->n >= f16_image_min_rows));
     try {
         if (!want || (h->d_Xh && (h->xh_cap < h->n || h->xh_rows > h->n))) {
             drop_f16_image(h);

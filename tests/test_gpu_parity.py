@@ -506,6 +506,7 @@ def test_fused_sample_launch_and_its_give_up_path(oracle):
     Q = rng.standard_normal((32, d)).astype(F)
     for metric in (0, 1, 2):
         idx = new_index(d, metric, lib=lib)
+        idx.set_f16_image(0)  # (with its fp16 image a corpus of this size takes the one-tile fp16 kernel: this test is about the fused split tile)
         idx.Add(None, X)
         want = {nq: oracle.search_batch(metric, Q[:nq], X, k, nthreads=8) for nq in (5, 9, 32)}
         for rep in range(3):
@@ -677,7 +678,7 @@ def test_fp16_image_follows_the_corpus(oracle):
         assert_same(lab, dist, oi, od, f"fp16 image after {done} rows")
     idx.set_candidate_mode(0)                  # strict mode: no fp16 route, no copy
     assert idx.f16_image_bytes == 0
-    idx.set_candidate_mode(3)                  # AUTO below 262,144 rows: not on offer either
+    idx.set_candidate_mode(3)                  # AUTO below 65,536 rows: not on offer either
     assert idx.f16_image_bytes == 0
     idx.Close()
 
