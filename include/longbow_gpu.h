@@ -107,7 +107,7 @@ typedef enum { LB_CAND_F32_MFMA = 0, LB_CAND_SPLIT_BF16 = 1, LB_CAND_SPLIT_BF16_
 int lb_gpu_index_set_candidate_mode(lb_gpu_index *h, int mode);
 /* The fp16 route's own copy of the corpus (2 bytes per element, K-blocked): half the bytes to stage per batched search of
  * more than 64 queries (1M x 768, 1024 queries: see LABNOTES.md 4.2).  mode 1 (default): kept while the route is on offer for
- * this index (LB_CAND_AUTO from 65,536 rows, or LB_CAND_F16; norms in range; any dimension: the copy is laid out in
+ * this index (LB_CAND_AUTO from 16,384 rows, or LB_CAND_F16; norms in range; any dimension: the copy is laid out in
  * zero-padded planes of 32 dimensions, which is also what opens the matrix-core routes to dimensions like 100 or 300) and the copy leaves
  * max(2 GiB, 1/16 of the device) free -- brought up to date inside Add, dropped when the conditions end; mode 0: never (the
  * route then rounds the f32 rows in registers).  Results do not depend on it: both forms see the same fp16 values, and every

@@ -496,7 +496,10 @@ static SamplePlan sample_plan_for(int64_t n, int keep, uint32_t cap, uint32_t co
 }
 static SamplePlan sample_plan(int64_t n, int keep, uint32_t cap, uint32_t count_max = 8192u)
 {
-    if (!g_sample_tau.load() || n < 65536 || (uint32_t)keep >= cap) return SamplePlan{};
+    // (round 4: sampled thresholds from 16,384 rows -- was 65,536: below it the classic schedule ran three corpus launches and
+    // three selects where the sampled one runs a sample, one pass and the finish: 40k x 768 at 64 queries 0.19 -> 0.10 ms)
+    static const int64_t sample_min_rows = lb_tunable("LB_SAMPLE_MIN_ROWS", 16384);
+    if (!g_sample_tau.load() || n < sample_min_rows || (uint32_t)keep >= cap) return SamplePlan{};
     // the largest sample whose threshold rank stays within the kernel's reach and whose span covers the view: a small view
     // (a selective filter) or a long candidate list (large k) takes a smaller sample -- a sample that is a large share of
     // the rows would need its several-hundredth smallest entry
@@ -721,7 +724,7 @@ static Route choose_route(int nq, int64_t n, int D, int cmode, bool narrow_ok, b
     // (a filtered view of a corpus that has its fp16 image: from the size a sampled threshold exists for, the cost model
     // decides -- round 3's gate of 128 Mi elements kept 100k x 768 views on the 64-query split tile: 0.21 / 0.30 / 0.50 ms at
     // 128 / 256 / 512 queries where the image serves them in 0.16 / 0.20 / 0.28)
-    static const int64_t f16_view_min = lb_tunable("LB_F16_VIEW_MIN", 65536);
+    static const int64_t f16_view_min = lb_tunable("LB_F16_VIEW_MIN", 16384);
     // (over the fp16 copy the route needs neither dim % 32 == 0 nor aligned queries: both images are zero-padded planes)
     if ((narrow_ok || have_f16_image) && f16_ok && f16_on && !image && (nq > 32 || have_f16_image) &&
         (cmode == LB_CAND_F16 || (cmode == LB_CAND_AUTO && (n >= 262144 || (have_f16_image && n >= f16_view_min)))))
@@ -1497,7 +1500,7 @@ void sync_f16_image(lb_gpu_index *h)
     const int cm = h->cand_mode.load();
     // (round 4: from 65,536 rows -- the size from which a sampled threshold exists -- instead of 262,144: 100k x 768 at 256 queries
     // 0.298 -> 0.163 ms, 1024: 0.82 -> 0.43; 200k x 768: 0.49 -> 0.21, 1.25 -> 0.57; +50 % of a corpus of this size is 0.15-0.4 GB)
-    static const int64_t f16_image_min_rows = lb_tunable("LB_F16_IMAGE_MIN_ROWS", 65536);
+    static const int64_t f16_image_min_rows = lb_tunable("LB_F16_IMAGE_MIN_ROWS", 16384);
     const bool l2 = h->metric == LB_METRIC_EUCLIDEAN;
     // (L2: the image is centred, so what must fit fp16 are the centred norms -- known once the centre is)
     const bool range_ok = l2 ? (!h->nonfinite && (h->xh_declined_n == 0 || h->n >= 2 * h->xh_declined_n)) : h->f16_ok;

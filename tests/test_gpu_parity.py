@@ -213,7 +213,7 @@ def test_selective_filter_walks_compacted_row_list(oracle):
 
 
 def test_sampled_threshold_first_pass(oracle):
-    """corpora >= 64k rows take a strided row sample's m-th best entry as admission threshold and walk
+    """corpora >= 16k rows (64k before round 4) take a strided row sample's m-th best entry as admission threshold and walk
     the rows once; the classic bootstrap schedule is the fallback.  Both must equal the oracle on random,
     sorted (worst->best and best->worst), and heavily duplicated corpora, on every search path."""
     lib = diag_lib()  # lb_debug_set_sample_tau exists only in the diagnostic build
@@ -301,8 +301,10 @@ def test_non_finite_rows_and_queries_rank_canonically(oracle):
 
 def test_adversarial_order_forces_list_overflow(oracle):
     """rows sorted from worst to best: every row is admitted, the candidate lists overflow, and the
-    library must fall back to overflow-proof chunking and still be exact"""
-    gpu_or_skip()
+    library must fall back to overflow-proof chunking and still be exact.  (The classic bootstrap schedule is forced
+    through the diagnostic build's hook: since round 4 a corpus of this size takes the sampled threshold, whose strided
+    sample does not care about the row order -- the second half of the test checks exactly that.)"""
+    lib = diag_lib()
     rng = np.random.default_rng(21)
     d = 32
     q = rng.random(d, dtype=F)
@@ -310,13 +312,25 @@ def test_adversarial_order_forces_list_overflow(oracle):
     dist = oracle.batch_flat(0, q, X)
     X = X[np.argsort(-dist)]                     # descending distance to q
     Q = np.stack([q + F(1e-3) * rng.random(d, dtype=F) for _ in range(24)])
-    idx = new_index(d, 0)
+    idx = new_index(d, 0, lib=lib)
     idx.Add(None, X)
-    for qs in (Q[:2], Q):
+    lib.lb_debug_set_sample_tau(0)                # classic schedule: bootstrap chunk, then growing chunks
+    try:
+        for qs in (Q[:2], Q):
+            lab, dd = idx.SearchBatch(qs, 10)
+            oi, od = oracle.search_batch(0, qs, X, 10, nthreads=4)
+            assert_same(lab, dd, oi, od)
+        assert idx.last_fallbacks > 0             # the batched path did have to fall back
+    finally:
+        lib.lb_debug_set_sample_tau(1)
+    idx.Close()
+    idx = new_index(d, 0, lib=lib)                # (a fresh index: the one above remembers the widened lists of its hard batches)
+    idx.Add(None, X)
+    for qs in (Q[:2], Q):                         # sampled threshold: the order does not matter, nothing falls back
         lab, dd = idx.SearchBatch(qs, 10)
         oi, od = oracle.search_batch(0, qs, X, 10, nthreads=4)
         assert_same(lab, dd, oi, od)
-    assert idx.last_fallbacks > 0                 # the batched path did have to fall back
+        assert idx.last_fallbacks == 0
     idx.Close()
 
 
@@ -495,7 +509,7 @@ def test_every_path_boundary(oracle, metric):
 
 
 def test_fused_sample_launch_and_its_give_up_path(oracle):
-    """5-32 queries on >= 64k rows: the sampled threshold rides inside the candidate launch (sample tiles, per-query
+    """5-32 queries on >= 16k rows: the sampled threshold rides inside the candidate launch (sample tiles, per-query
     threshold workgroups, corpus workgroups that pick the thresholds up).  Results equal the oracle; when a wait inside
     the launch gives up (forced here through the host hook) the whole batch is redone on the exact path and the next
     searches run fused again."""
@@ -678,7 +692,7 @@ def test_fp16_image_follows_the_corpus(oracle):
         assert_same(lab, dist, oi, od, f"fp16 image after {done} rows")
     idx.set_candidate_mode(0)                  # strict mode: no fp16 route, no copy
     assert idx.f16_image_bytes == 0
-    idx.set_candidate_mode(3)                  # AUTO below 65,536 rows: not on offer either
+    idx.set_candidate_mode(3)                  # AUTO below 16,384 rows: not on offer either
     assert idx.f16_image_bytes == 0
     idx.Close()
 
