@@ -926,7 +926,11 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     // Up to 64 queries on the narrow split tiles the sample and its thresholds ride INSIDE the candidate launch (FUSED
     // in kernels_gemm_narrow.hip: 19-34 us of sample + 13 us of threshold kernel off the critical path).
     static const int fused_max = lb_tunable("LB_FUSED_SAMPLE_MAXQ", 32); // (33-64 queries, the 64-query tile: measured level)
-    const bool fused = sp.on && use_narrow && nsplit && nq <= fused_max && nq <= 64;
+    // (from 131,072 rows: the fused launch has a floor of ~115 us whatever the corpus -- 70k x 768 at 8 queries 0.156 ms fused,
+    // 0.124 with the sample and the thresholds as launches of their own, level at 150k-300k, 20 us ahead at 1M -- and on the
+    // 16k-64k-row corpora that take a sampled threshold since round 4 its waits gave up: 17k rows at 16 queries, 40k at 32,
+    // the batch redone exactly in 1 ms)
+    const bool fused = sp.on && use_narrow && nsplit && nq <= fused_max && nq <= 64 && n >= 131072;
     // a search over a row list on the persistent fp16 kernels: its candidate entries carry positions of the list
     const bool entries_pos = use_tall16 && rv.rowmap != nullptr &&
                              tall16_entries_are_positions(h->dim, nq, have_xh, true, mask != nullptr);
