@@ -129,3 +129,29 @@ def test_a_wait_for_the_thresholds_that_gives_up_is_reported_and_the_batch_redon
     assert_same(lab, dist, oi, od, "after")
     assert idx.fused_giveups == 1 and idx.last_fallbacks == 0
     idx.Close()
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_image_less_corpora_of_16k_to_64k_rows_run_separate_sample_launches(oracle, metric):
+    """Since round 4 corpora from 16,384 rows take the sampled threshold.  An index WITHOUT its fp16 image (switched off
+    here; also norms outside fp16's range, or memory pressure) runs the split tiles there, and the fused form of their
+    sample launch is kept for 131,072 rows and more: on these sizes its in-launch waits gave up (17k rows at 16 queries, 40k
+    at 32) and the batch was redone exactly -- right answers, seven times the time.  Every batch size around the tile limits:
+    the oracle's lists, no give-up, nothing left to the exact scan."""
+    gpu_or_skip()
+    rng = np.random.default_rng(1234 + metric)
+    d, k = 64, 20
+    for n in (17000, 40000, 60000):
+        X = rng.standard_normal((n, d)).astype(F)
+        Q = rng.standard_normal((64, d)).astype(F)
+        idx = new_index(d, metric)
+        idx.set_f16_image(0)
+        idx.Add(None, X)
+        assert idx.f16_image_bytes == 0
+        for nq in (5, 8, 16, 32, 33, 64):
+            lab, dist = idx.SearchBatch(Q[:nq], k)
+            oi, od = oracle.search_batch(metric, Q[:nq], X, k, nthreads=8)
+            assert_same(lab, dist, oi, od, f"metric={metric} n={n} nq={nq}")
+            assert idx.last_fallbacks == 0, (n, nq)
+        assert idx.fused_giveups == 0, n
+        idx.Close()
