@@ -797,7 +797,16 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
                          (!h->xh_centred || tall16_runs_persistent(h->dim, nq, true, rv.rowmap != nullptr, false));
     const bool centred = have_xh && h->xh_centred; // L2 keys about the image's centre (sync_f16_image)
     // within the fp16 contraction's range: the centred norms when the image is centred, the rows' own norms otherwise
-    const bool f16_range_ok = centred ? h->xh_c_ok : h->f16_ok;
+    bool f16_range_ok = centred ? h->xh_c_ok : h->f16_ok;
+    // Mid-size corpora and views (below 262,144 rows: offered the fp16 routes since round 4): only while ONE sampled span covers
+    // the view with the candidate list the fp16 keys need (twice / four times the split tiles') -- with k = 300 that list is a
+    // quarter of the lists' capacity, the sampled span ends short of 200k rows and the rest runs the classic schedule:
+    // 0.45 ms where the split tiles over the f32 rows take 0.15.  (Larger corpora: as before.)
+    if (cmode == LB_CAND_AUTO && n < 262144 && kc_in > 0) {
+        const int kc16 = std::min(std::min(kc_in * (h->dim > 1024 ? 4 : 2), std::max(1024, 2 * kc_in)), (int)(w->cap / 4));
+        const SamplePlan sp16 = sample_plan(n, kc16, w->cap);
+        if (!(sp16.on && sp16.span >= n)) f16_range_ok = false;
+    }
     // 1 .. 4 queries: the exact scan streams the f32 corpus (0.52 ms per 1M x 768); with the fp16 copy the candidate pass
     // streams half the bytes and the exact re-rank of 512 candidates costs 0.03 ms -- taken when the model says it is cheaper
     bool small_on_copy = false;
@@ -930,7 +939,9 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     // 0.124 with the sample and the thresholds as launches of their own, level at 150k-300k, 20 us ahead at 1M -- and on the
     // 16k-64k-row corpora that take a sampled threshold since round 4 its waits gave up: 17k rows at 16 queries, 40k at 32,
     // the batch redone exactly in 1 ms)
-    const bool fused = sp.on && use_narrow && nsplit && nq <= fused_max && nq <= 64 && n >= 131072;
+    // (and thresholds of rank up to 32: with k = 300 -- 1024 candidates, m = 48 -- the threshold workgroups outlast the waits of
+    // the corpus workgroups: 200k x 768 at 32 queries gave up on every search, 1.5 ms)
+    const bool fused = sp.on && use_narrow && nsplit && nq <= fused_max && nq <= 64 && n >= 131072 && sp.m <= 32;
     // a search over a row list on the persistent fp16 kernels: its candidate entries carry positions of the list
     const bool entries_pos = use_tall16 && rv.rowmap != nullptr &&
                              tall16_entries_are_positions(h->dim, nq, have_xh, true, mask != nullptr);
@@ -944,7 +955,9 @@ int search_batch_device(lb_gpu_index *h, Workspace *w, hipStream_t s, int nq, co
     // computes too, from the f32 rows about the same centre)
     const bool granule_sample = sp.on && use_tall16 && sp.count % 16 == 0 && (rv.rowmap == nullptr || entries_pos) &&
                                 ((have_xh && granule_on && nq > light_max) || dot_lb || (centred && nq > light_max));
-    const bool light_sample = sp.on && !fused && !granule_sample && nq <= light_max;
+    // (not in front of the split tiles: up to 32 queries they always ran fused, and the wave-per-row sample was never paired
+    // with them -- L2, k = 300, 8 queries over 50k rows: every query flagged and scanned)
+    const bool light_sample = sp.on && !fused && !granule_sample && nq <= light_max && !use_narrow;
     // Up to 128 queries on the one-tile kernel over the image, one span: the candidate launch turns the sample into the
     // thresholds ITSELF (its first nq workgroups, on shorter row ranges; kernels_gemm_tall16.hip, TAUIN) -- no threshold launch
     // and no gap behind it in front of the pass.
