@@ -155,3 +155,28 @@ def test_image_less_corpora_of_16k_to_64k_rows_run_separate_sample_launches(orac
             assert idx.last_fallbacks == 0, (n, nq)
         assert idx.fused_giveups == 0, n
         idx.Close()
+
+
+@pytest.mark.parametrize("image", [1, 0])
+def test_long_result_lists_on_mid_size_corpora(oracle, image):
+    """k = 300 (1024 candidates, thresholds of rank ~48) on 50k and 200k rows, the cells of tools/probe/small_corpus_grid.py
+    that fell back or gave up before the gates of round 4: the fused launch (waits gave up at 200k rows, 32 queries, every
+    search), the wave-per-row sample in front of the split tiles (L2, 8 queries over 50k rows: all flagged), the fp16
+    routes when one sampled span cannot cover the view.  Oracle lists, nothing left to the scan, no give-up."""
+    gpu_or_skip()
+    rng = np.random.default_rng(4321)
+    d, k = 128, 300
+    for metric, n in ((0, 50000), (1, 200000), (0, 200000)):
+        X = rng.random((n, d), dtype=F)
+        Q = rng.random((32, d), dtype=F)
+        idx = new_index(d, metric)
+        if not image:
+            idx.set_f16_image(0)
+        idx.Add(None, X)
+        for nq in (8, 32):
+            lab, dist = idx.SearchBatch(Q[:nq], k)
+            oi, od = oracle.search_batch(metric, Q[:nq], X, k, nthreads=8)
+            assert_same(lab, dist, oi, od, f"metric={metric} n={n} nq={nq} image={image}")
+            assert idx.last_fallbacks == 0, (metric, n, nq)
+        assert idx.fused_giveups == 0, (metric, n)
+        idx.Close()
