@@ -68,7 +68,7 @@ def test_sample_plan_invariants():
         pytest.skip(f"liblongbow_gpu_diag.so not loadable here: {e}")
     out = (C.c_longlong * 4)()
     seen_on = 0
-    for n in (1000, 65535, 65536, 10**5, 10**6, 2_500_000, 10**7, 10**8, 4 * 10**9):
+    for n in (1000, 16383, 16384, 20000, 65535, 65536, 10**5, 10**6, 2_500_000, 10**7, 10**8, 4 * 10**9):
         for keep in (1, 10, 100, 256, 512, 1024, 4096):
             for cap in (8192, 16384, 32768):
                 for count_max in (4096, 8192):
@@ -79,7 +79,7 @@ def test_sample_plan_invariants():
                     if not on:
                         continue
                     seen_on += 1
-                    assert n >= 65536 and 0 < span <= n
+                    assert n >= 16384 and 0 < span <= n  # (sampled thresholds start at 16,384 rows since round 4: 65,536 before)
                     assert count <= min(cap, count_max) and span >= 8 * count
                     assert 8 <= m <= 64
                     lam = keep * count / span
