@@ -180,3 +180,22 @@ def test_long_result_lists_on_mid_size_corpora(oracle, image):
             assert idx.last_fallbacks == 0, (metric, n, nq)
         assert idx.fused_giveups == 0, (metric, n)
         idx.Close()
+
+
+def test_k_300_on_a_large_corpus_takes_one_sampled_span(oracle):
+    """k = 300 over 600k rows on the library default: 16,384-entry lists (from 1,024 candidates), one sampled span, the fp16
+    image -- oracle lists for a batch and for a single query, nothing left to the exact scan."""
+    gpu_or_skip()
+    rng = np.random.default_rng(99)
+    n, d, k = 600_000, 32, 300
+    X = rng.random((n, d), dtype=F)
+    Q = rng.random((40, d), dtype=F)
+    idx = new_index(d, 1)
+    idx.Add(None, X)
+    assert idx.f16_image_bytes > 0
+    for nq in (1, 40):
+        lab, dist = idx.SearchBatch(Q[:nq], k)
+        oi, od = oracle.search_batch(1, Q[:nq], X, k, nthreads=8)
+        assert_same(lab, dist, oi, od, f"k=300 nq={nq}")
+        assert idx.last_fallbacks == 0
+    idx.Close()

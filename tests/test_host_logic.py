@@ -91,6 +91,23 @@ def test_sample_plan_invariants():
     assert seen_on > 50
 
 
+def test_long_result_lists_get_one_sampled_span():
+    """k = 241 .. 512 keeps 1,024 candidates, twice that on the fp16 routes.  With the 8,192-entry lists of rounds 1-3 the
+    sampled span of such a search ended short of a 1M-row corpus (the rest ran the classic schedule: 0.71 ms a query where
+    k = 100 took 0.29); with the 16,384-entry lists the index allots from 1,024 candidates one span covers it."""
+    import ctypes as C
+    from longbow_amd import _lib
+    try:
+        lib = _lib.load_diag()
+    except (RuntimeError, OSError) as e:
+        pytest.skip(f"liblongbow_gpu_diag.so not loadable here: {e}")
+    out = (C.c_longlong * 4)()
+    lib.lb_debug_sample_plan(1_000_000, 2048, 8192, 8192, out)
+    assert not out[0] or out[1] < 1_000_000      # the old geometry: no plan, or a span that ends short
+    lib.lb_debug_sample_plan(1_000_000, 2048, 16384, 8192, out)
+    assert out[0] and out[1] >= 1_000_000        # the new one: a single span
+
+
 def test_gpu_partition_packs_ring_shards_evenly():
     """GpuPartition: the reference's RingSharder with 8 ring shards per GPU, shards packed onto GPUs by the
     share of the hash space they own.  The id -> ring shard map stays the reference's; only shard -> GPU is
